@@ -1,0 +1,232 @@
+// Short-Weierstrass (a = 0) group arithmetic over bigfield.cuh, for the MSM hot path.
+//
+// The reference does every EC operation with the complete homogeneous-projective formulas of
+// Renes-Costello-Batina (icicle/include/icicle/curves/projective.h:73-188; mixed add = 11 muls +
+// 2 small-constant muls). The bucket-accumulation hot loop here uses extended-Jacobian "XYZZ"
+// accumulators instead (x = X/ZZ, y = Y/ZZZ; mixed add = 8M + 2S, no multiplication by b),
+// with the three exceptional inputs (empty accumulator, P+P, P+(-P)) peeled off into rare
+// divergent branches. Everything after accumulation (bucket reduction, window combine) is <2 % of
+// the work and uses the same complete projective addition as the reference, which has no
+// exceptional cases at all (identity = (0:1:0), projective.h:26).
+//
+// Bounds (units of p, see bigfield.cuh; machine-checked under -DBIGFIELD_BOUNDS):
+//   affine (Montgomery)  x <= 1.2, y <= 2.2         XYZZ  X <= 8, Y <= 4, ZZ,ZZZ <= 2
+//   projective           X,Y,Z <= 4
+#pragma once
+#include "bigfield.cuh"
+
+namespace icicle_hip {
+
+  template <class C>
+  struct EC {
+    using F = FieldOps<typename C::fq>;
+    using fe = typename F::fe;
+    static constexpr int N32 = F::N32;
+
+    struct Aff { // Montgomery coordinates; never the identity
+      fe x, y;
+    };
+    struct XYZZ {
+      fe x, y, zz, zzz;
+    };
+    struct Proj {
+      fe x, y, z;
+    };
+
+    static HD fe b3()
+    {
+      fe r;
+#pragma unroll
+      for (int i = 0; i < F::N; i++)
+        r.l[i] = C::B3[i];
+      BF_SET_BOUND(r, 1);
+      return r;
+    }
+    static HD Aff generator()
+    {
+      Aff g;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) {
+        g.x.l[i] = C::GX[i];
+        g.y.l[i] = C::GY[i];
+      }
+      BF_SET_BOUND(g.x, 1);
+      BF_SET_BOUND(g.y, 1);
+      return g;
+    }
+
+    // ---- affine points in memory -------------------------------------------------------------
+    // Reference layout Affine<F>{x,y}: 2*N32 words (curves/affine.h:9-34); identity is (0,0).
+    static HD bool words_are_zero(const uint32_t* w)
+    {
+      uint32_t o = 0;
+#pragma unroll
+      for (int i = 0; i < 2 * N32; i++)
+        o |= w[i];
+      return o == 0;
+    }
+    // packed Montgomery copy kept in HBM by the MSM (same 2*N32 words per point)
+    static HD Aff load_mont(const uint32_t* w)
+    {
+      Aff a;
+      a.x = F::unpack(w);
+      a.y = F::unpack(w + N32);
+      return a;
+    }
+    static HD Aff neg(const Aff& a)
+    {
+      Aff r;
+      r.x = a.x;
+      r.y = F::template neg<2>(a.y);
+      return r;
+    }
+    static HD Aff cneg(const Aff& a, bool negate)
+    {
+      Aff r;
+      r.x = a.x;
+      r.y = F::select(negate, F::template neg<2>(a.y), a.y);
+      return r;
+    }
+
+    // ---- XYZZ --------------------------------------------------------------------------------
+    // 2*(x,y) for an affine point (dbl-2008-s-1 with ZZ1 = ZZZ1 = 1, a = 0)
+    static HD XYZZ dbl_affine(const Aff& p)
+    {
+      XYZZ r;
+      fe U = F::dbl(p.y);                // <= 4.4
+      fe V = F::sqr(U);                  // ~1.2
+      fe W = F::mul(U, V);               // ~1.1
+      fe S = F::mul(p.x, V);             // ~1.1
+      fe X2 = F::sqr(p.x);               // ~1.1
+      fe M = F::add(F::dbl(X2), X2);     // 3x^2 <= 3.3
+      fe S2 = F::dbl(S);                 // <= 2.2
+      r.x = F::template sub<4>(F::sqr(M), S2);             // <= 5.1
+      fe t = F::template sub<8>(S, r.x);                   // <= 9.1
+      r.y = F::template sub<2>(F::mul(M, t), F::mul(W, p.y)); // <= 3.3
+      r.zz = V;
+      r.zzz = W;
+      return r;
+    }
+
+    // acc += b (b affine, not the identity). `empty` is the accumulator's "is identity" flag.
+    // madd-2008-s: 8M + 2S.
+    static HD void madd(XYZZ& acc, bool& empty, const Aff& b)
+    {
+      if (empty) {
+        acc.x = b.x;
+        acc.y = b.y;
+        acc.zz = F::one();
+        acc.zzz = F::one();
+        empty = false;
+        return;
+      }
+      fe U2 = F::mul(b.x, acc.zz);
+      fe S2 = F::mul(b.y, acc.zzz);
+      fe P = F::template sub<8>(U2, acc.x); // <= 9.1
+      fe R = F::template sub<4>(S2, acc.y); // <= 5.1
+      fe PP = F::sqr(P);                    // <= 1.7
+      if (F::maybe_zero_mulout(PP)) {
+        if (F::is_zero(P)) { // same x: either b == acc (double) or b == -acc (cancel)
+          if (F::is_zero(R)) {
+            acc = dbl_affine(b);
+          } else {
+            empty = true;
+          }
+          return;
+        }
+      }
+      fe PPP = F::mul(P, PP);               // ~1.2
+      fe Q = F::mul(acc.x, PP);             // ~1.2
+      fe t = F::add(PPP, F::dbl(Q));        // <= 3.6
+      fe X3 = F::template sub<4>(F::sqr(R), t); // <= 5.3
+      fe d = F::template sub<8>(Q, X3);     // <= 9.2
+      fe Y3 = F::template sub<2>(F::mul(R, d), F::mul(acc.y, PPP)); // <= 3.4
+      acc.zz = F::mul(acc.zz, PP);
+      acc.zzz = F::mul(acc.zzz, PPP);
+      acc.x = X3;
+      acc.y = Y3;
+    }
+
+    // ---- complete projective arithmetic (identity = (0:1:0)) -----------------------------------
+    static HD Proj proj_identity()
+    {
+      Proj r;
+      r.x = F::zero();
+      r.y = F::one();
+      r.z = F::zero();
+      return r;
+    }
+    static HD Proj to_proj(const XYZZ& a, bool empty)
+    {
+      if (empty) return proj_identity();
+      Proj r;
+      r.x = F::mul(a.x, a.zzz);
+      r.y = F::mul(a.y, a.zz);
+      r.z = F::mul(a.zz, a.zzz);
+      return r;
+    }
+    static HD Proj to_proj(const Aff& a)
+    {
+      Proj r;
+      r.x = a.x;
+      r.y = a.y;
+      r.z = F::one();
+      return r;
+    }
+    // Renes-Costello-Batina 2016, Algorithm 7 (a = 0), the formula the reference uses
+    // (projective.h:101-143): 12M + 2 mul-by-3b, valid for ALL inputs.
+    static HD Proj add(const Proj& p, const Proj& q)
+    {
+      fe t0 = F::mul(p.x, q.x);
+      fe t1 = F::mul(p.y, q.y);
+      fe t2 = F::mul(p.z, q.z);
+      fe t3 = F::mul(F::add(p.x, p.y), F::add(q.x, q.y));
+      t3 = F::template sub<4>(t3, F::add(t0, t1)); // X1Y2 + X2Y1
+      fe t4 = F::mul(F::add(p.y, p.z), F::add(q.y, q.z));
+      t4 = F::template sub<4>(t4, F::add(t1, t2)); // Y1Z2 + Y2Z1
+      fe t5 = F::mul(F::add(p.x, p.z), F::add(q.x, q.z));
+      t5 = F::template sub<4>(t5, F::add(t0, t2)); // X1Z2 + X2Z1
+      fe t0_3 = F::add(F::dbl(t0), t0);            // 3 X1X2
+      fe bt2 = F::mul(b3(), t2);
+      fe z3 = F::add(t1, bt2);
+      fe t1m = F::template sub<2>(t1, bt2);
+      fe y3 = F::mul(b3(), t5);
+      Proj r;
+      r.x = F::template sub<2>(F::mul(t3, t1m), F::mul(t4, y3));
+      r.y = F::add(F::mul(t1m, z3), F::mul(y3, t0_3));
+      r.z = F::add(F::mul(z3, t4), F::mul(t0_3, t3));
+      return r;
+    }
+    static HD Proj dbl(const Proj& p) { return add(p, p); }
+
+    // k * p for a small unsigned k (bucket reduction segment offsets), MSB-first double-and-add
+    static HD Proj mul_small(const Proj& p, uint32_t k)
+    {
+      Proj r = proj_identity();
+      bool started = false;
+      for (int bit = 31; bit >= 0; bit--) {
+        if (started) r = dbl(r);
+        if ((k >> bit) & 1) {
+          r = started ? add(r, p) : p;
+          started = true;
+        }
+      }
+      return r;
+    }
+
+    // Projective{x,y,z} -> reference layout (3*N32 canonical words, non-Montgomery)
+    static HD void store_proj_canonical(uint32_t* w, const Proj& p)
+    {
+      F::to_canonical(w, p.x);
+      F::to_canonical(w + N32, p.y);
+      F::to_canonical(w + 2 * N32, p.z);
+    }
+    static HD void store_proj_refmont(uint32_t* w, const Proj& p)
+    {
+      F::to_refmont(w, p.x);
+      F::to_refmont(w + N32, p.y);
+      F::to_refmont(w + 2 * N32, p.z);
+    }
+  };
+
+} // namespace icicle_hip

@@ -1,0 +1,175 @@
+"""TEST INFRASTRUCTURE ONLY (never imported by icicle_amd/).
+
+Pure-Python big-integer restatement of the definitions the MSM / NTT hot path must satisfy, used
+to pin both the C oracle (oracle/oracle.c) and the reference build (oracle/_ref) on small cases:
+
+  * MSM:  result = sum_i s_i * P_i on y^2 = x^3 + b over F_q, affine identity = (0,0)
+          (reference: icicle/include/icicle/curves/affine.h:16,28; projective.h:55-59 to_affine;
+           icicle/backend/cpu/src/curve/cpu_msm.hpp:431-443 for the batch/precompute layout).
+  * NTT:  X[k] = sum_j x[j] w^(jk), inverse scaled by N^-1, coset / ordering / batch layouts as in
+          icicle/backend/cpu/include/ntt_cpu.h:70-232, 247-306.
+
+Curve and field parameters are the published ones; tests/test_consts.py cross-checks them against
+the reference headers when /root/reference is available.
+"""
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Curve:
+    name: str
+    q: int  # base field modulus
+    r: int  # scalar field modulus (group order)
+    b: int
+    gx: int
+    gy: int
+    limbs_q: int  # 32-bit limbs per base-field element
+    limbs_r: int
+
+
+BN254 = Curve(
+    "bn254",
+    21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    3,
+    1,
+    2,
+    8,
+    8,
+)
+BLS12_381 = Curve(
+    "bls12_381",
+    0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+    0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+    4,
+    0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+    0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1,
+    12,
+    8,
+)
+CURVES = {"bn254": BN254, "bls12_381": BLS12_381}
+
+INF = (0, 0)  # the reference's affine identity encoding
+
+
+def ec_add(c: Curve, p, q):
+    if p == INF:
+        return q
+    if q == INF:
+        return p
+    x1, y1 = p
+    x2, y2 = q
+    if x1 == x2:
+        if (y1 + y2) % c.q == 0:
+            return INF
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, c.q) % c.q
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, c.q) % c.q
+    x3 = (lam * lam - x1 - x2) % c.q
+    return (x3, (lam * (x1 - x3) - y1) % c.q)
+
+
+def ec_neg(c: Curve, p):
+    return INF if p == INF else (p[0], (-p[1]) % c.q)
+
+
+def ec_mul(c: Curve, k: int, p):
+    k %= c.r
+    acc = INF
+    while k:
+        if k & 1:
+            acc = ec_add(c, acc, p)
+        p = ec_add(c, p, p)
+        k >>= 1
+    return acc
+
+
+def on_curve(c: Curve, p):
+    return p == INF or (p[1] * p[1] - p[0] ** 3 - c.b) % c.q == 0
+
+
+def msm_naive(c: Curve, scalars, points):
+    acc = INF
+    for s, p in zip(scalars, points):
+        acc = ec_add(c, acc, ec_mul(c, s, p))
+    return acc
+
+
+def proj_to_affine(c: Curve, x, y, z):
+    """Projective{x,y,z} -> affine, with the reference's convention inverse(0) = 0 => (0,0)."""
+    if z % c.q == 0:
+        return INF
+    zi = pow(z, -1, c.q)
+    return (x * zi % c.q, y * zi % c.q)
+
+
+def gen_points(c: Curve, n: int, k0: int = 1):
+    """n distinct affine points (k0 + i) * G, by a running affine add."""
+    g = (c.gx, c.gy)
+    p = ec_mul(c, k0, g)
+    out = []
+    for _ in range(n):
+        out.append(p)
+        p = ec_add(c, p, g)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# small NTT fields
+@dataclass(frozen=True)
+class NttField:
+    name: str
+    p: int
+    rou: int  # root of unity of order 2^two_adicity (reference fp_config::rou)
+    two_adicity: int
+
+
+BABYBEAR = NttField("babybear", 0x78000001, 0x89, 27)
+KOALABEAR = NttField("koalabear", 0x7F000001, 0x6AC49F88, 24)
+BN254_FR = NttField(
+    "bn254", BN254.r, 0x2A3C09F0A58A7E8500E0A7EB8EF62ABC402D111E41112ED49BD61B6E725B19F0, 28
+)
+NTT_FIELDS = {"babybear": BABYBEAR, "koalabear": KOALABEAR, "bn254": BN254_FR}
+
+
+def omega(f: NttField, logn: int) -> int:
+    """ModArith::omega (modular_arithmetic.h:61-73): rou^(2^(two_adicity-logn))."""
+    if logn == 0:
+        return 1
+    assert logn <= f.two_adicity
+    return pow(f.rou, 1 << (f.two_adicity - logn), f.p)
+
+
+def bitrev(i: int, logn: int) -> int:
+    r = 0
+    for _ in range(logn):
+        r = (r << 1) | (i & 1)
+        i >>= 1
+    return r
+
+
+def ntt_naive(f: NttField, x, w_n: int, inverse: bool = False, coset_gen: int = 1, ordering: str = "NN"):
+    """O(N^2) definition of the reference transform for ONE row:
+    ordering[0]=='R': memory index bitrev(j) holds logical x[j]; ordering[1]=='R': logical X[k]
+    stored at bitrev(k). 'M' behaves like 'N' (what the CPU backend does).
+    forward: x[j] *= g^j first; inverse: result[j] *= g^-j * N^-1 after."""
+    n = len(x)
+    logn = n.bit_length() - 1
+    p = f.p
+    xin = list(x)
+    if ordering[0] == "R":
+        xin = [x[bitrev(j, logn)] for j in range(n)]
+    if not inverse and coset_gen != 1:
+        xin = [v * pow(coset_gen, j, p) % p for j, v in enumerate(xin)]
+    w = pow(w_n, -1, p) if inverse else w_n
+    out = [sum(xin[j] * pow(w, j * k, p) for j in range(n)) % p for k in range(n)]
+    if inverse:
+        ninv = pow(n, -1, p)
+        ginv = pow(coset_gen, -1, p)
+        out = [v * ninv * pow(ginv, j, p) % p for j, v in enumerate(out)]
+    if ordering[1] == "R":
+        o2 = [0] * n
+        for k in range(n):
+            o2[bitrev(k, logn)] = out[k]
+        out = o2
+    return out

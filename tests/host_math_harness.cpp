@@ -1,0 +1,154 @@
+// TEST-ONLY host build of the device arithmetic headers (bigfield.cuh / ec.cuh / smallfield.cuh)
+// with the debug bound tracker on (-DBIGFIELD_BOUNDS). Lets the CPU test-suite check the exact
+// code the kernels run against Python big-int arithmetic and the reference oracle, without a GPU.
+// Not part of the shipped library; nothing in icicle_amd/ links it.
+#include <cstdint>
+#include <cstring>
+#include "../icicle_amd/csrc/ec.cuh"
+#include "../icicle_amd/csrc/smallfield.cuh"
+
+using namespace icicle_hip;
+
+namespace {
+  template <class PR>
+  int field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out)
+  {
+    using F = FieldOps<PR>;
+    typename F::fe x = F::from_canonical(a), y = F::from_canonical(b), r;
+    switch (op) {
+    case 0: r = F::mul(x, y); break;
+    case 1: r = F::sqr(x); break;
+    case 2: r = F::add(x, y); break;
+    case 3: r = F::template sub<2>(x, y); break;
+    case 4: r = F::template neg<2>(x); break;
+    case 5: { // stress lazy bounds: ((x+y)+(x+y)) * (x - y + 8p) ...
+      auto s = F::add(F::add(x, y), F::add(x, y));
+      auto d = F::template sub<8>(x, F::add(F::add(y, y), F::add(y, y)));
+      r = F::mul(s, d); // 2(x+y)(x-4y)
+      break;
+    }
+    case 6: { // from reference-Montgomery words -> canonical
+      r = F::from_refmont(a);
+      break;
+    }
+    case 7: { // canonical -> reference-Montgomery words
+      F::to_refmont(out, x);
+      return 0;
+    }
+    case 8: { // is_zero(x - y)
+      out[0] = F::is_zero(F::template sub<2>(x, y)) ? 1 : 0;
+      return 0;
+    }
+    default: return -1;
+    }
+    F::to_canonical(out, r);
+    return 0;
+  }
+
+  // points: affine canonical words (x,y); identity (0,0)
+  template <class C>
+  int ec_op(int op, const uint32_t* pts, int n, const uint32_t* aux, uint32_t* out)
+  {
+    using E = EC<C>;
+    using F = typename E::F;
+    constexpr int N32 = E::N32;
+    auto load = [&](const uint32_t* w) {
+      typename E::Aff a;
+      a.x = F::from_canonical(w);
+      a.y = F::from_canonical(w + N32);
+      // mimic the packed-Montgomery HBM copy: reduce + pack + unpack
+      uint32_t tmp[2 * N32];
+      F::pack(tmp, F::reduce(a.x));
+      F::pack(tmp + N32, F::reduce(a.y));
+      return E::load_mont(tmp);
+    };
+    switch (op) {
+    case 0: { // XYZZ accumulate all points (aux[i]&1 = negate), output projective canonical
+      typename E::XYZZ acc;
+      bool empty = true;
+      for (int i = 0; i < n; i++) {
+        const uint32_t* w = pts + (size_t)i * 2 * N32;
+        if (E::words_are_zero(w)) continue;
+        auto a = E::cneg(load(w), aux && (aux[i] & 1));
+        E::madd(acc, empty, a);
+      }
+      E::store_proj_canonical(out, E::to_proj(acc, empty));
+      return 0;
+    }
+    case 1: { // complete projective sum of all points (identity allowed)
+      auto acc = E::proj_identity();
+      for (int i = 0; i < n; i++) {
+        const uint32_t* w = pts + (size_t)i * 2 * N32;
+        if (E::words_are_zero(w)) {
+          acc = E::add(acc, E::proj_identity());
+          continue;
+        }
+        acc = E::add(acc, E::to_proj(E::cneg(load(w), aux && (aux[i] & 1))));
+      }
+      E::store_proj_canonical(out, acc);
+      return 0;
+    }
+    case 2: { // mul_small: aux[0] * pts[0]
+      auto p = E::words_are_zero(pts) ? E::proj_identity() : E::to_proj(load(pts));
+      E::store_proj_canonical(out, E::mul_small(p, aux[0]));
+      return 0;
+    }
+    case 3: { // generator
+      E::store_proj_canonical(out, E::to_proj(E::generator()));
+      return 0;
+    }
+    case 4: { // repeated doubling: 2^aux[0] * pts[0] via complete dbl
+      auto p = E::to_proj(load(pts));
+      for (uint32_t i = 0; i < aux[0]; i++)
+        p = E::dbl(p);
+      E::store_proj_canonical(out, p);
+      return 0;
+    }
+    default: return -1;
+    }
+  }
+} // namespace
+
+extern "C" int host_field_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out)
+{
+  switch (field) {
+  case 0: return field_op<bn254_fq_params>(op, a, b, out);
+  case 1: return field_op<bn254_fr_params>(op, a, b, out);
+  case 2: return field_op<bls12_381_fq_params>(op, a, b, out);
+  case 3: return field_op<bls12_381_fr_params>(op, a, b, out);
+  }
+  return -1;
+}
+
+extern "C" int host_ec_op(int curve, int op, const uint32_t* pts, int n, const uint32_t* aux, uint32_t* out)
+{
+  switch (curve) {
+  case 0: return ec_op<bn254_g1>(op, pts, n, aux, out);
+  case 1: return ec_op<bls12_381_g1>(op, pts, n, aux, out);
+  }
+  return -1;
+}
+
+// 31-bit fields
+extern "C" int host_small_op(int field, int op, uint32_t a, uint32_t b, uint32_t* out)
+{
+  auto run = [&](auto tag) {
+    using S = SmallField<decltype(tag)>;
+    uint32_t x = S::to_mont(a), y = S::to_mont(b), r;
+    switch (op) {
+    case 0: r = S::mul(x, y); break;
+    case 1: r = S::add(x, y); break;
+    case 2: r = S::sub(x, y); break;
+    case 3: r = S::pow(x, b); break; // x^b (b plain integer)
+    case 4: r = S::inv(x); break;
+    default: return -1;
+    }
+    *out = S::from_mont(r);
+    return 0;
+  };
+  switch (field) {
+  case 0: return run(babybear_params{});
+  case 1: return run(koalabear_params{});
+  }
+  return -1;
+}

@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Generate icicle_amd/csrc/field_consts.h: per-field constants for the 29-bit-radix Montgomery
+big-field arithmetic (bigfield.cuh) and the 31-bit NTT fields.
+
+Moduli / generators / roots of unity are the published curve parameters; they are cross-checked
+against the reference headers (icicle/include/icicle/fields/snark_fields/*.h, stark_fields/*.h,
+curves/params/*.h) by tests/test_consts.py when /root/reference is present.
+"""
+import sys
+
+BIG = {
+    # name: (modulus, limbs32)
+    "bn254_fq": (21888242871839275222246405745257275088696311157297823662689037894645226208583, 8),
+    "bn254_fr": (21888242871839275222246405745257275088548364400416034343698204186575808495617, 8),
+    "bls12_381_fq": (
+        0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+        12,
+    ),
+    "bls12_381_fr": (0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, 8),
+}
+RB = 29
+
+
+def limbs(x, n, rb=RB, top_unbounded=True):
+    out = []
+    for i in range(n):
+        if i == n - 1 and top_unbounded:
+            out.append(x)
+        else:
+            out.append(x & ((1 << rb) - 1))
+            x >>= rb
+    assert out[-1] < (1 << 32)
+    return out
+
+
+def arr(v):
+    return "{" + ", ".join("0x%08xu" % x for x in v) + "}"
+
+
+def gen_big(name, p, l32):
+    bits = p.bit_length()
+    nl = (bits + 6 + RB - 1) // RB  # >= 7 bits of slack: values up to 64p never overflow, R/p >= 2^7... checked below
+    R = 1 << (RB * nl)
+    assert R // p >= 64, (name, R // p)  # lazy-reduction slack, see bigfield.cuh bounds
+    pinv = (-pow(p, -1, 1 << RB)) % (1 << RB)
+    r32 = 1 << (32 * l32)
+    s = []
+    s.append(f"struct {name}_params {{")
+    s.append(f"  static constexpr int NL = {nl};      // {RB}-bit limbs")
+    s.append(f"  static constexpr int NL32 = {l32};   // packed 32-bit limbs (reference storage<{l32}>)")
+    s.append(f"  static constexpr int NBITS = {bits};")
+    s.append(f"  static constexpr uint32_t PINV = 0x{pinv:08x}u; // -p^-1 mod 2^{RB}")
+    s.append(f"  static constexpr uint32_t P[{nl}] = {arr(limbs(p, nl))};")
+    s.append(f"  static constexpr uint32_t P32[{l32}] = {arr(limbs(p, l32, 32))};")
+    for k in (2, 4, 8, 16):
+        s.append(f"  static constexpr uint32_t P{k}[{nl}] = {arr(limbs(k * p, nl))}; // {k}p")
+    s.append(f"  static constexpr uint32_t ONE[{nl}] = {arr(limbs(R % p, nl))}; // R mod p")
+    s.append(f"  static constexpr uint32_t R2[{nl}] = {arr(limbs(R * R % p, nl))}; // R^2 mod p")
+    # reference-Montgomery (x * 2^(32*l32)) -> canonical, via montmul(x, C): C = R / 2^(32 l32)
+    c1 = R * pow(r32, -1, p) % p
+    s.append(f"  static constexpr uint32_t REFMONT_TO_CANON[{nl}] = {arr(limbs(c1, nl))}; // R/2^{32*l32}")
+    c2 = R * R * pow(r32, -1, p) % p
+    s.append(f"  static constexpr uint32_t REFMONT_TO_MONT[{nl}] = {arr(limbs(c2, nl))}; // R^2/2^{32*l32}")
+    c3 = r32 % p  # our-Montgomery x*R -> reference-Montgomery: montmul(xR, C) = x*C => C = 2^(32 l32)
+    s.append(f"  static constexpr uint32_t MONT_TO_REFMONT[{nl}] = {arr(limbs(c3, nl))}; // 2^{32*l32} mod p")
+    s.append("};")
+    return "\n".join(s)
+
+
+CURVES = {
+    # name: (base field, scalar field, weierstrass b, generator x, generator y)
+    "bn254": ("bn254_fq", "bn254_fr", 3, 1, 2),
+    "bls12_381": (
+        "bls12_381_fq",
+        "bls12_381_fr",
+        4,
+        0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+        0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1,
+    ),
+}
+
+
+def gen_curve(name, fq, fr, b, gx, gy):
+    p, _ = BIG[fq]
+    nl = (p.bit_length() + 6 + RB - 1) // RB
+    R = 1 << (RB * nl)
+    assert (gy * gy - gx * gx * gx - b) % p == 0
+    s = []
+    s.append(f"struct {name}_g1 {{")
+    s.append(f"  using fq = {fq}_params;")
+    s.append(f"  using fr = {fr}_params;")
+    s.append(f"  static constexpr uint32_t B3[{nl}] = {arr(limbs(3 * b * R % p, nl))}; // 3*b, Montgomery")
+    s.append(f"  static constexpr uint32_t GX[{nl}] = {arr(limbs(gx * R % p, nl))}; // generator, Montgomery")
+    s.append(f"  static constexpr uint32_t GY[{nl}] = {arr(limbs(gy * R % p, nl))};")
+    s.append("};")
+    return "\n".join(s)
+
+
+SMALL = {
+    # name: (p, rou (order 2^two_adicity), ext nonresidue)
+    "babybear": (0x78000001, 0x89),
+    "koalabear": (0x7F000001, 0x6AC49F88),
+}
+
+
+def gen_small(name, p, rou):
+    two_adicity = ((p - 1) & -(p - 1)).bit_length() - 1
+    assert pow(rou, 1 << two_adicity, p) == 1 and pow(rou, 1 << (two_adicity - 1), p) != 1
+    R = 1 << 32
+    s = []
+    s.append(f"struct {name}_params {{")
+    s.append(f"  static constexpr uint32_t P = 0x{p:08x}u;")
+    s.append(f"  static constexpr uint32_t PINV = 0x{pow(p, -1, R):08x}u;    // p^-1 mod 2^32")
+    s.append(f"  static constexpr uint32_t NPINV = 0x{(-pow(p, -1, R)) % R:08x}u;   // -p^-1 mod 2^32")
+    s.append(f"  static constexpr uint32_t ONE = 0x{R % p:08x}u;     // R mod p")
+    s.append(f"  static constexpr uint32_t R2 = 0x{R * R % p:08x}u;      // R^2 mod p")
+    s.append(f"  static constexpr uint32_t ROU = 0x{rou:08x}u;     // root of unity of order 2^TWO_ADICITY")
+    s.append(f"  static constexpr int TWO_ADICITY = {two_adicity};")
+    s.append("};")
+    return "\n".join(s)
+
+
+def main():
+    out = []
+    out.append("// GENERATED by tools/gen_consts.py -- do not edit.")
+    out.append("// Constants for the 29-bit-radix Montgomery representation used on device (bigfield.cuh)")
+    out.append("// and for the 31-bit NTT fields (smallfield.cuh).")
+    out.append("#pragma once")
+    out.append("#include <cstdint>")
+    out.append("namespace icicle_hip {")
+    out.append(f"static constexpr int RB = {RB};")
+    out.append(f"static constexpr uint32_t RB_MASK = 0x{(1 << RB) - 1:08x}u;")
+    for name, (p, l32) in BIG.items():
+        out.append(gen_big(name, p, l32))
+    for name, (fq, fr, b, gx, gy) in CURVES.items():
+        out.append(gen_curve(name, fq, fr, b, gx, gy))
+    for name, (p, rou) in SMALL.items():
+        out.append(gen_small(name, p, rou))
+    out.append("} // namespace icicle_hip")
+    text = "\n".join(out) + "\n"
+    path = sys.argv[1] if len(sys.argv) > 1 else "icicle_amd/csrc/field_consts.h"
+    with open(path, "w") as f:
+        f.write(text)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
