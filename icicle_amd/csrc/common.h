@@ -1,0 +1,150 @@
+// Shared host-side plumbing for libicicle_hip.so: error translation, per-thread active device,
+// stream-ordered temporaries, kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <variant>
+#include <vector>
+#include "../../include/icicle_hip.h"
+
+namespace icicle_hip {
+
+  // hipError_t -> eIcicleError, modelled on the reference's CUDA table
+  // (icicle/backend/cuda_pqc/include/gpu-utils/error_translation.h:6-33)
+  inline icicle_error_t translate(hipError_t e, icicle_error_t dflt)
+  {
+    switch (e) {
+    case hipSuccess: return ICICLE_SUCCESS;
+    case hipErrorInvalidDevice: return ICICLE_INVALID_DEVICE;
+    case hipErrorOutOfMemory: return ICICLE_OUT_OF_MEMORY;
+    case hipErrorInvalidDevicePointer: return ICICLE_INVALID_POINTER;
+    case hipErrorInvalidValue: return dflt == ICICLE_SUCCESS ? ICICLE_INVALID_ARGUMENT : dflt;
+    default: return dflt == ICICLE_SUCCESS ? ICICLE_INVALID_ARGUMENT : dflt;
+    }
+  }
+
+#define HIP_TRY(expr, dflt)                                                                                            \
+  do {                                                                                                                 \
+    hipError_t _e = (expr);                                                                                            \
+    if (_e != hipSuccess) {                                                                                            \
+      (void)hipGetLastError();                                                                                         \
+      if (icicle_hip::verbose())                                                                                       \
+        fprintf(stderr, "[icicle_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__);     \
+      return icicle_hip::translate(_e, dflt);                                                                          \
+    }                                                                                                                  \
+  } while (0)
+
+#define ICICLE_TRY(expr)                                                                                               \
+  do {                                                                                                                 \
+    icicle_error_t _ie = (expr);                                                                                       \
+    if (_ie != ICICLE_SUCCESS) return _ie;                                                                             \
+  } while (0)
+
+  bool verbose();
+  bool sync_debug(); // ICICLE_HIP_SYNC_DEBUG=1: synchronise + check after every kernel launch
+
+// after every kernel launch: catches launch-time errors always, execution errors in debug mode
+#define LAUNCH_CHECK(name, stream)                                                                                     \
+  do {                                                                                                                 \
+    hipError_t _le = hipGetLastError();                                                                                \
+    if (_le == hipSuccess && icicle_hip::sync_debug()) _le = hipStreamSynchronize(stream);                             \
+    if (_le != hipSuccess) {                                                                                           \
+      fprintf(stderr, "[icicle_hip] kernel %s failed: %s (%s:%d)\n", name, hipGetErrorString(_le), __FILE__, __LINE__); \
+      return icicle_hip::translate(_le, ICICLE_INVALID_ARGUMENT);                                                      \
+    }                                                                                                                  \
+  } while (0)
+
+  // thread-local active device (reference: thread_local sCurDevice, src/device_api.cpp:86-102).
+  int current_device_id();
+  // makes the calling thread's HIP context match its icicle device; call at the top of every API
+  icicle_error_t bind_current_device();
+
+  // opaque ConfigExtension (reference: include/icicle/config_extension.h:12-46)
+  struct ConfigExt {
+    std::unordered_map<std::string, std::variant<int, bool>> kv;
+    bool has(const char* k) const { return kv.find(k) != kv.end(); }
+    int get_int(const char* k, int dflt) const
+    {
+      auto it = kv.find(k);
+      if (it == kv.end()) return dflt;
+      if (auto p = std::get_if<int>(&it->second)) return *p;
+      return dflt;
+    }
+    bool get_bool(const char* k, bool dflt) const
+    {
+      auto it = kv.find(k);
+      if (it == kv.end()) return dflt;
+      if (auto p = std::get_if<bool>(&it->second)) return *p;
+      return dflt;
+    }
+  };
+
+  // Workspace arenas for temporaries. hipMallocAsync/hipFreeAsync was the first choice, but on this
+  // ROCm 7.2 / gfx950 stack large pool allocations came back with multi-MiB ranges whose contents
+  // were lost between two kernels of the same stream (profiles/r01_notes.md), so temporaries now come
+  // from cached hipMalloc arenas, PyTorch-caching-allocator style:
+  //   * acquire(bytes, stream): reuse a free arena of this device that is big enough (or grow one);
+  //     if its previous user was another stream, the new stream waits on the arena's last-use event
+  //     (hipStreamWaitEvent) -- the host never blocks, so is_async calls stay asynchronous;
+  //   * release(stream): record the last-use event on the stream.
+  struct Arena {
+    void* base = nullptr;
+    size_t cap = 0;
+    size_t used = 0;
+    int device = 0;
+    bool busy = false;
+    hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;
+  };
+  Arena* arena_acquire(size_t bytes, hipStream_t st); // nullptr on allocation failure
+  void arena_release(Arena* a, hipStream_t st);
+  void arena_trim(int device); // frees all idle arenas of a device (tests / release_domain)
+
+  // One temporary = one arena lease (released, i.e. made reusable in stream order, on destruction).
+  class TempBuf
+  {
+  public:
+    TempBuf() = default;
+    TempBuf(const TempBuf&) = delete;
+    TempBuf& operator=(const TempBuf&) = delete;
+    ~TempBuf() { release(); }
+    hipError_t alloc(size_t bytes, hipStream_t s)
+    {
+      release();
+      m_stream = s;
+      m_arena = arena_acquire(bytes ? bytes : 16, s);
+      return m_arena ? hipSuccess : hipErrorOutOfMemory;
+    }
+    void release()
+    {
+      if (m_arena) {
+        arena_release(m_arena, m_stream);
+        m_arena = nullptr;
+      }
+    }
+    template <class T>
+    T* as() const
+    {
+      return reinterpret_cast<T*>(ptr());
+    }
+    void* ptr() const { return m_arena ? m_arena->base : nullptr; }
+
+  private:
+    Arena* m_arena = nullptr;
+    hipStream_t m_stream = nullptr;
+  };
+
+  // ---- dominant-kernel timing with hipEvents on the launch stream (bench.py roofline figure) ----
+  struct KernelTimer {
+    static bool enabled();
+    // records start/stop events around a launch region on `s` and queues them for later readout
+    static void begin(int which, hipStream_t s);
+    static void end(int which, hipStream_t s);
+  };
+
+} // namespace icicle_hip

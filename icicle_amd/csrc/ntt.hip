@@ -1,0 +1,468 @@
+// NTT for gfx950 over 31-bit fields (BabyBear, KoalaBear).
+//
+// Reference semantics: icicle/backend/cpu/include/ntt_cpu.h:70-232 (run), :247-306 (input
+// reorder), :317-364 (coset), cpu_ntt_domain.h:65-110,614-654 (domain), ntt_task.h:1208-1236
+// (radix-2 DIT, inverse twiddle = table[max - idx], 1/N folded into the last layer).
+// SURVEY.md App. C lists the fine print (orderings, coset, batch layouts, kNM/kMN = natural).
+//
+// Design (not the CPU's Winograd-leaf hierarchy): N = N0*N1[*N2] is split into at most three
+// passes of <= 2^12-point sub-transforms. A pass stages a [2^s x T] tile (T adjacent columns, so
+// every HBM access is a run of T contiguous elements) in LDS, runs the s radix-2 stages there,
+// applies the inter-pass twiddle w_M^(j*K) on the way out, and the LAST pass scatters straight
+// into natural order (runs of T again) -- so an NN transform is exactly P reads + P writes of the
+// data with no separate transpose / bit-reverse pass. Data stays in canonical form throughout:
+// twiddles are stored in Montgomery form, and montmul(canonical, w*R) = canonical.
+#include "common.h"
+#include "smallfield.cuh"
+#include <algorithm>
+#include <cmath>
+
+namespace icicle_hip {
+
+  // ---- per-device, per-field twiddle domain (reference: one global domain per device) ----------
+  struct NttDomain {
+    uint32_t* tw = nullptr; // tw[i] = w_max^i (Montgomery), i < max_size
+    int log_max = -1;
+    uint32_t root = 0; // canonical w_max
+  };
+  template <class PR>
+  struct DomainStore {
+    static std::mutex& mtx()
+    {
+      static std::mutex m;
+      return m;
+    }
+    static std::map<int, NttDomain>& map()
+    {
+      static std::map<int, NttDomain> m;
+      return m;
+    }
+  };
+
+  template <class PR>
+  __global__ __launch_bounds__(256) void k_gen_twiddles(uint32_t* __restrict__ tw, uint32_t root_mont, size_t n)
+  {
+    using S = SmallField<PR>;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) tw[i] = S::pow(root_mont, (uint64_t)i);
+  }
+
+  // ---- pass descriptor -------------------------------------------------------------------------
+  struct PassDesc {
+    int s;            // log2 of the sub-transform length L
+    int T;            // tile width (columns per block)
+    uint32_t ntiles;  // tiles per row-transform
+    // tile -> (a, c0): tile index = a * tiles_per_a + ct ;
+    uint32_t tiles_per_a;
+    // load/store addressing inside one logical row: addr = base + k*sk + t*st
+    uint64_t in_base_a, in_base_ct, in_sk, in_st;     // base = a*in_base_a + ct*in_base_ct
+    uint64_t out_sk, out_st;                          // out base computed in-kernel (needs digit reversal)
+    int is_last;      // last pass: natural-order scatter + optional 1/N scaling
+    int pidx;         // pass index
+    // twiddle after this pass (not last): exponent = jnext * K, table stride tstride
+    uint64_t tw_stride;  // max / M
+    uint32_t cprime;     // C' = C / N_{p+1}; jnext = (c0 + t) / C'
+    uint32_t n0, n1;     // N_0, N_1 (for K and digit reversal)
+  };
+
+  struct NttLaunch {
+    uint32_t logn;
+    uint64_t n;
+    uint32_t nbatch;   // number of independent lane-transforms (batch * lanes)
+    uint32_t lanes;    // 1 (scalar) or 4 (quartic extension)
+    uint64_t bs;       // offset(b') = (b'/lanes)*bs + (b'%lanes)
+    uint64_t es;       // element stride
+    int in_rev, out_rev; // bit-reversed logical->memory maps
+    int inverse;
+    uint32_t log_max;
+    uint32_t ninv_mont;  // N^-1 (Montgomery) for inverse
+    int coset;           // multiply by powers table (forward: on first load; inverse: on last store)
+  };
+
+  __device__ __forceinline__ uint64_t bitrev64(uint64_t x, uint32_t bits)
+  {
+    return bits == 0 ? 0 : (__brevll(x) >> (64 - bits));
+  }
+
+  // One pass. grid = (ntiles, nbatch). Dynamic LDS: L*T u32.
+  template <class PR>
+  __global__ __launch_bounds__(1024) void k_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ coset_pow, PassDesc pd, NttLaunch nl)
+  {
+    using S = SmallField<PR>;
+    extern __shared__ uint32_t tile[];
+    const uint32_t L = 1u << pd.s, T = pd.T;
+    const uint32_t bprime = blockIdx.y;
+    const uint64_t boff = (uint64_t)(bprime / nl.lanes) * nl.bs + (bprime % nl.lanes);
+    const uint32_t a = blockIdx.x / pd.tiles_per_a, ct = blockIdx.x % pd.tiles_per_a;
+    const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
+    const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
+    const uint32_t tot = L * T;
+
+    // ---- load: logical (k,t) -> LDS row bitrev_s(k)
+    for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+      const uint32_t t = e % T, k = e / T;
+      uint64_t addr = in_base + (uint64_t)k * pd.in_sk + (uint64_t)t * pd.in_st; // logical index in the row
+      uint64_t maddr = nl.in_rev && pd.pidx == 0 ? bitrev64(addr, nl.logn) : addr;
+      uint32_t v = in[boff + maddr * nl.es];
+      if (nl.coset && !nl.inverse && pd.pidx == 0) v = S::mul(v, coset_pow[addr]);
+      tile[(__brev(k) >> (32 - pd.s)) * T + t] = v;
+    }
+    __syncthreads();
+
+    // ---- s radix-2 DIT stages in LDS; w_L^e = tw[e * (max/L)], inverse uses tw[max - idx]
+    const uint32_t lstride_log = nl.log_max - pd.s;
+    for (int q = 0; q < pd.s; q++) {
+      const uint32_t half = 1u << q;
+      for (uint32_t id = threadIdx.x; id < tot / 2; id += blockDim.x) {
+        const uint32_t t = id % T, bf = id / T;
+        const uint32_t pos = bf & (half - 1);
+        const uint32_t i = ((bf >> q) << (q + 1)) + pos;
+        uint64_t widx = ((uint64_t)pos << (pd.s - 1 - q)) << lstride_log;
+        if (nl.inverse) widx = (((uint64_t)1 << nl.log_max) - widx) & max_mask;
+        const uint32_t w = tw[widx];
+        const uint32_t u = tile[i * T + t];
+        const uint32_t v = S::mul(tile[(i + half) * T + t], w);
+        tile[i * T + t] = S::add(u, v);
+        tile[(i + half) * T + t] = S::sub(u, v);
+      }
+      __syncthreads();
+    }
+
+    // ---- store
+    for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+      const uint32_t t = e % T, k = e / T;
+      uint32_t v = tile[k * T + t];
+      uint64_t oaddr;
+      if (!pd.is_last) {
+        // in place: same slot as the load; multiply by w_M^(jnext*K)
+        oaddr = in_base + (uint64_t)k * pd.in_sk + (uint64_t)t * pd.in_st;
+        const uint64_t c = (uint64_t)ct * T + t;            // column index within [0,C)
+        const uint64_t jnext = c / pd.cprime;
+        const uint64_t K = (pd.pidx == 0) ? (uint64_t)k : ((uint64_t)a + (uint64_t)pd.n0 * k);
+        uint64_t widx = (jnext * K * pd.tw_stride) & max_mask;
+        if (nl.inverse) widx = (((uint64_t)1 << nl.log_max) - widx) & max_mask;
+        v = S::mul(v, tw[widx]);
+      } else {
+        // natural-order scatter: K = digitrev(a_t) + (N/L)*k
+        uint64_t K0;
+        if (pd.pidx <= 1) {
+          K0 = (uint64_t)ct * T + t;                        // P=1: 0 ; P=2: a = k0
+        } else {
+          const uint64_t k0 = (uint64_t)ct * T + t, k1 = a; // P=3: tile over k0, a carries k1
+          K0 = k0 + (uint64_t)pd.n0 * k1;
+        }
+        oaddr = K0 + (uint64_t)k * pd.out_sk;
+        if (nl.inverse) {
+          v = S::mul(v, nl.ninv_mont);
+          if (nl.coset) v = S::mul(v, coset_pow[oaddr]);
+        }
+        if (nl.out_rev) oaddr = bitrev64(oaddr, nl.logn);
+      }
+      out[boff + oaddr * nl.es] = v;
+    }
+  }
+
+  // coset powers: pw[j] = g^j (forward) or g^-j (inverse), Montgomery
+  template <class PR>
+  __global__ __launch_bounds__(256) void k_coset_powers(uint32_t* __restrict__ pw, uint32_t g_mont, uint64_t n)
+  {
+    using S = SmallField<PR>;
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t j0 = t * 16;
+    if (j0 >= n) return;
+    uint32_t v = S::pow(g_mont, j0);
+    for (int q = 0; q < 16 && j0 + q < n; q++) {
+      pw[j0 + q] = v;
+      v = S::mul(v, g_mont);
+    }
+  }
+
+  // n == 1 and pure-copy helper with strides
+  __global__ void k_copy_strided(const uint32_t* in, uint32_t* out, uint64_t count)
+  {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < count) out[i] = in[i];
+  }
+
+  template <class PR>
+  static icicle_error_t ntt_init_domain_run(const uint32_t* root, const icicle_ntt_init_domain_config_t* cfg)
+  {
+    using S = SmallField<PR>;
+    if (!root || !cfg) return ICICLE_INVALID_POINTER;
+    ICICLE_TRY(bind_current_device());
+    const int dev = current_device_id();
+    std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
+    auto& dom = DomainStore<PR>::map()[dev];
+    if (dom.tw) return ICICLE_SUCCESS; // already initialised: silent success (cpu_ntt_domain.h:69)
+    const uint32_t r = *root;
+    if (r == 0 || r >= PR::P) return ICICLE_INVALID_ARGUMENT;
+    // order of the root by repeated squaring (cpu_ntt_domain.h:78-94)
+    uint32_t x = S::to_mont(r);
+    int log_max = 0;
+    while (x != S::one() && log_max <= PR::TWO_ADICITY) {
+      x = S::mul(x, x);
+      log_max++;
+    }
+    if (x != S::one()) return ICICLE_INVALID_ARGUMENT; // not a 2^k-th root of unity
+    hipStream_t st = (hipStream_t)cfg->stream;
+    const size_t n = (size_t)1 << log_max;
+    uint32_t* tw = nullptr;
+    HIP_TRY(hipMalloc(&tw, n * 4), ICICLE_ALLOCATION_FAILED);
+    k_gen_twiddles<PR><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(tw, S::to_mont(r), n);
+    LAUNCH_CHECK("k_gen_twiddles", st);
+    HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
+    if (!cfg->is_async) HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    dom.tw = tw;
+    dom.log_max = log_max;
+    dom.root = r;
+    return ICICLE_SUCCESS;
+  }
+
+  template <class PR>
+  static icicle_error_t ntt_release_domain_run()
+  {
+    ICICLE_TRY(bind_current_device());
+    const int dev = current_device_id();
+    std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
+    auto it = DomainStore<PR>::map().find(dev);
+    if (it != DomainStore<PR>::map().end()) {
+      if (it->second.tw) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(it->second.tw);
+      }
+      DomainStore<PR>::map().erase(it);
+    }
+    return ICICLE_SUCCESS;
+  }
+
+  template <class PR>
+  static icicle_error_t ntt_rou_from_domain_run(uint64_t logn, uint32_t* rou)
+  {
+    using S = SmallField<PR>;
+    if (!rou) return ICICLE_INVALID_POINTER;
+    const int dev = current_device_id();
+    std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
+    auto it = DomainStore<PR>::map().find(dev);
+    if (it == DomainStore<PR>::map().end() || !it->second.tw) return ICICLE_INVALID_ARGUMENT;
+    if ((int64_t)logn > it->second.log_max) return ICICLE_INVALID_ARGUMENT;
+    // twiddles[max >> logn] (cpu_ntt_domain.h:644-654)
+    uint32_t x = S::to_mont(it->second.root);
+    for (int i = 0; i < it->second.log_max - (int)logn; i++)
+      x = S::mul(x, x);
+    *rou = S::from_mont(x);
+    return ICICLE_SUCCESS;
+  }
+
+  template <class PR>
+  static icicle_error_t get_root_of_unity_run(uint64_t max_size, uint32_t* rou)
+  {
+    using S = SmallField<PR>;
+    if (!rou || max_size == 0) return ICICLE_INVALID_ARGUMENT;
+    uint32_t logn = 0;
+    while (((uint64_t)1 << logn) < max_size)
+      logn++; // ceil(log2(max_size)), src/ntt.cpp:57
+    if ((int)logn > PR::TWO_ADICITY) return ICICLE_INVALID_ARGUMENT;
+    uint32_t x = S::to_mont(PR::ROU);
+    for (int i = 0; i < PR::TWO_ADICITY - (int)logn; i++)
+      x = S::mul(x, x);
+    *rou = logn == 0 ? 1u : S::from_mont(x);
+    return ICICLE_SUCCESS;
+  }
+
+  static void split_logn(int logn, int* parts, int* np)
+  {
+    const int SMAX = 12;
+    const int P = std::max(1, (logn + SMAX - 1) / SMAX);
+    for (int i = 0; i < P; i++)
+      parts[i] = logn / P + (i < logn % P ? 1 : 0);
+    *np = P;
+  }
+
+  template <class PR>
+  static icicle_error_t ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, uint32_t lanes)
+  {
+    using S = SmallField<PR>;
+    if (!cfg) return ICICLE_INVALID_POINTER;
+    if (size <= 0 || (size & (size - 1)) != 0) return ICICLE_INVALID_ARGUMENT; // cpu_ntt_main.h:38-41
+    if (!input || !output) return ICICLE_INVALID_POINTER;
+    if (dir != ICICLE_NTT_FORWARD && dir != ICICLE_NTT_INVERSE) return ICICLE_INVALID_ARGUMENT;
+    if (cfg->ordering < 0 || cfg->ordering > ICICLE_kMN) return ICICLE_INVALID_ARGUMENT;
+    const int batch = std::max(1, cfg->batch_size);
+    ICICLE_TRY(bind_current_device());
+    const int dev = current_device_id();
+    NttDomain dom;
+    {
+      std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
+      auto it = DomainStore<PR>::map().find(dev);
+      if (it == DomainStore<PR>::map().end() || !it->second.tw) return ICICLE_INVALID_ARGUMENT; // domain not initialised
+      dom = it->second;
+    }
+    int logn = 0;
+    while ((1 << logn) < size)
+      logn++;
+    if (logn > dom.log_max) return ICICLE_INVALID_ARGUMENT;
+    if (cfg->coset_gen == 0 || cfg->coset_gen >= PR::P) return ICICLE_INVALID_ARGUMENT;
+
+    hipStream_t st = (hipStream_t)cfg->stream;
+    const uint64_t n = (uint64_t)size;
+    const uint64_t total = n * batch * lanes;
+    const size_t bytes = total * 4;
+
+    TempBuf d_in_tmp, d_out_tmp, d_pw;
+    const uint32_t* d_in = input;
+    uint32_t* d_out = output;
+    if (!cfg->are_inputs_on_device) {
+      HIP_TRY(d_in_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(hipMemcpyAsync(d_in_tmp.ptr(), input, bytes, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
+      d_in = d_in_tmp.as<uint32_t>();
+    }
+    if (!cfg->are_outputs_on_device) {
+      // reuse the staged input buffer as output when both are host-side (in-place on device)
+      if (!cfg->are_inputs_on_device) {
+        d_out = d_in_tmp.as<uint32_t>();
+      } else {
+        HIP_TRY(d_out_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+        d_out = d_out_tmp.as<uint32_t>();
+      }
+    }
+
+    NttLaunch nl;
+    nl.logn = logn;
+    nl.n = n;
+    nl.nbatch = (uint32_t)batch * lanes;
+    nl.lanes = lanes;
+    if (cfg->columns_batch) { // element j of transform b at (j*batch + b)*lanes + lane (ntt_cpu.h:250,274-275)
+      nl.bs = lanes;
+      nl.es = (uint64_t)batch * lanes;
+    } else {
+      nl.bs = n * lanes;
+      nl.es = lanes;
+    }
+    const int ord = cfg->ordering;
+    nl.in_rev = (ord == ICICLE_kRN || ord == ICICLE_kRR);
+    nl.out_rev = (ord == ICICLE_kNR || ord == ICICLE_kRR);
+    nl.inverse = (dir == ICICLE_NTT_INVERSE);
+    nl.log_max = dom.log_max;
+    {
+      uint32_t two_inv = S::inv(S::to_mont(2));
+      nl.ninv_mont = S::pow(two_inv, (uint64_t)logn);
+    }
+    nl.coset = (cfg->coset_gen != 1);
+    if (nl.coset) {
+      HIP_TRY(d_pw.alloc(n * 4, st), ICICLE_ALLOCATION_FAILED);
+      uint32_t g = S::to_mont(cfg->coset_gen);
+      if (nl.inverse) g = S::inv(g);
+      k_coset_powers<PR><<<(unsigned)((n / 16 + 256) / 256), 256, 0, st>>>(d_pw.as<uint32_t>(), g, n);
+      LAUNCH_CHECK("k_coset_powers", st);
+    }
+
+    int parts[3], P;
+    split_logn(logn, parts, &P);
+    // P >= 2: passes 0..P-2 run in a work buffer (the last pass permutes across tiles, so it can
+    // never be in place; this also makes input == output legal, test_mod_arithmetic_api.h:627,679)
+    TempBuf d_work;
+    uint32_t* W = nullptr;
+    if (P >= 2) {
+      HIP_TRY(d_work.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+      W = d_work.as<uint32_t>();
+    }
+    HIP_TRY(hipFuncSetAttribute((const void*)k_ntt_pass<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072), ICICLE_INVALID_ARGUMENT);
+
+    KernelTimer::begin(1, st);
+    for (int p = 0; p < P; p++) {
+      const uint32_t* src = (p == 0) ? d_in : W;
+      uint32_t* dst = (p == P - 1) ? d_out : W;
+      PassDesc pd{};
+      pd.s = parts[p];
+      pd.pidx = p;
+      pd.is_last = (p == P - 1);
+      const uint64_t L = (uint64_t)1 << pd.s;
+      uint64_t A = 1, C = 1;
+      for (int q = 0; q < p; q++)
+        A <<= parts[q];
+      for (int q = p + 1; q < P; q++)
+        C <<= parts[q];
+      pd.n0 = 1u << parts[0];
+      pd.n1 = P > 1 ? (1u << parts[1]) : 1;
+      const uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, 32768 / L));
+      if (!pd.is_last) {
+        pd.T = (int)std::min<uint64_t>(tmax, C);
+        pd.tiles_per_a = (uint32_t)(C / pd.T);
+        pd.ntiles = (uint32_t)(A * pd.tiles_per_a);
+        pd.in_base_a = L * C;
+        pd.in_base_ct = pd.T;
+        pd.in_sk = C;
+        pd.in_st = 1;
+        int lm = 0; // M = N_0..N_{p+1}
+        for (int q = 0; q <= p + 1; q++)
+          lm += parts[q];
+        pd.tw_stride = (uint64_t)1 << (dom.log_max - lm);
+        pd.cprime = (uint32_t)(C >> parts[p + 1]);
+      } else {
+        // tile over k0 (the slowest digit of a); for P==3 `a` in the kernel carries k1
+        const uint64_t n0 = P >= 2 ? ((uint64_t)1 << parts[0]) : 1;
+        const uint64_t n1 = P == 3 ? ((uint64_t)1 << parts[1]) : 1;
+        pd.T = (int)std::min<uint64_t>(tmax, n0);
+        pd.tiles_per_a = (uint32_t)(n0 / pd.T);
+        pd.ntiles = (uint32_t)(n1 * pd.tiles_per_a);
+        // row index = k0*n1 + k1 ; row start = row*L
+        pd.in_base_a = L;               // a = k1
+        pd.in_base_ct = (uint64_t)pd.T * n1 * L;
+        pd.in_sk = 1;
+        pd.in_st = n1 * L;
+        pd.out_sk = n >> pd.s;
+        pd.out_st = 1;
+      }
+      const uint32_t tot = (uint32_t)(L * pd.T);
+      const unsigned threads = std::max(64u, std::min(1024u, tot / 2));
+      k_ntt_pass<PR><<<dim3(pd.ntiles, nl.nbatch), threads, tot * 4, st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, nl);
+      LAUNCH_CHECK("k_ntt_pass", st);
+    }
+    KernelTimer::end(1, st);
+    HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
+
+    if (!cfg->are_outputs_on_device) {
+      HIP_TRY(hipMemcpyAsync(output, d_out, bytes, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
+      HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    } else if (!cfg->is_async) {
+      HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    }
+    return ICICLE_SUCCESS;
+  }
+
+} // namespace icicle_hip
+
+using namespace icicle_hip;
+
+#define GUARDED(expr)                                                                                                  \
+  try {                                                                                                                \
+    return (expr);                                                                                                     \
+  } catch (...) {                                                                                                      \
+    return ICICLE_INVALID_ARGUMENT;                                                                                    \
+  }
+
+#define DEFINE_NTT_U32(F)                                                                                              \
+  extern "C" icicle_error_t F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* config, uint32_t* output) \
+  {                                                                                                                    \
+    GUARDED(ntt_run<F##_params>(input, size, dir, config, output, 1));                                                 \
+  }                                                                                                                    \
+  extern "C" icicle_error_t F##_extension_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* config, uint32_t* output) \
+  {                                                                                                                    \
+    GUARDED(ntt_run<F##_params>(input, size, dir, config, output, 4));                                                 \
+  }                                                                                                                    \
+  extern "C" icicle_error_t F##_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config) \
+  {                                                                                                                    \
+    GUARDED(ntt_init_domain_run<F##_params>(primitive_root, config));                                                  \
+  }                                                                                                                    \
+  extern "C" icicle_error_t F##_ntt_release_domain(void) { GUARDED(ntt_release_domain_run<F##_params>()); }            \
+  extern "C" icicle_error_t F##_get_root_of_unity(uint64_t max_size, uint32_t* rou)                                    \
+  {                                                                                                                    \
+    GUARDED(get_root_of_unity_run<F##_params>(max_size, rou));                                                         \
+  }                                                                                                                    \
+  extern "C" icicle_error_t F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou)                            \
+  {                                                                                                                    \
+    GUARDED(ntt_rou_from_domain_run<F##_params>(logn, rou));                                                           \
+  }
+
+DEFINE_NTT_U32(babybear)
+DEFINE_NTT_U32(koalabear)

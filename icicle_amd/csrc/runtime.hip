@@ -1,0 +1,486 @@
+// icicle-runtime C ABI over HIP: device selection, stream-ordered memory, copies, streams.
+// Mirrors the behaviour of the reference runtime + a DeviceAPI implementation in one layer
+// (icicle/src/runtime.cpp:15-286, icicle/src/device_api.cpp:17-143, include/icicle/device_api.h:30-196;
+// behavioural requirements read off icicle/tests/test_device_api.cpp:17-259).
+#include "common.h"
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <optional>
+
+namespace icicle_hip {
+
+  bool verbose()
+  {
+    static const bool v = (getenv("ICICLE_HIP_VERBOSE") != nullptr);
+    return v;
+  }
+
+  bool sync_debug()
+  {
+    static const bool v = (getenv("ICICLE_HIP_SYNC_DEBUG") != nullptr);
+    return v;
+  }
+
+  // ---- device state -------------------------------------------------------------------------
+  static std::atomic<int> g_default_device{0};
+  static thread_local int t_device = -1; // -1: thread never called icicle_set_device -> default
+
+  int current_device_id() { return t_device >= 0 ? t_device : g_default_device.load(); }
+
+  static int device_count_cached()
+  {
+    static const int n = []() {
+      int c = 0;
+      if (hipGetDeviceCount(&c) != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+      }
+      return c;
+    }();
+    return n;
+  }
+
+  icicle_error_t bind_current_device()
+  {
+    const int id = current_device_id();
+    if (id < 0 || id >= device_count_cached()) return ICICLE_INVALID_DEVICE;
+    HIP_TRY(hipSetDevice(id), ICICLE_INVALID_DEVICE);
+    return ICICLE_SUCCESS;
+  }
+
+  static bool is_hip_type(const icicle_device_t* d) { return d && strncmp(d->type, "HIP", sizeof(d->type)) == 0; }
+
+  // ---- allocation tracker (include/icicle/memory_tracker.h:16-44): interior pointers resolve ----
+  struct Alloc {
+    size_t size;
+    int device;
+  };
+  static std::mutex g_track_mtx;
+  static std::map<uintptr_t, Alloc>& tracker()
+  {
+    static std::map<uintptr_t, Alloc> m;
+    return m;
+  }
+  static void track_add(void* p, size_t size, int dev)
+  {
+    std::lock_guard<std::mutex> g(g_track_mtx);
+    tracker()[(uintptr_t)p] = {size, dev};
+  }
+  static void track_remove(void* p)
+  {
+    std::lock_guard<std::mutex> g(g_track_mtx);
+    tracker().erase((uintptr_t)p);
+  }
+  static std::optional<Alloc> track_identify(const void* p)
+  {
+    std::lock_guard<std::mutex> g(g_track_mtx);
+    auto& m = tracker();
+    auto it = m.upper_bound((uintptr_t)p);
+    if (it == m.begin()) return std::nullopt;
+    --it;
+    if ((uintptr_t)p < it->first + it->second.size) return it->second;
+    return std::nullopt;
+  }
+
+  // ---- workspace arenas ----------------------------------------------------------------------
+  static std::mutex g_arena_mtx;
+  static std::vector<Arena*>& arenas()
+  {
+    static std::vector<Arena*> v;
+    return v;
+  }
+  Arena* arena_acquire(size_t bytes, hipStream_t st)
+  {
+    const int dev = current_device_id();
+    std::lock_guard<std::mutex> g(g_arena_mtx);
+    Arena* best = nullptr;
+    Arena* small = nullptr;
+    for (Arena* a : arenas()) {
+      if (a->busy || a->device != dev) continue;
+      if (a->cap >= bytes) {
+        if (!best || a->cap < best->cap) best = a;
+      } else if (!small || a->cap > small->cap) {
+        small = a;
+      }
+    }
+    if (!best) {
+      // grow: drop the largest idle-but-too-small arena (after its last user finished) and allocate
+      if (small) {
+        if (small->last_use) (void)hipEventSynchronize(small->last_use);
+        (void)hipFree(small->base);
+        small->base = nullptr;
+        small->cap = 0;
+        best = small;
+      } else {
+        best = new Arena();
+        best->device = dev;
+        if (hipEventCreateWithFlags(&best->last_use, hipEventDisableTiming) != hipSuccess) {
+          (void)hipGetLastError();
+          delete best;
+          return nullptr;
+        }
+        arenas().push_back(best);
+      }
+      const size_t want = (bytes + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);
+      if (hipMalloc(&best->base, want) != hipSuccess) {
+        (void)hipGetLastError();
+        best->base = nullptr;
+        best->cap = 0;
+        return nullptr;
+      }
+      best->cap = want;
+      best->last_stream = st;
+    } else if (best->last_stream != st && best->last_use) {
+      (void)hipStreamWaitEvent(st, best->last_use, 0);
+    }
+    best->busy = true;
+    best->used = 0;
+    return best;
+  }
+  void arena_release(Arena* a, hipStream_t st)
+  {
+    std::lock_guard<std::mutex> g(g_arena_mtx);
+    (void)hipEventRecord(a->last_use, st);
+    a->last_stream = st;
+    a->busy = false;
+  }
+  void arena_trim(int device)
+  {
+    std::lock_guard<std::mutex> g(g_arena_mtx);
+    for (Arena* a : arenas()) {
+      if (a->busy || a->device != device || !a->base) continue;
+      if (a->last_use) (void)hipEventSynchronize(a->last_use);
+      (void)hipFree(a->base);
+      a->base = nullptr;
+      a->cap = 0;
+    }
+  }
+
+  // ---- kernel timing ---------------------------------------------------------------------------
+  static std::atomic<bool> g_timing{false};
+  struct TimedSpan {
+    hipEvent_t a, b;
+  };
+  static std::mutex g_time_mtx;
+  static std::deque<TimedSpan> g_spans[2];
+  static thread_local hipEvent_t g_open[2];
+
+  bool KernelTimer::enabled() { return g_timing.load(std::memory_order_relaxed); }
+  void KernelTimer::begin(int which, hipStream_t s)
+  {
+    if (!enabled()) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    g_open[which] = e;
+  }
+  void KernelTimer::end(int which, hipStream_t s)
+  {
+    if (!enabled() || !g_open[which]) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    std::lock_guard<std::mutex> g(g_time_mtx);
+    g_spans[which].push_back({g_open[which], e});
+    g_open[which] = nullptr;
+  }
+
+} // namespace icicle_hip
+
+using namespace icicle_hip;
+
+extern "C" {
+
+const char* icicle_hip_version(void) { return "icicle_hip 0.1 (gfx950)"; }
+
+icicle_error_t icicle_hip_enable_kernel_timing(bool enable)
+{
+  g_timing.store(enable);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_hip_kernel_timing(int which, bool reset, double* total_ms, int* launches)
+{
+  if (which < 0 || which > 1 || !total_ms || !launches) return ICICLE_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> g(g_time_mtx);
+  double tot = 0;
+  int n = 0;
+  for (auto& sp : g_spans[which]) {
+    (void)hipEventSynchronize(sp.b);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      tot += ms;
+      n++;
+    }
+  }
+  *total_ms = tot;
+  *launches = n;
+  if (reset) {
+    for (auto& sp : g_spans[which]) {
+      (void)hipEventDestroy(sp.a);
+      (void)hipEventDestroy(sp.b);
+    }
+    g_spans[which].clear();
+  }
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_load_backend(const char*, bool) { return ICICLE_SUCCESS; }
+icicle_error_t icicle_load_backend_from_env_or_default(void) { return ICICLE_SUCCESS; }
+
+icicle_error_t icicle_set_device(const icicle_device_t* device)
+{
+  if (!is_hip_type(device)) return ICICLE_INVALID_DEVICE;
+  if (device->id < 0 || device->id >= device_count_cached()) return ICICLE_INVALID_DEVICE;
+  HIP_TRY(hipSetDevice(device->id), ICICLE_INVALID_DEVICE);
+  t_device = device->id;
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_set_default_device(const icicle_device_t* device)
+{
+  if (!is_hip_type(device)) return ICICLE_INVALID_DEVICE;
+  if (device->id < 0 || device->id >= device_count_cached()) return ICICLE_INVALID_DEVICE;
+  g_default_device.store(device->id);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_get_active_device(icicle_device_t* device)
+{
+  if (!device) return ICICLE_INVALID_POINTER;
+  memset(device->type, 0, sizeof(device->type));
+  strcpy(device->type, "HIP");
+  device->id = current_device_id();
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_is_host_memory(const void* ptr)
+{
+  return track_identify(ptr) ? ICICLE_INVALID_POINTER : ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_is_active_device_memory(const void* ptr)
+{
+  auto a = track_identify(ptr);
+  if (!a) return ICICLE_INVALID_POINTER;
+  return a->device == current_device_id() ? ICICLE_SUCCESS : ICICLE_INVALID_POINTER;
+}
+
+icicle_error_t icicle_get_device_count(int* device_count)
+{
+  if (!device_count) return ICICLE_INVALID_POINTER;
+  *device_count = device_count_cached();
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_malloc(void** ptr, size_t size)
+{
+  if (!ptr) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(bind_current_device());
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size > total_b) return ICICLE_OUT_OF_MEMORY;
+  HIP_TRY(hipMalloc(ptr, size ? size : 1), ICICLE_ALLOCATION_FAILED);
+  track_add(*ptr, size ? size : 1, current_device_id());
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_malloc_async(void** ptr, size_t size, icicleStreamHandle stream)
+{
+  if (!ptr) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(bind_current_device());
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size > total_b) return ICICLE_OUT_OF_MEMORY;
+  HIP_TRY(hipMallocAsync(ptr, size ? size : 1, (hipStream_t)stream), ICICLE_ALLOCATION_FAILED);
+  track_add(*ptr, size ? size : 1, current_device_id());
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_free(void* ptr)
+{
+  auto a = track_identify(ptr);
+  if (!a) return ICICLE_INVALID_DEVICE; // "trying to release host memory" (src/runtime.cpp:74-77)
+  // memory of a non-active device: switch, release, switch back (src/runtime.cpp:87-92)
+  const int cur = current_device_id();
+  HIP_TRY(hipSetDevice(a->device), ICICLE_INVALID_DEVICE);
+  hipError_t e = hipFree(ptr);
+  (void)hipSetDevice(cur);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return ICICLE_DEALLOCATION_FAILED;
+  }
+  track_remove(ptr);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_free_async(void* ptr, icicleStreamHandle stream)
+{
+  auto a = track_identify(ptr);
+  if (!a) return ICICLE_INVALID_DEVICE;
+  if (a->device != current_device_id()) return ICICLE_INVALID_DEVICE; // src/runtime.cpp:107-113
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipFreeAsync(ptr, (hipStream_t)stream), ICICLE_DEALLOCATION_FAILED);
+  track_remove(ptr);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_get_available_memory(size_t* total, size_t* free)
+{
+  if (!total || !free) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemGetInfo(free, total), ICICLE_INVALID_DEVICE);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_memset(void* ptr, int value, size_t size)
+{
+  if (icicle_is_active_device_memory(ptr) != ICICLE_SUCCESS) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemset(ptr, value, size), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_memset_async(void* ptr, int value, size_t size, icicleStreamHandle stream)
+{
+  if (icicle_is_active_device_memory(ptr) != ICICLE_SUCCESS) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemsetAsync(ptr, value, size, (hipStream_t)stream), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+// direction inferred from the tracker; untracked = host (src/runtime.cpp:152-185)
+static icicle_error_t copy_kind(void* dst, const void* src, hipMemcpyKind* kind)
+{
+  auto d = track_identify(dst), s = track_identify(src);
+  const int cur = current_device_id();
+  if ((d && d->device != cur) || (s && s->device != cur)) return ICICLE_INVALID_POINTER;
+  *kind = (!d && !s) ? hipMemcpyHostToHost : (s && !d) ? hipMemcpyDeviceToHost : (!s && d) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_copy(void* dst, const void* src, size_t size)
+{
+  hipMemcpyKind kind;
+  ICICLE_TRY(copy_kind(dst, src, &kind));
+  if (kind == hipMemcpyHostToHost) {
+    memcpy(dst, src, size);
+    return ICICLE_SUCCESS;
+  }
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemcpy(dst, src, size, kind), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_copy_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
+{
+  hipMemcpyKind kind;
+  ICICLE_TRY(copy_kind(dst, src, &kind));
+  if (kind == hipMemcpyHostToHost) {
+    memcpy(dst, src, size);
+    return ICICLE_SUCCESS;
+  }
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemcpyAsync(dst, src, size, kind, (hipStream_t)stream), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_copy_to_host(void* dst, const void* src, size_t size)
+{
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_copy_to_host_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
+{
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t)stream), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_copy_to_device(void* dst, const void* src, size_t size)
+{
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_copy_to_device_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
+{
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, (hipStream_t)stream), ICICLE_COPY_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_create_stream(icicleStreamHandle* stream)
+{
+  if (!stream) return ICICLE_INVALID_POINTER;
+  ICICLE_TRY(bind_current_device());
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
+  *stream = (icicleStreamHandle)s;
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_destroy_stream(icicleStreamHandle stream)
+{
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream), ICICLE_STREAM_DESTRUCTION_FAILED);
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_stream_synchronize(icicleStreamHandle stream)
+{
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream), ICICLE_SYNCHRONIZATION_FAILED);
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_device_synchronize(void)
+{
+  ICICLE_TRY(bind_current_device());
+  HIP_TRY(hipDeviceSynchronize(), ICICLE_SYNCHRONIZATION_FAILED);
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_get_device_properties(icicle_device_properties_t* p)
+{
+  if (!p) return ICICLE_INVALID_POINTER;
+  p->using_host_memory = false;
+  p->num_memory_regions = 0;
+  p->supports_pinned_memory = true;
+  return ICICLE_SUCCESS;
+}
+
+icicle_error_t icicle_is_device_available(const icicle_device_t* dev)
+{
+  return (is_hip_type(dev) && device_count_cached() > 0) ? ICICLE_SUCCESS : ICICLE_INVALID_DEVICE;
+}
+
+icicle_error_t icicle_get_registered_devices(char* output, size_t output_size)
+{
+  if (!output || output_size < 4) return ICICLE_INVALID_ARGUMENT;
+  strcpy(output, "HIP");
+  return ICICLE_SUCCESS;
+}
+
+// ---- ConfigExtension (src/config_extension.cpp:7-37); never throws across the C boundary ----
+icicle_config_extension_t* create_config_extension(void) { return (icicle_config_extension_t*)new ConfigExt(); }
+void destroy_config_extension(icicle_config_extension_t* ext) { delete (ConfigExt*)ext; }
+void config_extension_set_int(icicle_config_extension_t* ext, const char* key, int value)
+{
+  if (ext && key) ((ConfigExt*)ext)->kv[key] = value;
+}
+void config_extension_set_bool(icicle_config_extension_t* ext, const char* key, bool value)
+{
+  if (ext && key) ((ConfigExt*)ext)->kv[key] = value;
+}
+int config_extension_get_int(const icicle_config_extension_t* ext, const char* key)
+{
+  return (ext && key) ? ((const ConfigExt*)ext)->get_int(key, 0) : 0;
+}
+bool config_extension_get_bool(const icicle_config_extension_t* ext, const char* key)
+{
+  return (ext && key) ? ((const ConfigExt*)ext)->get_bool(key, false) : false;
+}
+icicle_config_extension_t* clone_config_extension(const icicle_config_extension_t* ext)
+{
+  return ext ? (icicle_config_extension_t*)new ConfigExt(*(const ConfigExt*)ext) : nullptr;
+}
+
+} // extern "C"

@@ -1,0 +1,67 @@
+"""msm() / precompute_bases(): mirror of wrappers/rust/icicle-core/src/msm/mod.rs:90-207.
+
+Arrays are numpy uint32 in the reference's memory layout: scalars [batch*N, 8]; affine bases
+[M, 2*L] (x then y, identity = all zeros); projective results [batch, 3*L] (L = 8 bn254, 12 bls12_381).
+Device-resident operands are passed as runtime.DeviceVec or raw integer device pointers.
+"""
+import ctypes
+import numpy as np
+from ._lib import lib, check, MSMConfig
+from .runtime import DeviceVec
+
+LIMBS = {"bn254": 8, "bls12_381": 12}
+SCALAR_LIMBS = 8
+
+
+def _ptr(x):
+    if isinstance(x, DeviceVec):
+        return x.ptr, True
+    if isinstance(x, int):
+        return x, True
+    assert isinstance(x, np.ndarray) and x.dtype == np.uint32 and x.flags["C_CONTIGUOUS"], "need contiguous uint32 ndarray"
+    return x.ctypes.data, False
+
+
+def msm(curve: str, scalars, bases, cfg: MSMConfig = None, results=None, msm_size: int = None):
+    """results[b] = sum_i scalars[b*N+i] * bases[...]. Returns `results` (host ndarray unless a DeviceVec was given)."""
+    L = LIMBS[curve]
+    cfg = cfg or MSMConfig.default()
+    sp, s_dev = _ptr(scalars)
+    bp, b_dev = _ptr(bases)
+    cfg.are_scalars_on_device = s_dev
+    cfg.are_points_on_device = b_dev
+    if msm_size is None:
+        assert isinstance(scalars, np.ndarray), "msm_size is required for device scalars"
+        total = scalars.size // SCALAR_LIMBS
+        assert total % max(1, cfg.batch_size) == 0, "scalars length must be a multiple of batch_size"
+        msm_size = total // max(1, cfg.batch_size)
+    if results is None:
+        results = np.zeros((max(1, cfg.batch_size), 3 * L), dtype=np.uint32)
+    rp, r_dev = _ptr(results)
+    cfg.are_results_on_device = r_dev
+    check(getattr(lib, f"{curve}_msm")(sp, bp, msm_size, ctypes.byref(cfg), rp), f"{curve}_msm")
+    return results
+
+
+def precompute_bases(curve: str, bases, cfg: MSMConfig, output=None, nof_bases: int = None):
+    L = LIMBS[curve]
+    bp, b_dev = _ptr(bases)
+    cfg.are_points_on_device = b_dev
+    if nof_bases is None:
+        nof_bases = bases.size // (2 * L)
+    if output is None:
+        output = np.zeros((nof_bases * cfg.precompute_factor, 2 * L), dtype=np.uint32)
+    op, o_dev = _ptr(output)
+    cfg.are_results_on_device = o_dev
+    check(getattr(lib, f"{curve}_msm_precompute_bases")(bp, nof_bases, ctypes.byref(cfg), op), f"{curve}_msm_precompute_bases")
+    return output
+
+
+def generate_affine_points(curve: str, n: int, k0: int = 1, out=None):
+    """n distinct points (k0+i)*G generated on the GPU (synthetic benchmark inputs)."""
+    L = LIMBS[curve]
+    if out is None:
+        out = np.zeros((n, 2 * L), dtype=np.uint32)
+    op, o_dev = _ptr(out)
+    check(getattr(lib, f"{curve}_hip_generate_affine_points")(op, n, k0, o_dev, None), "generate_affine_points")
+    return out

@@ -1,0 +1,181 @@
+/*
+ * icicle_hip.h -- C ABI of libicicle_hip.so, the MI355X (gfx950) backend for ICICLE's MSM / NTT hot path.
+ *
+ * Every entry point below has the NAME, ARGUMENT ORDER, STRUCT LAYOUT and ERROR CODES of the
+ * extern "C" symbol the reference's Rust / Go wrappers bind (wrappers/rust/icicle-core/src/msm/mod.rs:249-266,
+ * ntt/mod.rs:285-293,346-355, icicle-runtime/src/runtime.rs:10-54; wrappers/golang/curves/bn254/msm/include/msm.h:15-16),
+ * so those bindings link against this library unchanged. Each declaration cites the reference
+ * definition it replaces (paths relative to /root/reference/icicle).
+ *
+ * Plain C: pointers and sizes only. C++ references in the reference's extern "C" signatures
+ * (`const Device&`, `int&`) are passed as pointers here -- the same machine ABI.
+ */
+#ifndef ICICLE_HIP_H
+#define ICICLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#ifndef __cplusplus
+  #include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- errors: include/icicle/errors.h:13-29. Only 0..11 are ever returned (Rust's enum stops at 12). ---- */
+typedef enum {
+  ICICLE_SUCCESS = 0,
+  ICICLE_INVALID_DEVICE = 1,
+  ICICLE_OUT_OF_MEMORY = 2,
+  ICICLE_INVALID_POINTER = 3,
+  ICICLE_ALLOCATION_FAILED = 4,
+  ICICLE_DEALLOCATION_FAILED = 5,
+  ICICLE_COPY_FAILED = 6,
+  ICICLE_SYNCHRONIZATION_FAILED = 7,
+  ICICLE_STREAM_CREATION_FAILED = 8,
+  ICICLE_STREAM_DESTRUCTION_FAILED = 9,
+  ICICLE_API_NOT_IMPLEMENTED = 10,
+  ICICLE_INVALID_ARGUMENT = 11
+} icicle_error_t;
+
+/* ---- device: include/icicle/device.h:14-48 (sizeof 68, id at offset 64) ---- */
+typedef struct {
+  char type[64]; /* "HIP" */
+  int id;        /* GPU ordinal */
+} icicle_device_t;
+
+/* include/icicle/device.h:53-58 */
+typedef struct {
+  bool using_host_memory;
+  int num_memory_regions;
+  bool supports_pinned_memory;
+} icicle_device_properties_t;
+
+typedef void* icicleStreamHandle; /* a hipStream_t; NULL = default stream (include/icicle/runtime.h) */
+
+/* ======================================================================================
+ * Runtime: include/icicle/runtime.h:17-281, src/runtime.cpp.
+ * The only registered device type is "HIP". Pointers returned by icicle_malloc* are recorded in an
+ * allocation tracker (include/icicle/memory_tracker.h:16-44) so icicle_copy can infer direction.
+ * ====================================================================================== */
+icicle_error_t icicle_load_backend(const char* path, bool is_recursive); /* runtime.h:17  (no-op: backend is linked in) */
+icicle_error_t icicle_load_backend_from_env_or_default(void);            /* runtime.h:29  (no-op) */
+icicle_error_t icicle_set_device(const icicle_device_t* device);         /* runtime.h:37 */
+icicle_error_t icicle_set_default_device(const icicle_device_t* device); /* runtime.h:45 */
+icicle_error_t icicle_get_active_device(icicle_device_t* device);        /* runtime.h:53 */
+icicle_error_t icicle_is_host_memory(const void* ptr);                   /* runtime.h:61 */
+icicle_error_t icicle_is_active_device_memory(const void* ptr);          /* runtime.h:69 */
+icicle_error_t icicle_get_device_count(int* device_count);               /* runtime.h:77 */
+icicle_error_t icicle_malloc(void** ptr, size_t size);                   /* runtime.h:86 */
+icicle_error_t icicle_malloc_async(void** ptr, size_t size, icicleStreamHandle stream); /* runtime.h:97 */
+icicle_error_t icicle_free(void* ptr);                                   /* runtime.h:105 */
+icicle_error_t icicle_free_async(void* ptr, icicleStreamHandle stream);  /* runtime.h:114 */
+icicle_error_t icicle_get_available_memory(size_t* total, size_t* free); /* runtime.h:123 */
+icicle_error_t icicle_memset(void* ptr, int value, size_t size);         /* runtime.h:135 */
+icicle_error_t icicle_memset_async(void* ptr, int value, size_t size, icicleStreamHandle stream); /* runtime.h:149 */
+icicle_error_t icicle_copy(void* dst, const void* src, size_t size);     /* runtime.h:161 */
+icicle_error_t icicle_copy_async(void* dst, const void* src, size_t size, icicleStreamHandle stream); /* :172 */
+icicle_error_t icicle_copy_to_host(void* dst, const void* src, size_t size);                          /* :184 */
+icicle_error_t icicle_copy_to_host_async(void* dst, const void* src, size_t size, icicleStreamHandle stream); /* :195 */
+icicle_error_t icicle_copy_to_device(void* dst, const void* src, size_t size);                        /* :205 */
+icicle_error_t icicle_copy_to_device_async(void* dst, const void* src, size_t size, icicleStreamHandle stream); /* :216 */
+icicle_error_t icicle_create_stream(icicleStreamHandle* stream);         /* runtime.h:227 */
+icicle_error_t icicle_destroy_stream(icicleStreamHandle stream);         /* runtime.h:236 */
+icicle_error_t icicle_stream_synchronize(icicleStreamHandle stream);     /* runtime.h:246 */
+icicle_error_t icicle_device_synchronize(void);                          /* runtime.h:253 */
+icicle_error_t icicle_get_device_properties(icicle_device_properties_t* properties); /* runtime.h:261 */
+icicle_error_t icicle_is_device_available(const icicle_device_t* dev);   /* runtime.h:271 */
+icicle_error_t icicle_get_registered_devices(char* output, size_t output_size); /* runtime.h:281 */
+
+/* ---- ConfigExtension: src/config_extension.cpp:7-37 (string-keyed int/bool bag, opaque handle) ----
+ * Keys understood by this backend: "hip_msm_chunk_log2" (int), "hip_ntt_force_radix2" (bool).
+ * Foreign keys (the CUDA backend's "large_bucket_factor", "fast_twiddles", ...) are tolerated and ignored. */
+typedef struct icicle_config_extension icicle_config_extension_t;
+icicle_config_extension_t* create_config_extension(void);
+void destroy_config_extension(icicle_config_extension_t* ext);
+void config_extension_set_int(icicle_config_extension_t* ext, const char* key, int value);
+void config_extension_set_bool(icicle_config_extension_t* ext, const char* key, bool value);
+int config_extension_get_int(const icicle_config_extension_t* ext, const char* key);
+bool config_extension_get_bool(const icicle_config_extension_t* ext, const char* key);
+icicle_config_extension_t* clone_config_extension(const icicle_config_extension_t* ext);
+
+/* ======================================================================================
+ * MSM: include/icicle/msm.h:21-53 (MSMConfig, 40 bytes), src/msm.cpp:12-16, 45-49.
+ * scalars: batch*N canonical (or reference-Montgomery) scalar_t = 8 x u32 little-endian.
+ * bases:   affine_t {x,y}, 2*L x u32 (L = 8 bn254, 12 bls12_381); identity = (0,0).
+ * results: batch projective_t {x,y,z}, 3*L x u32, canonical; identity = (0:1:0).
+ * ====================================================================================== */
+typedef struct {
+  icicleStreamHandle stream;       /* offset 0  */
+  int precompute_factor;           /* 8  */
+  int c;                           /* 12 */
+  int bitsize;                     /* 16 */
+  int batch_size;                  /* 20 */
+  bool are_points_shared_in_batch; /* 24 */
+  bool are_scalars_on_device;      /* 25 */
+  bool are_scalars_montgomery_form;/* 26 */
+  bool are_points_on_device;       /* 27 */
+  bool are_points_montgomery_form; /* 28 */
+  bool are_results_on_device;      /* 29 */
+  bool is_async;                   /* 30 */
+  icicle_config_extension_t* ext;  /* 32 */
+} icicle_msm_config_t;
+
+icicle_error_t bn254_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results); /* src/msm.cpp:12 */
+icicle_error_t bn254_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases); /* src/msm.cpp:45 */
+icicle_error_t bls12_381_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
+icicle_error_t bls12_381_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
+
+/* ======================================================================================
+ * NTT: include/icicle/ntt.h:23-26 (NTTDir), 37-44 (Ordering), 53-64 (NTTConfig<S>), 92-96
+ * (NTTInitDomainConfig); src/ntt.cpp:11-84.  NTTConfig<S> for a 4-byte S is 40 bytes.
+ * ====================================================================================== */
+typedef enum { ICICLE_NTT_FORWARD = 0, ICICLE_NTT_INVERSE = 1 } icicle_ntt_dir_t;
+typedef enum { ICICLE_kNN = 0, ICICLE_kNR = 1, ICICLE_kRN = 2, ICICLE_kRR = 3, ICICLE_kNM = 4, ICICLE_kMN = 5 } icicle_ordering_t;
+
+typedef struct {
+  icicleStreamHandle stream;      /* 0  */
+  uint32_t coset_gen;             /* 8   canonical field element, 1 = no coset */
+  int batch_size;                 /* 12 */
+  bool columns_batch;             /* 16 */
+  int ordering;                   /* 20  icicle_ordering_t */
+  bool are_inputs_on_device;      /* 24 */
+  bool are_outputs_on_device;     /* 25 */
+  bool is_async;                  /* 26 */
+  icicle_config_extension_t* ext; /* 32 */
+} icicle_ntt_config_u32_t;
+
+typedef struct {
+  icicleStreamHandle stream;      /* 0 */
+  bool is_async;                  /* 8 */
+  icicle_config_extension_t* ext; /* 16 */
+} icicle_ntt_init_domain_config_t;
+
+#define ICICLE_HIP_DECLARE_NTT_U32(F)                                                                                  \
+  icicle_error_t F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* config, uint32_t* output); /* src/ntt.cpp:11 */ \
+  icicle_error_t F##_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config);  /* src/ntt.cpp:26 */ \
+  icicle_error_t F##_ntt_release_domain(void);                                                                          /* src/ntt.cpp:41 */ \
+  icicle_error_t F##_get_root_of_unity(uint64_t max_size, uint32_t* rou);                                               /* src/ntt.cpp:55 */ \
+  icicle_error_t F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);                                       /* src/ntt.cpp:75 */ \
+  icicle_error_t F##_extension_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* config, uint32_t* output); /* src/ntt.cpp:90 */
+
+ICICLE_HIP_DECLARE_NTT_U32(babybear)
+ICICLE_HIP_DECLARE_NTT_U32(koalabear)
+
+/* ---- backend-specific helpers (not part of the reference ABI) ---- */
+const char* icicle_hip_version(void);
+/* Device-side synthetic input generator for benchmarks: fills `out` (device or host per flag) with
+ * `n` DISTINCT affine points (k0 + i) * G in the reference's canonical affine layout. */
+icicle_error_t bn254_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream);
+icicle_error_t bls12_381_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream);
+/* Average device time (ms) of the dominant kernel's launches since the last reset, measured with
+ * hipEvents on the launch stream (bench.py's live roofline figure). which: 0 = MSM bucket
+ * accumulation, 1 = NTT pass kernels. */
+icicle_error_t icicle_hip_kernel_timing(int which, bool reset, double* total_ms, int* launches);
+icicle_error_t icicle_hip_enable_kernel_timing(bool enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICICLE_HIP_H */

@@ -1,0 +1,198 @@
+"""TEST INFRASTRUCTURE ONLY (never imported by icicle_amd/).
+
+ctypes access to the REAL reference: the unmodified ICICLE CPU backend compiled by
+oracle/build_ref.sh into oracle/_ref/ (libicicle_device.so, libicicle_curve_<c>.so,
+libicicle_field_<f>.so). Used as the parity oracle by tests/, by __graft_entry__.smoke() and as
+the `cpu_baseline` ("kind": "reference") leg of bench.py. The libraries travel to the GPU box
+with the snapshot; /root/reference itself is only needed to (re)build them.
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(_HERE, "_ref")
+
+
+def available(name: str = "device") -> bool:
+    return os.path.exists(os.path.join(REF_DIR, _libname(name)))
+
+
+def _libname(name):
+    if name == "device":
+        return "libicicle_device.so"
+    if name in ("bn254", "bls12_381"):
+        return f"libicicle_curve_{name}.so"
+    return f"libicicle_field_{name}.so"
+
+
+_loaded = {}
+
+
+def _load(name):
+    if name not in _loaded:
+        path = os.path.join(REF_DIR, _libname(name))
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: run oracle/build_ref.sh where /root/reference exists")
+        _loaded[name] = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL if name == "device" else ctypes.RTLD_LOCAL)
+    return _loaded[name]
+
+
+class MSMConfig(ctypes.Structure):  # icicle/include/icicle/msm.h:21-53
+    _fields_ = [
+        ("stream", ctypes.c_void_p), ("precompute_factor", ctypes.c_int), ("c", ctypes.c_int),
+        ("bitsize", ctypes.c_int), ("batch_size", ctypes.c_int),
+        ("are_points_shared_in_batch", ctypes.c_bool), ("are_scalars_on_device", ctypes.c_bool),
+        ("are_scalars_montgomery_form", ctypes.c_bool), ("are_points_on_device", ctypes.c_bool),
+        ("are_points_montgomery_form", ctypes.c_bool), ("are_results_on_device", ctypes.c_bool),
+        ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p),
+    ]
+
+
+class NTTConfigU32(ctypes.Structure):  # icicle/include/icicle/ntt.h:53-64 for a 4-byte scalar_t
+    _fields_ = [
+        ("stream", ctypes.c_void_p), ("coset_gen", ctypes.c_uint32), ("batch_size", ctypes.c_int),
+        ("columns_batch", ctypes.c_bool), ("ordering", ctypes.c_int), ("are_inputs_on_device", ctypes.c_bool),
+        ("are_outputs_on_device", ctypes.c_bool), ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p),
+    ]
+
+
+class NTTInitDomainConfig(ctypes.Structure):
+    _fields_ = [("stream", ctypes.c_void_p), ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p)]
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class RefCurve:
+    """bn254 / bls12_381 through the reference's own C ABI, on its "CPU" device."""
+
+    def __init__(self, name: str):
+        _load("device")
+        _load(name)  # field lib (dependency of the curve lib, resolved through RPATH=$ORIGIN)
+        self.name = name
+        self.lib = _load(name)
+        self.L = {"bn254": 8, "bls12_381": 12}[name]
+
+    def msm(self, scalars: np.ndarray, bases: np.ndarray, batch=1, shared=True, precompute_factor=1, c=0, bitsize=0,
+            scalars_mont=False, points_mont=False, n_threads=0):
+        n = scalars.size // 8 // batch
+        cfg = MSMConfig(None, precompute_factor, c, bitsize, batch, shared, False, scalars_mont, False, points_mont,
+                        False, False, None)
+        ext = None
+        if n_threads:
+            dev = _load("device")
+            dev.create_config_extension.restype = ctypes.c_void_p
+            ext = dev.create_config_extension()
+            dev.config_extension_set_int.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+            dev.config_extension_set_int(ext, b"n_threads", n_threads)
+            cfg.ext = ext
+        out = np.zeros((batch, 3 * self.L), dtype=np.uint32)
+        rc = getattr(self.lib, f"{self.name}_msm")(_p(scalars), _p(bases), n, ctypes.byref(cfg), _p(out))
+        if ext:
+            dev.destroy_config_extension.argtypes = [ctypes.c_void_p]
+            dev.destroy_config_extension(ext)
+        assert rc == 0, f"reference msm failed rc={rc}"
+        return out
+
+    def precompute_bases(self, bases: np.ndarray, precompute_factor: int, c=0):
+        n = bases.size // (2 * self.L)
+        cfg = MSMConfig(None, precompute_factor, c, 0, 1, True, False, False, False, False, False, False, None)
+        out = np.zeros((n * precompute_factor, 2 * self.L), dtype=np.uint32)
+        rc = getattr(self.lib, f"{self.name}_msm_precompute_bases")(_p(bases), n, ctypes.byref(cfg), _p(out))
+        assert rc == 0
+        return out
+
+    def to_affine(self, proj: np.ndarray) -> np.ndarray:
+        """projective_t[...] -> affine_t[...] with Projective::to_affine (projective.h:55-59)."""
+        proj = np.ascontiguousarray(proj.reshape(-1, 3 * self.L))
+        out = np.zeros((proj.shape[0], 2 * self.L), dtype=np.uint32)
+        fn = getattr(self.lib, f"{self.name}_to_affine")
+        for i in range(proj.shape[0]):
+            fn(ctypes.c_void_p(proj[i].ctypes.data), ctypes.c_void_p(out[i].ctypes.data))
+        return out
+
+    def projective_eq(self, a: np.ndarray, b: np.ndarray) -> bool:
+        fn = getattr(self.lib, f"{self.name}_projective_eq")
+        fn.restype = ctypes.c_bool
+        a = np.ascontiguousarray(a)
+        b = np.ascontiguousarray(b)
+        return bool(fn(_p(a), _p(b)))
+
+    def is_on_curve(self, a: np.ndarray) -> bool:
+        fn = getattr(self.lib, f"{self.name}_is_on_curve")
+        fn.restype = ctypes.c_bool
+        a = np.ascontiguousarray(a)
+        return bool(fn(_p(a)))
+
+    def generate_affine_points(self, n: int) -> np.ndarray:
+        """projective_t::rand_host_many(affine_t*, n) (projective.h:43-53): period-100 repetition."""
+        out = np.zeros((n, 2 * self.L), dtype=np.uint32)
+        getattr(self.lib, f"{self.name}_generate_affine_points")(_p(out), n)
+        return out
+
+    def generate_scalars(self, n: int) -> np.ndarray:
+        fl = _load(self.name)
+        out = np.zeros((n, 8), dtype=np.uint32)
+        # <prefix>_generate_random lives in the field library; the curve lib links it
+        flib = ctypes.CDLL(os.path.join(REF_DIR, f"libicicle_field_{self.name}.so"))
+        getattr(flib, f"{self.name}_generate_random")(_p(out), n)
+        return out
+
+    def scalars_to_montgomery(self, scalars: np.ndarray) -> np.ndarray:
+        """host-side x -> x*R mod r using the reference field mul (R = 2^256)."""
+        flib = ctypes.CDLL(os.path.join(REF_DIR, f"libicicle_field_{self.name}.so"))
+        from . import pyref
+        r = pyref.CURVES[self.name].r
+        out = np.zeros_like(scalars)
+        for i in range(scalars.shape[0]):
+            v = sum(int(x) << (32 * k) for k, x in enumerate(scalars[i])) * (1 << 256) % r
+            out[i] = [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+        return out
+
+
+class RefNttField:
+    """babybear / koalabear through the reference's C ABI on its "CPU" device."""
+
+    def __init__(self, name: str):
+        _load("device")
+        self.name = name
+        self.lib = _load(name)
+        self._domain_log = None
+
+    def get_root_of_unity(self, max_size: int) -> int:
+        r = ctypes.c_uint32()
+        fn = getattr(self.lib, f"{self.name}_get_root_of_unity")
+        fn.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+        rc = fn(max_size, ctypes.byref(r))
+        assert rc == 0
+        return r.value
+
+    def init_domain(self, root: int):
+        cfg = NTTInitDomainConfig(None, False, None)
+        r = ctypes.c_uint32(root)
+        rc = getattr(self.lib, f"{self.name}_ntt_init_domain")(ctypes.byref(r), ctypes.byref(cfg))
+        assert rc == 0
+
+    def release_domain(self):
+        rc = getattr(self.lib, f"{self.name}_ntt_release_domain")()
+        assert rc == 0
+
+    def get_root_of_unity_from_domain(self, logn: int) -> int:
+        r = ctypes.c_uint32()
+        fn = getattr(self.lib, f"{self.name}_get_root_of_unity_from_domain")
+        fn.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+        rc = fn(logn, ctypes.byref(r))
+        assert rc == 0
+        return r.value
+
+    def ntt(self, inp: np.ndarray, size: int, direction: int, batch=1, columns_batch=False, ordering=0, coset_gen=1,
+            extension=False) -> np.ndarray:
+        cfg = NTTConfigU32(None, coset_gen, batch, columns_batch, ordering, False, False, False, None)
+        out = np.zeros_like(inp)
+        fn = getattr(self.lib, f"{self.name}_extension_ntt" if extension else f"{self.name}_ntt")
+        rc = fn(_p(inp), size, direction, ctypes.byref(cfg), _p(out))
+        assert rc == 0, f"reference ntt failed rc={rc}"
+        return out

@@ -1,0 +1,229 @@
+"""GPU parity: <curve>_msm through the C ABI vs the reference CPU backend (oracle/_ref) and the
+pure-Python definition, on identical seeded inputs. Comparison is on AFFINE limbs (bit-exact),
+plus the reference's own checks: projective_eq and is_on_curve (icicle/tests/test_curve_api.cpp:77).
+Cases follow the reference tests: sizes 2^k - r (test_curve_api.cpp:40), zero points injected and
+Montgomery scalars (wrappers/rust/icicle-core/src/msm/tests.rs:17-24,54-59), batch shared/non-shared
+(:92-254), skewed 0/1 scalars (:256-304), bitsize sweep (test_curve_api.cpp:82-123)."""
+import numpy as np
+import pytest
+
+from oracle import pyref, ref
+from tests.util import cached_points, from_words, points_to_array, proj_to_affine_py, rand_scalars, to_words
+
+pytestmark = pytest.mark.gpu
+CURVES = ["bn254", "bls12_381"]
+
+
+def _check(hip, cname, scalars, bases, refc, **kw):
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    batch = kw.get("batch", 1)
+    cfg = hip.MSMConfig.default()
+    cfg.batch_size = batch
+    cfg.are_points_shared_in_batch = kw.get("shared", True)
+    cfg.c = kw.get("c", 0)
+    cfg.bitsize = kw.get("bitsize", 0)
+    cfg.are_scalars_montgomery_form = kw.get("scalars_mont", False)
+    got = M.msm(cname, scalars, bases, cfg)
+    sc_ref = scalars
+    exp = refc.msm(sc_ref, bases, batch=batch, shared=cfg.are_points_shared_in_batch, bitsize=cfg.bitsize,
+                   scalars_mont=cfg.are_scalars_montgomery_form)
+    ga, ea = refc.to_affine(got), refc.to_affine(exp)
+    assert np.array_equal(ga, ea), f"affine mismatch {cname} {kw}"
+    for b in range(batch):
+        assert refc.is_on_curve(got[b])
+        assert refc.projective_eq(got[b], exp[b])
+        (_, (x, y, z)) = proj_to_affine_py(C, got[b])
+        assert not (x == 0 and y == 0 and z == 0), "(0,0,0) is not a valid identity representative"
+    return got
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_small_vs_python_definition(hip, cname):
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3, 17, 64):
+        pts = cached_points(C, n)
+        sc = rand_scalars(rng, n, C.r)
+        got = M.msm(cname, to_words(sc, 8), points_to_array(C, pts))
+        aff, _ = proj_to_affine_py(C, got[0])
+        assert aff == pyref.msm_naive(C, sc, pts), (cname, n)
+
+
+@pytest.mark.parametrize("cname", CURVES)
+@pytest.mark.parametrize("logn", [8, 12, 14])
+def test_msm_vs_reference(hip, cname, logn):
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(100 + logn)
+    n = (1 << logn) - int(rng.integers(0, 60))
+    bases = points_to_array(C, cached_points(C, n))
+    scalars = to_words(rand_scalars(rng, n, C.r), 8)
+    _check(hip, cname, scalars, bases, refc)
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_reference_generator_distribution(hip, cname):
+    """bases from projective_t::rand_host_many (period-100 repetition -> equal points meet in buckets)."""
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(5)
+    n = 3000
+    bases = refc.generate_affine_points(n)
+    scalars = to_words(rand_scalars(rng, n, pyref.CURVES[cname].r), 8)
+    _check(hip, cname, scalars, bases, refc)
+    _check(hip, cname, scalars, bases, refc, c=5)
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_edge_cases(hip, cname):
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(11)
+    n = 500
+    pts = list(cached_points(C, n))
+    # zero points injected (msm/tests.rs:17-24), duplicates and exact negations
+    pts[3] = pyref.INF
+    pts[77] = pyref.INF
+    pts[10] = pts[11]
+    pts[20] = pyref.ec_neg(C, pts[21])
+    bases = points_to_array(C, pts)
+    sc = rand_scalars(rng, n, C.r)
+    sc[0] = 0
+    sc[1] = 1
+    sc[2] = C.r - 1
+    sc[10] = sc[11] = 5          # same point, same scalar -> doubling inside a bucket
+    sc[20] = sc[21] = 9          # P and -P with the same digit -> cancellation inside a bucket
+    _check(hip, cname, to_words(sc, 8), bases, refc)
+    # all scalars zero / all bases identity -> identity (0:1:0)-like, never (0,0,0)
+    z = M.msm(cname, np.zeros((n, 8), dtype=np.uint32), bases)
+    aff, (x, y, zz) = proj_to_affine_py(C, z[0])
+    assert aff == pyref.INF and zz == 0 and y != 0
+    z = M.msm(cname, to_words(sc, 8), np.zeros_like(bases))
+    aff, (x, y, zz) = proj_to_affine_py(C, z[0])
+    assert aff == pyref.INF and zz == 0 and y != 0
+    # all points equal, all scalars equal (every bucket add is a doubling or hits the same x)
+    same = points_to_array(C, [pts[5]] * 64)
+    _check(hip, cname, to_words([7] * 64, 8), same, refc)
+    # size 0
+    z = M.msm(cname, np.zeros((0, 8), dtype=np.uint32), np.zeros((0, 2 * C.limbs_q), dtype=np.uint32), msm_size=0)
+    aff, (x, y, zz) = proj_to_affine_py(C, z[0])
+    assert aff == pyref.INF and y != 0
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_skewed_and_bitsize(hip, cname):
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(13)
+    n = 4000
+    bases = points_to_array(C, cached_points(C, n))
+    # skewed: mostly 0/1 scalars with bitsize = 1 (msm/tests.rs:256-304)
+    sc = [int(v) for v in rng.integers(0, 2, size=n)]
+    _check(hip, cname, to_words(sc, 8), bases, refc, bitsize=1)
+    _check(hip, cname, to_words(sc, 8), bases, refc)
+    for bits in (2, 7, 31, 32, 33, 64, 129, 200, C.r.bit_length() - 1):
+        sc = rand_scalars(rng, 300, C.r, bits=bits)
+        _check(hip, cname, to_words(sc, 8), bases[:300], refc, bitsize=bits)
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_batch_and_montgomery(hip, cname):
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(17)
+    n, batch = 700, 3
+    pts = cached_points(C, n * batch)
+    sc = to_words(rand_scalars(rng, n * batch, C.r), 8)
+    _check(hip, cname, sc, points_to_array(C, pts[:n]), refc, batch=batch, shared=True)
+    _check(hip, cname, sc, points_to_array(C, pts), refc, batch=batch, shared=False)
+    # scalars in Montgomery form (R = 2^256), as the Rust test always does
+    scm = refc.scalars_to_montgomery(sc[:n])
+    got = _check(hip, cname, scm, points_to_array(C, pts[:n]), refc, scalars_mont=True)
+    plain = _check(hip, cname, sc[:n], points_to_array(C, pts[:n]), refc)
+    assert np.array_equal(refc.to_affine(got), refc.to_affine(plain))
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_explicit_c_sweep(hip, cname):
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(19)
+    n = 1000
+    bases = points_to_array(C, cached_points(C, n))
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    from icicle_amd import msm as M
+
+    base = None
+    for c in (2, 3, 7, 10, 13, 16):
+        cfg = hip.MSMConfig.default()
+        cfg.c = c
+        got = refc.to_affine(M.msm(cname, sc, bases, cfg))
+        if base is None:
+            base = refc.to_affine(refc.msm(sc, bases))
+        assert np.array_equal(got, base), c
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_device_resident_async(hip, cname):
+    """scalars, bases and results on device, is_async on a created stream (msm/tests.rs:60-75)."""
+    from icicle_amd import msm as M
+    from icicle_amd.runtime import DeviceVec, Stream
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(23)
+    n = 2048
+    bases = points_to_array(C, cached_points(C, n))
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    d_sc, d_b = DeviceVec.from_host(sc), DeviceVec.from_host(bases)
+    d_res = DeviceVec(3 * C.limbs_q * 4)
+    st = Stream()
+    cfg = hip.MSMConfig.default()
+    cfg.stream = st.handle
+    cfg.is_async = True
+    M.msm(cname, d_sc, d_b, cfg, results=d_res, msm_size=n)
+    st.synchronize()
+    got = d_res.to_host(shape=(1, 3 * C.limbs_q))
+    exp = refc.msm(sc, bases)
+    assert np.array_equal(refc.to_affine(got), refc.to_affine(exp))
+    st.destroy()
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_precompute(hip, cname):
+    """msm_precompute_bases + precompute_factor (test_curve_api.cpp:126-171): self-consistency on
+    our device plus equality with the reference result computed WITHOUT precompute."""
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(29)
+    n = 600
+    pts = list(cached_points(C, n))
+    pts[4] = pyref.INF
+    bases = points_to_array(C, pts)
+    sc = to_words(rand_scalars(rng, n * 2, C.r), 8)
+    exp = refc.to_affine(refc.msm(sc, bases, batch=2, shared=True))
+    for pf in (2, 3, 8):
+        cfg = hip.MSMConfig.default()
+        cfg.precompute_factor = pf
+        cfg.batch_size = 2
+        pre = M.precompute_bases(cname, bases, cfg)
+        assert pre.shape == (n * pf, 2 * C.limbs_q)
+        assert np.array_equal(pre[::pf], bases)  # j = 0 entry is the point itself
+        got = M.msm(cname, sc, pre, cfg)
+        assert np.array_equal(refc.to_affine(got), exp), pf
+
+
+def test_generated_points_are_distinct_multiples_of_g(hip):
+    from icicle_amd import msm as M
+
+    C = pyref.BN254
+    pts = M.generate_affine_points("bn254", 100, k0=5)
+    exp = points_to_array(C, pyref.gen_points(C, 100, k0=5))
+    assert np.array_equal(pts, exp)

@@ -1,0 +1,132 @@
+"""GPU parity: <field>_ntt through the C ABI vs the reference CPU backend, memcmp-exact
+(icicle/tests/test_mod_arithmetic_api.h:614-695 draws logn, batch, columns_batch, in-place, dir,
+ordering and coset at random and memcmp's main vs reference; same matrix here, seeded)."""
+import numpy as np
+import pytest
+
+from oracle import pyref, ref
+
+pytestmark = pytest.mark.gpu
+FIELDS = ["babybear", "koalabear"]
+DOMAIN_LOG = {"babybear": 20, "koalabear": 20}
+
+
+@pytest.fixture(scope="module", params=FIELDS)
+def env(request, hip):
+    from icicle_amd import ntt as N
+
+    fname = request.param
+    F = pyref.NTT_FIELDS[fname]
+    rf = ref.RefNttField(fname)
+    root = N.get_root_of_unity(fname, 1 << DOMAIN_LOG[fname])
+    assert root == rf.get_root_of_unity(1 << DOMAIN_LOG[fname]) == pyref.omega(F, DOMAIN_LOG[fname])
+    N.init_domain(fname, root)
+    N.init_domain(fname, root)  # second init is a silent success (cpu_ntt_domain.h:69)
+    rf.init_domain(root)
+    yield fname, F, rf, N
+    N.release_domain(fname)
+    rf.release_domain()
+
+
+def test_rou_from_domain(env):
+    fname, F, rf, N = env
+    for logn in (0, 1, 5, DOMAIN_LOG[fname]):
+        assert N.get_root_of_unity_from_domain(fname, logn) == rf.get_root_of_unity_from_domain(logn)
+
+
+def test_ntt_vs_python_definition(env, hip):
+    fname, F, rf, N = env
+    rng = np.random.default_rng(1)
+    for logn in (0, 1, 2, 5, 8):
+        n = 1 << logn
+        x = rng.integers(0, F.p, size=n, dtype=np.uint32)
+        y = N.ntt(fname, x, N.FORWARD)
+        assert [int(v) for v in y] == pyref.ntt_naive(F, [int(v) for v in x], pyref.omega(F, logn))
+        back = N.ntt(fname, y, N.INVERSE)
+        assert np.array_equal(back, x)
+
+
+@pytest.mark.parametrize("logn", [0, 1, 3, 6, 10, 12, 13, 15, 17])
+def test_ntt_matrix_vs_reference(env, hip, logn):
+    fname, F, rf, N = env
+    rng = np.random.default_rng(1000 + logn)
+    n = 1 << logn
+    for trial in range(6):
+        batch = int(rng.choice([1, 2, 4, 7]))
+        columns = bool(rng.integers(0, 2))
+        ordering = int(rng.integers(0, 6))
+        direction = int(rng.integers(0, 2))
+        coset = 1 if rng.integers(0, 2) else int(rng.integers(2, F.p))
+        x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+        cfg = hip.NTTConfigU32.default()
+        cfg.batch_size, cfg.columns_batch, cfg.ordering, cfg.coset_gen = batch, columns, ordering, coset
+        got = N.ntt(fname, x, direction, cfg)
+        exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset)
+        assert np.array_equal(got, exp), (fname, logn, batch, columns, ordering, direction, coset)
+
+
+@pytest.mark.parametrize("logn", [4, 11, 14])
+def test_ntt_device_inplace_async(env, hip, logn):
+    fname, F, rf, N = env
+    from icicle_amd.runtime import DeviceVec, Stream
+
+    rng = np.random.default_rng(77 + logn)
+    n, batch = 1 << logn, 3
+    x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+    d = DeviceVec.from_host(x)
+    st = Stream()
+    cfg = hip.NTTConfigU32.default()
+    cfg.batch_size, cfg.stream, cfg.is_async = batch, st.handle, True
+    N.ntt(fname, d, N.FORWARD, cfg, out=d, size=n)  # in place on device
+    st.synchronize()
+    assert np.array_equal(d.to_host(), rf.ntt(x, n, 0, batch=batch))
+    cfg.ordering = N.kRN
+    cfg.coset_gen = 3
+    N.ntt(fname, d, N.INVERSE, cfg, out=d, size=n)
+    st.synchronize()
+    assert np.array_equal(d.to_host(), rf.ntt(rf.ntt(x, n, 0, batch=batch), n, 1, batch=batch, ordering=2, coset_gen=3))
+    st.destroy()
+
+
+def test_ntt_extension_field(env, hip):
+    fname, F, rf, N = env
+    rng = np.random.default_rng(5)
+    for logn, batch, columns in ((5, 1, False), (9, 2, False), (13, 3, True)):
+        n = 1 << logn
+        x = rng.integers(0, F.p, size=n * batch * 4, dtype=np.uint32)
+        cfg = hip.NTTConfigU32.default()
+        cfg.batch_size, cfg.columns_batch = batch, columns
+        for direction in (0, 1):
+            got = N.ntt(fname, x, direction, cfg, extension=True)
+            exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, extension=True)
+            assert np.array_equal(got, exp), (logn, batch, columns, direction)
+
+
+def test_ntt_errors(env, hip):
+    fname, F, rf, N = env
+    x = np.zeros(12, dtype=np.uint32)
+    with pytest.raises(hip.IcicleError):  # not a power of two
+        N.ntt(fname, x, N.FORWARD, size=12)
+    big = np.zeros(1 << (DOMAIN_LOG[fname] + 1), dtype=np.uint32)
+    with pytest.raises(hip.IcicleError):  # larger than the domain (cpu_ntt_main.h:38-41)
+        N.ntt(fname, big, N.FORWARD)
+
+
+def test_ntt_roundtrip_large(env, hip):
+    """size-independent property at a size the CPU oracle would take long on: inverse(forward(x)) == x,
+    and linearity NTT(a+b) = NTT(a)+NTT(b)."""
+    fname, F, rf, N = env
+    rng = np.random.default_rng(9)
+    logn, batch = DOMAIN_LOG[fname], 4
+    n = 1 << logn
+    a = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+    b = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+    cfg = hip.NTTConfigU32.default()
+    cfg.batch_size = batch
+    fa, fb = N.ntt(fname, a, N.FORWARD, cfg), N.ntt(fname, b, N.FORWARD, cfg)
+    assert np.array_equal(N.ntt(fname, fa, N.INVERSE, cfg), a)
+    s = ((a.astype(np.uint64) + b) % F.p).astype(np.uint32)
+    fs = N.ntt(fname, s, N.FORWARD, cfg)
+    assert np.array_equal(fs, ((fa.astype(np.uint64) + fb) % F.p).astype(np.uint32))
+    # one row checked against the reference
+    assert np.array_equal(fa[:n], rf.ntt(a[:n], n, 0))

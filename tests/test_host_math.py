@@ -1,0 +1,129 @@
+"""CPU: the exact arithmetic headers the kernels use (bigfield.cuh, ec.cuh, smallfield.cuh), compiled
+for the host with the debug bound tracker on, against Python big-int arithmetic. This pins the
+29-bit-radix Montgomery field, the XYZZ mixed add with its exceptional cases, and the complete
+projective formulas (reference: icicle/include/icicle/curves/projective.h:73-188) without a GPU."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import pyref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "_build", "libhost_math.so")
+SRC = os.path.join(HERE, "host_math_harness.cpp")
+FIELDS = {0: pyref.BN254.q, 1: pyref.BN254.r, 2: pyref.BLS12_381.q, 3: pyref.BLS12_381.r}
+NL = {0: 8, 1: 8, 2: 12, 3: 8}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.cuh", "ec.cuh", "smallfield.cuh", "field_consts.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-DBIGFIELD_BOUNDS", "-fPIC", "-shared", SRC, "-o", SO])
+    return ctypes.CDLL(SO)
+
+
+def w(x, n):
+    return (ctypes.c_uint32 * n)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(n)])
+
+
+def iv(a):
+    return sum(int(v) << (32 * i) for i, v in enumerate(a))
+
+
+@pytest.mark.parametrize("f", [0, 1, 2, 3])
+def test_field_ops(lib, f):
+    p, n = FIELDS[f], NL[f]
+    rnd = random.Random(f)
+    special = [0, 1, 2, 3, p - 1, p - 2, (1 << 29) - 1, 1 << 29, 1 << 58, p // 2, p // 2 + 1]
+    r32 = 1 << (32 * n)
+    for it in range(600):
+        a = special[it % len(special)] if it < 2 * len(special) else rnd.randrange(p)
+        b = special[(it * 7) % len(special)] if it < len(special) else rnd.randrange(p)
+        out = (ctypes.c_uint32 * n)()
+        for op, exp in [(0, a * b % p), (1, a * a % p), (2, (a + b) % p), (3, (a - b) % p), (4, (-a) % p),
+                        (5, 2 * (a + b) * (a - 4 * b) % p)]:
+            assert lib.host_field_op(f, op, w(a, n), w(b, n), out) == 0
+            assert iv(out) == exp, (f, op, a, b)
+        lib.host_field_op(f, 6, w(a * r32 % p, n), w(0, n), out)
+        assert iv(out) == a  # reference-Montgomery -> canonical
+        lib.host_field_op(f, 7, w(a, n), w(0, n), out)
+        assert iv(out) == a * r32 % p
+        lib.host_field_op(f, 8, w(a, n), w(b, n), out)
+        assert out[0] == (1 if a == b else 0)
+
+
+@pytest.mark.parametrize("ci,c", [(0, pyref.BN254), (1, pyref.BLS12_381)])
+def test_ec_ops(lib, ci, c):
+    n32 = c.limbs_q
+    rnd = random.Random(42 + ci)
+
+    def run(op, pts, aux=None):
+        flat = []
+        for (x, y) in pts:
+            flat += list(w(x, n32)) + list(w(y, n32))
+        arr = (ctypes.c_uint32 * max(1, len(flat)))(*flat)
+        out = (ctypes.c_uint32 * (3 * n32))()
+        auxa = (ctypes.c_uint32 * len(aux))(*aux) if aux is not None else None
+        assert lib.host_ec_op(ci, op, arr, len(pts), auxa, out) == 0
+        o = list(out)
+        X, Y, Z = iv(o[:n32]), iv(o[n32:2 * n32]), iv(o[2 * n32:])
+        assert X < c.q and Y < c.q and Z < c.q
+        return pyref.proj_to_affine(c, X, Y, Z), (X, Y, Z)
+
+    G = (c.gx, c.gy)
+    assert run(3, [G])[0] == G
+    base = pyref.gen_points(c, 30, k0=rnd.randrange(c.r))
+    for trial in range(24):
+        k = rnd.randrange(1, 16)
+        pts = [rnd.choice(base) for _ in range(k)]
+        neg = [rnd.randrange(2) for _ in range(k)]
+        if trial % 3 == 0:  # doubling right at the start of a bucket
+            pts[0:0] = [pts[0]] * 2
+            neg[0:0] = [neg[0]] * 2
+        if trial % 4 == 0:  # cancellation at the end
+            pts.append(pts[-1])
+            neg.append(1 - neg[-1])
+        if trial % 5 == 0:
+            pts.insert(1, pyref.INF)
+            neg.insert(1, 0)
+        if trial == 7:
+            pts, neg = [base[0], base[0]], [0, 1]
+        if trial == 8:
+            pts, neg = [base[0], base[0], base[1]], [0, 1, 0]
+        if trial == 9:
+            pts, neg = [base[0]] * 9, [0] * 9
+        exp = pyref.INF
+        for p_, n_ in zip(pts, neg):
+            exp = pyref.ec_add(c, exp, pyref.ec_neg(c, p_) if n_ else p_)
+        for op in (0, 1):  # XYZZ accumulate / complete projective sum
+            got, raw = run(op, pts, neg)
+            assert got == exp, (c.name, trial, op)
+            if exp == pyref.INF:
+                assert raw[2] == 0 and raw[1] != 0  # (0 : y!=0 : 0), never (0,0,0)
+    for k in [0, 1, 2, 3, 5, 255, 256, 32767, 32768, 65535, 1 << 20]:
+        assert run(2, [base[3]], [k])[0] == pyref.ec_mul(c, k, base[3])
+    got, raw = run(2, [pyref.INF], [5])
+    assert got == pyref.INF and raw[1] != 0
+    for k in [0, 1, 5, 16]:
+        assert run(4, [base[2]], [k])[0] == pyref.ec_mul(c, 1 << k, base[2])
+
+
+@pytest.mark.parametrize("fi,f", [(0, pyref.BABYBEAR), (1, pyref.KOALABEAR)])
+def test_small_field(lib, fi, f):
+    rnd = random.Random(fi)
+    out = ctypes.c_uint32()
+    for it in range(1500):
+        a, b = rnd.randrange(f.p), rnd.randrange(f.p)
+        if it < 4:
+            a, b = [(0, 0), (f.p - 1, f.p - 1), (1, f.p - 1), (f.p - 1, 0)][it]
+        for op, exp in [(0, a * b % f.p), (1, (a + b) % f.p), (2, (a - b) % f.p), (3, pow(a, b, f.p))]:
+            lib.host_small_op(fi, op, a, b, ctypes.byref(out))
+            assert out.value == exp, (f.name, op, a, b)
+        if a:
+            lib.host_small_op(fi, 4, a, 0, ctypes.byref(out))
+            assert out.value == pow(a, -1, f.p)
