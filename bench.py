@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- BN254 MSM 2^26 (primary, BASELINE.json configs[1]) + BabyBear NTT 2^24 x 64
+(secondary, configs[2]) on N MI355X, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM:
+one 2^26-term BN254 MSM per rank (weak scaling: the N shards form one 2^26*N-term MSM whose partial
+results are all-gathered over RCCL and summed on every rank). Timed region: barrier + synchronize on
+both sides, max over ranks. One JSON line on rank 0.
+
+Extra objects: "roofline" (dominant kernel = MSM bucket accumulation, duration from hipEvents on the
+launch stream, algorithmic bytes per SURVEY.md 8(d)), "cpu_baseline" (the reference CPU backend from
+oracle/_ref timed on this box's host cores on a bounded sample), "ntt" (secondary metric with its
+own roofline/cpu_baseline).  --size-log2 / --ntt-log2 shrink the workload for quick checks; the
+JSON then names the reduced workload (never reported as the headline config).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 4.63 TB/s measured copy
+BN254_R_TOP = 0x30644E72
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size-log2", type=int, default=26, help="MSM size per GPU (headline: 26)")
+    ap.add_argument("--ntt-log2", type=int, default=24, help="NTT size (headline: 24)")
+    ap.add_argument("--ntt-batch", type=int, default=64)
+    ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-msm-log2", type=int, default=20)
+    ap.add_argument("--cpu-ntt-log2", type=int, default=20)
+    return ap.parse_args()
+
+
+def synth_scalars(n, device, seed):
+    """n x 8 uint32 limbs, value < r (top limb drawn below r's top limb), resident on `device`."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    s = torch.randint(-(2 ** 31), 2 ** 31, (n, 8), dtype=torch.int32, device=device, generator=g)
+    top = torch.randint(0, BN254_R_TOP, (n,), dtype=torch.int32, device=device, generator=g)
+    s[:, 7] = top
+    return s
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or (world == 1 and args.gpus == 1), "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    import icicle_amd
+    from icicle_amd import dist as D
+    from icicle_amd import msm as M
+    from icicle_amd import ntt as N
+    from icicle_amd import runtime
+    from icicle_amd._lib import MSMConfig, NTTConfigU32, lib, check
+
+    runtime.set_device(local_rank)
+
+    def barrier_sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---------------- MSM: synthetic inputs resident in HBM ----------------
+    n = 1 << args.size_log2
+    bases = torch.empty((n, 16), dtype=torch.int32, device=dev)
+    # distinct points (k0 + i)G, a different range per rank; generated on the GPU
+    check(lib.bn254_hip_generate_affine_points(bases.data_ptr(), n, 1 + rank * (1 << 40), True, None), "generate")
+    scalars = synth_scalars(n, dev, 1234 + rank)
+    torch.cuda.synchronize()
+
+    def msm_step():
+        return D.msm_sharded("bn254", scalars, bases, n, rank, world, dist, MSMConfig.default())
+
+    for _ in range(args.warmup):
+        msm_step()
+    lib.icicle_hip_enable_kernel_timing(True)
+    tot, cnt = ctypes.c_double(), ctypes.c_int()
+    lib.icicle_hip_kernel_timing(0, True, ctypes.byref(tot), ctypes.byref(cnt))
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = msm_step()
+    barrier_sync()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    lib.icicle_hip_kernel_timing(0, True, ctypes.byref(tot), ctypes.byref(cnt))
+    lib.icicle_hip_enable_kernel_timing(False)
+    msm_ms = dt / args.steps * 1e3
+    acc_ms = tot.value / max(1, cnt.value)
+    msm_bytes = n * (32 + 64) + 96  # N*sizeof(scalar) + N*sizeof(affine) + sizeof(projective)
+    units_per_step = world * (n / float(1 << 26))  # in 2^26-term MSMs
+    value = units_per_step * args.steps / dt
+    roofline = {
+        "bound": "hbm", "kernel": "k_accumulate<bn254_g1>", "achieved": msm_bytes / (acc_ms * 1e-3) / 1e9,
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": msm_bytes / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": None, "avg_launch_ms": acc_ms, "launches": cnt.value,
+        "note": "MSM is integer-ALU bound (v_mad_u64_u32), not HBM bound; see DESIGN.md and 'alu'",
+    }
+    # secondary: integer-ALU view. mixed adds per MSM = n * windows(c=16 -> 16); 10 field muls each
+    nwin = 16
+    madds = n * nwin
+    roofline["alu"] = {"mixed_adds_per_s": madds / (acc_ms * 1e-3), "mixed_adds": madds}
+
+    out = {
+        "metric": "bn254_msm_2^26_per_sec", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": msm_ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32x8 (254-bit integer field, 29-bit-limb Montgomery)", "data": "synthetic",
+        "config": {"workload": f"BN254 G1 MSM, 2^{args.size_log2} uniform scalars x 2^{args.size_log2} distinct affine "
+                               f"bases per GPU, batch 1, inputs resident in HBM, precompute_factor 1",
+                   "sharding": "bases/scalars sharded per rank; RCCL all_gather of partial sums + projective add"},
+        "roofline": roofline,
+    }
+
+    # ---------------- NTT secondary ----------------
+    if not args.no_ntt:
+        logn, batch = args.ntt_log2, args.ntt_batch
+        lo, hi = D.ntt_batch_shard(batch * world, rank, world)  # weak scaling: `batch` rows per GPU
+        rows = hi - lo
+        nn = 1 << logn
+        root = N.get_root_of_unity("babybear", nn)
+        N.init_domain("babybear", root)
+        g = torch.Generator(device=dev)
+        g.manual_seed(99 + rank)
+        x = torch.randint(0, 0x78000001, (rows, nn), dtype=torch.int32, device=dev, generator=g)
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+        cfg = NTTConfigU32.default()
+        cfg.batch_size = rows
+        cfg.is_async = True
+
+        def ntt_step():
+            N.ntt("babybear", x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=nn)
+            N.ntt("babybear", y.data_ptr(), N.INVERSE, cfg, out=z.data_ptr(), size=nn)
+
+        for _ in range(max(1, args.warmup)):
+            ntt_step()
+        torch.cuda.synchronize()
+        roundtrip_ok = bool(torch.equal(x, z))
+        lib.icicle_hip_enable_kernel_timing(True)
+        lib.icicle_hip_kernel_timing(1, True, ctypes.byref(tot), ctypes.byref(cnt))
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ntt_step()
+        barrier_sync()
+        dtn = max_over_ranks(time.perf_counter() - t0)
+        lib.icicle_hip_kernel_timing(1, True, ctypes.byref(tot), ctypes.byref(cnt))
+        lib.icicle_hip_enable_kernel_timing(False)
+        ntt_call_ms = tot.value / max(1, cnt.value)  # one direction, `rows` transforms
+        ntt_bytes = 2 * rows * nn * 4  # 2*batch*N*sizeof(elem) per direction
+        ntts = 2 * rows * world * args.steps  # forward + inverse each count
+        out["ntt"] = {
+            "metric": f"babybear_ntt_2^{logn}_per_sec", "value": ntts / dtn, "unit": "NTT/s",
+            "ms_per_step": dtn / args.steps * 1e3, "roundtrip_ok": roundtrip_ok,
+            "config": {"workload": f"BabyBear NTT 2^{logn}, batch {rows} per GPU, kNN, forward + inverse round trip, "
+                                   f"device resident", "sharding": "rows of the batch per rank, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_ntt_pass<babybear> (all passes of one direction)",
+                         "achieved": ntt_bytes / (ntt_call_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ntt_bytes / (ntt_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": ntt_call_ms, "launches": cnt.value},
+        }
+        N.release_domain("babybear")
+
+    # ---------------- CPU baseline: the reference CPU backend on this box's host cores ----------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import ref
+
+            cores = os.cpu_count()
+            refc = ref.RefCurve("bn254")
+            cn = 1 << args.cpu_msm_log2
+            hb = bases[:cn].cpu().numpy().view(np.uint32)
+            hs = scalars[:cn].cpu().numpy().view(np.uint32)
+            t0 = time.perf_counter()
+            exp = refc.msm(np.ascontiguousarray(hs), np.ascontiguousarray(hb))
+            tc = time.perf_counter() - t0
+            # parity of the sample on the GPU path too
+            got = M.msm("bn254", np.ascontiguousarray(hs), np.ascontiguousarray(hb))
+            parity = bool(np.array_equal(refc.to_affine(got), refc.to_affine(exp)))
+            out["cpu_baseline"] = {
+                "value": (cn / float(1 << 26)) / tc, "unit": "MSM/s", "cores": cores, "kind": "reference",
+                "sample": f"one BN254 MSM of 2^{args.cpu_msm_log2} terms (first 2^{args.cpu_msm_log2} of the bench inputs) "
+                          f"took {tc:.2f} s on the reference CPU backend (oracle/_ref, Taskflow shim); value = that rate "
+                          f"expressed in 2^26-term MSMs/s assuming linear scaling",
+                "parity_with_gpu_on_sample": parity,
+            }
+            if not args.no_ntt:
+                rf = ref.RefNttField("babybear")
+                cl = args.cpu_ntt_log2
+                rf.init_domain(rf.get_root_of_unity(1 << cl))
+                hx = np.ascontiguousarray(x[0, : 1 << cl].cpu().numpy().view(np.uint32))
+                hx4 = np.tile(hx, 4)
+                rf.ntt(hx4, 1 << cl, 0, batch=4)
+                t0 = time.perf_counter()
+                rf.ntt(hx4, 1 << cl, 0, batch=4)
+                tn = time.perf_counter() - t0
+                out["ntt"]["cpu_baseline"] = {
+                    "value": 4 / tn * ((1 << cl) * cl) / ((1 << args.ntt_log2) * args.ntt_log2), "unit": "NTT/s",
+                    "cores": cores, "kind": "reference",
+                    "sample": f"4 forward BabyBear NTTs of 2^{cl} took {tn * 1e3:.1f} ms on the reference CPU backend; "
+                              f"scaled by N log N to 2^{args.ntt_log2}",
+                }
+                rf.release_domain()
+        except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
+            out["cpu_baseline"] = {"value": None, "unit": "MSM/s", "cores": os.cpu_count(), "kind": "reference",
+                                   "sample": f"failed: {e!r}"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,7 +114,7 @@ RUNTIME_SYMBOLS = [
 CURVES = ["bn254", "bls12_381"]
 NTT_FIELDS = ["babybear", "koalabear"]
 API_SYMBOLS = (
-    [f"{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points")]
+    [f"{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
     + [f"{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
                                                "get_root_of_unity_from_domain", "extension_ntt")]
     + ["icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing"]
@@ -159,6 +159,7 @@ lib.icicle_get_registered_devices.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
 for _c in CURVES:
     getattr(lib, f"{_c}_msm").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.c_void_p]
     getattr(lib, f"{_c}_msm_precompute_bases").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.c_void_p]
+    getattr(lib, f"{_c}_hip_projective_sum").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     getattr(lib, f"{_c}_hip_generate_affine_points").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_bool, ctypes.c_void_p]
 for _f in NTT_FIELDS:
     getattr(lib, f"{_f}_ntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU32), ctypes.c_void_p]

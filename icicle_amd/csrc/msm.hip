@@ -425,6 +425,45 @@ namespace icicle_hip {
     }
   }
 
+  // sum of n projective points in the reference's canonical layout (multi-GPU partial-result combine)
+  template <class C>
+  __global__ __launch_bounds__(64) void k_proj_sum(const uint32_t* __restrict__ pts, int n, uint32_t* __restrict__ out)
+  {
+    using E = EC<C>;
+    using F = typename E::F;
+    __shared__ typename E::Proj sh[64];
+    const int lane = threadIdx.x;
+    typename E::Proj v = E::proj_identity();
+    for (int i = lane; i < n; i += 64) {
+      const uint32_t* w = pts + (size_t)i * 3 * E::N32;
+      typename E::Proj p;
+      p.x = F::from_canonical(w);
+      p.y = F::from_canonical(w + E::N32);
+      p.z = F::from_canonical(w + 2 * E::N32);
+      v = E::add(v, p);
+    }
+    sh[lane] = v;
+    __syncthreads();
+    for (int s = 32; s >= 1; s >>= 1) {
+      if (lane < s) {
+        v = E::add(v, sh[lane + s]);
+        sh[lane] = v;
+      }
+      __syncthreads();
+    }
+    if (lane == 0) E::store_proj_canonical(out, v);
+  }
+
+  template <class C>
+  static icicle_error_t proj_sum_run(const void* pts, int n, void* out, hipStream_t st)
+  {
+    if (n < 0 || !out || (n > 0 && !pts)) return ICICLE_INVALID_ARGUMENT;
+    ICICLE_TRY(bind_current_device());
+    k_proj_sum<C><<<1, 64, 0, st>>>((const uint32_t*)pts, n, (uint32_t*)out);
+    LAUNCH_CHECK("k_proj_sum", st);
+    return ICICLE_SUCCESS;
+  }
+
   // ------------------------------------------------------------------------------------------
   template <class C>
   static icicle_error_t msm_run(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v)
@@ -632,6 +671,14 @@ icicle_error_t bls12_381_msm(const void* scalars, const void* bases, int msm_siz
 icicle_error_t bls12_381_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases)
 {
   GUARDED(msm_precompute_run<bls12_381_g1>(input_bases, nof_bases, config, output_bases));
+}
+icicle_error_t bn254_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream)
+{
+  GUARDED(proj_sum_run<bn254_g1>(points, n, out, (hipStream_t)stream));
+}
+icicle_error_t bls12_381_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream)
+{
+  GUARDED(proj_sum_run<bls12_381_g1>(points, n, out, (hipStream_t)stream));
 }
 icicle_error_t bn254_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream)
 {

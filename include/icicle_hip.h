@@ -169,6 +169,10 @@ const char* icicle_hip_version(void);
  * `n` DISTINCT affine points (k0 + i) * G in the reference's canonical affine layout. */
 icicle_error_t bn254_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream);
 icicle_error_t bls12_381_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream);
+/* Device-side sum of n projective points (reference layout, device pointers): the combine step of a
+ * base-sharded multi-GPU MSM after the RCCL all-gather of per-GPU partial results. */
+icicle_error_t bn254_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);
+icicle_error_t bls12_381_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);
 /* Average device time (ms) of the dominant kernel's launches since the last reset, measured with
  * hipEvents on the launch stream (bench.py's live roofline figure). which: 0 = MSM bucket
  * accumulation, 1 = NTT pass kernels. */

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Mint the golden fixtures in this directory from the REAL reference (oracle/_ref = unmodified ICICLE
+CPU backend, built by oracle/build_ref.sh where /root/reference exists).
+
+The reference tree holds no golden vectors / KATs for MSM or NTT (its tests are differential,
+SURVEY.md 4, 8c), so these fixtures are what pins the oracle and the HIP path to absolute values:
+  python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+Inputs are seeded; inputs AND reference outputs are stored, so the fixtures are usable on the GPU box
+where neither /root/reference nor (necessarily) oracle/_ref exists.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import pyref, ref  # noqa: E402
+from tests.util import points_to_array, rand_scalars, to_words  # noqa: E402
+
+
+def msm_fixture(cname, seed):
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(seed)
+    n = 257
+    pts = pyref.gen_points(C, n, k0=0xC0FFEE + seed)
+    pts[3] = pyref.INF
+    pts[100] = pts[101]
+    pts[150] = pyref.ec_neg(C, pts[151])
+    sc = rand_scalars(rng, 2 * n, C.r)
+    sc[0], sc[1], sc[2] = 0, 1, C.r - 1
+    sc[100] = sc[101] = 12345
+    sc[150] = sc[151] = 77
+    scalars = to_words(sc, 8)
+    bases = points_to_array(C, pts)
+    out = {"scalars": scalars, "bases": bases}
+    out["res_single"] = refc.to_affine(refc.msm(scalars[:n], bases))
+    out["res_batch2_shared"] = refc.to_affine(refc.msm(scalars, bases, batch=2, shared=True))
+    small = to_words(rand_scalars(rng, n, C.r, bits=20), 8)
+    out["scalars_20bit"] = small
+    out["res_bitsize20"] = refc.to_affine(refc.msm(small, bases, bitsize=20))
+    out["scalars_mont"] = refc.scalars_to_montgomery(scalars[:n])
+    out["res_mont"] = refc.to_affine(refc.msm(out["scalars_mont"], bases, scalars_mont=True))
+    assert np.array_equal(out["res_mont"], out["res_single"])
+    # the pure-Python definition agrees on a prefix
+    m = 40
+    exp = pyref.msm_naive(C, sc[:m], pts[:m])
+    got = refc.to_affine(refc.msm(scalars[:m], bases[:m]))
+    assert points_to_array(C, [exp]).tolist() == got.tolist()
+    return out
+
+
+def ntt_fixture(fname, seed):
+    F = pyref.NTT_FIELDS[fname]
+    rf = ref.RefNttField(fname)
+    rng = np.random.default_rng(seed)
+    logn, batch = 10, 2
+    n = 1 << logn
+    root = rf.get_root_of_unity(1 << 12)  # domain larger than the transform (stride max/N = 4)
+    assert root == pyref.omega(F, 12)
+    rf.init_domain(root)
+    x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+    g = int(rng.integers(2, F.p))
+    out = {"x": x, "domain_root": np.array([root], dtype=np.uint32), "coset_gen": np.array([g], dtype=np.uint32)}
+    out["fwd_NN"] = rf.ntt(x, n, 0, batch=batch)
+    out["inv_NN"] = rf.ntt(x, n, 1, batch=batch)
+    out["fwd_NR_coset"] = rf.ntt(x, n, 0, batch=batch, ordering=1, coset_gen=g)
+    out["inv_RN_coset"] = rf.ntt(x, n, 1, batch=batch, ordering=2, coset_gen=g)
+    out["fwd_RR"] = rf.ntt(x, n, 0, batch=batch, ordering=3)
+    out["fwd_columns"] = rf.ntt(x, n, 0, batch=batch, columns_batch=True)
+    xe = rng.integers(0, F.p, size=64 * 4, dtype=np.uint32)
+    out["x_ext"] = xe
+    out["fwd_ext"] = rf.ntt(xe, 64, 0, extension=True)
+    # definition check on one small row
+    small = [int(v) for v in x[:16]]
+    assert [int(v) for v in rf.ntt(x[:16].copy(), 16, 0)] == pyref.ntt_naive(F, small, pyref.omega(F, 4))
+    rf.release_domain()
+    return out
+
+
+def main():
+    for i, c in enumerate(("bn254", "bls12_381")):
+        np.savez_compressed(os.path.join(HERE, f"msm_{c}.npz"), **msm_fixture(c, 11 + i))
+    for i, f in enumerate(("babybear", "koalabear")):
+        np.savez_compressed(os.path.join(HERE, f"ntt_{f}.npz"), **ntt_fixture(f, 21 + i))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""CPU: pin the oracle. The C restatement (oracle/oracle.c) and -- when present -- the real reference
+build (oracle/_ref) must both reproduce the committed golden fixtures (minted from oracle/_ref by
+tests/golden/make_golden.py), and the pure-Python definitions must agree on small cases."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyref, ref
+from tests import oracle_c as oc
+from tests.util import from_words, points_to_array, rand_scalars, to_words
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CURVES = ["bn254", "bls12_381"]
+FIELDS = ["babybear", "koalabear"]
+ORD = {"NN": 0, "NR": 1, "RN": 2, "RR": 3}
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_c_oracle_msm_matches_golden(cname):
+    g = np.load(os.path.join(GOLD, f"msm_{cname}.npz"))
+    n = g["bases"].shape[0]
+    for c in (7, 12):
+        got = oc.to_affine(cname, oc.msm(cname, np.ascontiguousarray(g["scalars"][:n]), g["bases"], c=c))
+        assert np.array_equal(got, g["res_single"][0]), c
+    got = oc.to_affine(cname, oc.msm(cname, np.ascontiguousarray(g["scalars"][n:]), g["bases"], c=9))
+    assert np.array_equal(got, g["res_batch2_shared"][1])
+    got = oc.to_affine(cname, oc.msm(cname, g["scalars_20bit"], g["bases"], c=6, bitsize=20))
+    assert np.array_equal(got, g["res_bitsize20"][0])
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_reference_build_matches_golden(cname):
+    if not ref.available(cname):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    g = np.load(os.path.join(GOLD, f"msm_{cname}.npz"))
+    refc = ref.RefCurve(cname)
+    n = g["bases"].shape[0]
+    assert np.array_equal(refc.to_affine(refc.msm(np.ascontiguousarray(g["scalars"][:n]), g["bases"])), g["res_single"])
+    assert np.array_equal(refc.to_affine(refc.msm(g["scalars"], g["bases"], batch=2)), g["res_batch2_shared"])
+    assert np.array_equal(refc.to_affine(refc.msm(g["scalars_mont"], g["bases"], scalars_mont=True)), g["res_mont"])
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_python_definition_matches_golden_prefix(cname):
+    C = pyref.CURVES[cname]
+    g = np.load(os.path.join(GOLD, f"msm_{cname}.npz"))
+    L = C.limbs_q
+    m = 24
+    pts = [(from_words(b[:L]), from_words(b[L:])) for b in g["bases"][:m]]
+    assert all(pyref.on_curve(C, p) for p in pts)
+    sc = from_words(g["scalars"][:m])
+    exp = pyref.msm_naive(C, sc, pts)
+    got = oc.to_affine(cname, oc.msm(cname, np.ascontiguousarray(g["scalars"][:m]), np.ascontiguousarray(g["bases"][:m]), c=5))
+    assert (from_words(got[:L]), from_words(got[L:])) == exp
+
+
+@pytest.mark.parametrize("fname", FIELDS)
+def test_c_oracle_ntt_matches_golden(fname):
+    g = np.load(os.path.join(GOLD, f"ntt_{fname}.npz"))
+    root, cg = int(g["domain_root"][0]), int(g["coset_gen"][0])
+    x, n, batch = g["x"], 1024, 2
+    assert np.array_equal(oc.ntt(fname, x, n, root, batch=batch), g["fwd_NN"])
+    assert np.array_equal(oc.ntt(fname, x, n, root, inverse=True, batch=batch), g["inv_NN"])
+    assert np.array_equal(oc.ntt(fname, x, n, root, ordering=1, coset_gen=cg, batch=batch), g["fwd_NR_coset"])
+    assert np.array_equal(oc.ntt(fname, x, n, root, inverse=True, ordering=2, coset_gen=cg, batch=batch), g["inv_RN_coset"])
+    assert np.array_equal(oc.ntt(fname, x, n, root, ordering=3, batch=batch), g["fwd_RR"])
+    assert np.array_equal(oc.ntt(fname, x, n, root, batch=batch, columns_batch=True), g["fwd_columns"])
+    assert np.array_equal(oc.ntt(fname, g["x_ext"], 64, root, lanes=4), g["fwd_ext"])
+    # round trip
+    assert np.array_equal(oc.ntt(fname, g["fwd_NN"], n, root, inverse=True, batch=batch), x)
+
+
+@pytest.mark.parametrize("fname", FIELDS)
+def test_reference_ntt_matches_golden_and_definition(fname):
+    F = pyref.NTT_FIELDS[fname]
+    g = np.load(os.path.join(GOLD, f"ntt_{fname}.npz"))
+    root = int(g["domain_root"][0])
+    assert root == pyref.omega(F, 12) == oc.omega(fname, 12)
+    # O(N^2) definition on one short row, through the C oracle with the same oversized domain
+    rng = np.random.default_rng(4)
+    x = rng.integers(0, F.p, size=32, dtype=np.uint32)
+    for o in ("NN", "NR", "RN", "RR"):
+        for inv in (False, True):
+            exp = pyref.ntt_naive(F, [int(v) for v in x], pyref.omega(F, 5), inverse=inv, coset_gen=5, ordering=o)
+            assert [int(v) for v in oc.ntt(fname, x, 32, root, inverse=inv, ordering=ORD[o], coset_gen=5)] == exp
+    if not ref.available(fname):
+        pytest.skip("oracle/_ref not built")
+    rf = ref.RefNttField(fname)
+    rf.init_domain(root)
+    try:
+        assert np.array_equal(rf.ntt(g["x"], 1024, 0, batch=2), g["fwd_NN"])
+        assert np.array_equal(rf.ntt(g["x"], 1024, 1, batch=2, ordering=2, coset_gen=int(g["coset_gen"][0])), g["inv_RN_coset"])
+    finally:
+        rf.release_domain()
+
+
+def test_c_oracle_vs_reference_random_msm():
+    if not ref.available("bn254"):
+        pytest.skip("oracle/_ref not built")
+    C = pyref.BN254
+    refc = ref.RefCurve("bn254")
+    rng = np.random.default_rng(8)
+    bases = refc.generate_affine_points(150)  # the reference's own generator (period-100 repetition)
+    sc = to_words(rand_scalars(rng, 150, C.r), 8)
+    got = oc.to_affine("bn254", oc.msm("bn254", sc, bases, c=8))
+    assert np.array_equal(got, refc.to_affine(refc.msm(sc, bases))[0])
