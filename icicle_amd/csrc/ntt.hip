@@ -84,9 +84,12 @@ namespace icicle_hip {
     return bits == 0 ? 0 : (__brevll(x) >> (64 - bits));
   }
 
-  // One pass. grid = (ntiles, nbatch). Dynamic LDS: L*T u32.
+  // ---- generic pass (any ordering / coset): one radix-2 stage per LDS round trip ---------------
+  // Correctness-first kernel used when the input or output is bit-reversed (kRN/kNR/kRR) or a coset
+  // generator is given; the headline path (kNN, no coset) uses k_ntt_fast below.
+  // grid = (ntiles, nbatch). Dynamic LDS: L*T u32.
   template <class PR>
-  __global__ __launch_bounds__(1024) void k_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ coset_pow, PassDesc pd, NttLaunch nl)
+  __global__ __launch_bounds__(1024) void k_ntt_pass_generic(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ coset_pow, PassDesc pd, NttLaunch nl)
   {
     using S = SmallField<PR>;
     extern __shared__ uint32_t tile[];
@@ -159,6 +162,244 @@ namespace icicle_hip {
         if (nl.out_rev) oaddr = bitrev64(oaddr, nl.logn);
       }
       out[boff + oaddr * nl.es] = v;
+    }
+  }
+
+
+  // ---- fast pass: register-blocked radix-2 butterflies, 4 stages per LDS round trip -------------
+  // Natural-order, no-coset transforms (kNN/kNM/kMN, any batch layout, both directions).
+  // A pass computes 2^s-point transforms on a [L x T] tile (T adjacent columns => every HBM access is
+  // a run of T contiguous words). A thread owns 16 tile elements per "round" and runs up to 4 butterfly
+  // stages on them in registers; the FIRST round loads its operands straight from HBM and the LAST
+  // round stores straight to HBM, so s = 8 costs one LDS round trip and one barrier per row-transform.
+  // Stage twiddles and the inter-pass twiddle w_M^(j*K) do not depend on the batch row: they are
+  // loaded ONCE per block into registers and the block loops over `rows_per_block` rows
+  // (double-buffered LDS).
+  //   DIF == false: column pass (HBM-contiguous direction = tile column t on both sides). The first
+  //                 round gathers bit-reversed rows, stages run DIT (ascending), output is natural.
+  //   DIF == true : row pass = the last pass (HBM-contiguous direction = k on the way in, t on the
+  //                 way out). Natural order in, stages run DIF (descending); the first executed round
+  //                 maps lanes along k, later rounds along t, so both HBM sides stay coalesced and the
+  //                 digit-reversal to natural order happens in the store addresses. INV folds 1/N in.
+  // Template: NQ0 = stages in the lowest round (1..4), NR = rounds; s = NQ0 + 4*(NR-1).
+  template <class S, int NQ, bool DIF, bool SKIP_TRIVIAL>
+  __device__ __forceinline__ void ntt_stages(uint32_t* x, const uint32_t* w)
+  {
+#pragma unroll
+    for (int jj = 0; jj < NQ; jj++) {
+      const int j = DIF ? (NQ - 1 - jj) : jj;
+      const int half = 1 << j;
+#pragma unroll
+      for (int bfly = 0; bfly < (1 << NQ) / 2; bfly++) {
+        const int pos = bfly & (half - 1);
+        const int i = ((bfly >> j) << (j + 1)) + pos;
+        const bool trivial = SKIP_TRIVIAL && pos == 0; // w_L^0 = 1
+        if (DIF) {
+          const uint32_t sum = S::add(x[i], x[i + half]);
+          const uint32_t dif = S::sub(x[i], x[i + half]);
+          x[i] = sum;
+          x[i + half] = trivial ? dif : S::mul(dif, w[half - 1 + pos]);
+        } else {
+          const uint32_t v = trivial ? x[i + half] : S::mul(x[i + half], w[half - 1 + pos]);
+          const uint32_t uu = x[i];
+          x[i] = S::add(uu, v);
+          x[i + half] = S::sub(uu, v);
+        }
+      }
+    }
+  }
+
+  template <int BITS>
+  __device__ __forceinline__ constexpr uint32_t brev_c(uint32_t v)
+  {
+    uint32_t r = 0;
+    for (int i = 0; i < BITS; i++)
+      r |= ((v >> i) & 1u) << (BITS - 1 - i);
+    return r;
+  }
+
+  template <class PR, int NQ0, int NR, bool DIF, bool INV>
+  __global__ __launch_bounds__(512) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
+  {
+    using S = SmallField<PR>;
+    constexpr int SS = NQ0 + 4 * (NR - 1);
+    constexpr uint32_t L = 1u << SS;
+    constexpr int E = (SS >= 4) ? 16 : (1 << SS); // elements per thread per round
+    constexpr int G0 = E >> NQ0;                  // groups per thread in the lowest round
+    constexpr uint32_t NG16 = L / E;              // threads per tile column
+    constexpr int QT = NR >= 2 ? NQ0 + 4 * (NR - 2) : 0; // first stage of the top round
+    constexpr int KB_BITS = SS - NQ0;
+    extern __shared__ uint32_t lds[];
+    const uint32_t T = pd.T, TP = T + 1;
+    const uint32_t a = blockIdx.x / pd.tiles_per_a, ct = blockIdx.x % pd.tiles_per_a;
+    const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
+    const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
+    const uint32_t lstride_log = nl.log_max - SS;
+    // mapping B (lanes along t) everywhere except the first executed round of a DIF pass (mapping A)
+    const uint32_t tB = threadIdx.x % T, gB = threadIdx.x / T;
+    const uint32_t gA = threadIdx.x % NG16, tA = threadIdx.x / NG16;
+
+    auto tw_load = [&](uint64_t idx) -> uint32_t {
+      idx &= max_mask;
+      if (nl.inverse) idx = (((uint64_t)1 << nl.log_max) - idx) & max_mask;
+      return tw[idx];
+    };
+
+    // ---- per-thread twiddles, loaded once per block ---------------------------------------------
+    uint32_t w0[(1 << NQ0)]; // lowest round: group-independent (wave-uniform => scalar registers)
+#pragma unroll
+    for (int j = 0; j < NQ0; j++)
+#pragma unroll
+      for (int pos = 0; pos < (1 << j); pos++)
+        w0[(1 << j) - 1 + pos] = tw_load(((uint64_t)pos << (SS - 1 - j)) << lstride_log);
+    uint32_t wr[NR > 1 ? NR - 1 : 1][16];
+#pragma unroll
+    for (int r = 1; r < NR; r++) {
+      const int q0 = NQ0 + 4 * (r - 1);
+      const uint32_t g = (DIF && r == NR - 1) ? gA : gB;
+      const uint32_t base_low = g & ((1u << q0) - 1);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int pos = 0; pos < (1 << j); pos++)
+          wr[r - 1][(1 << j) - 1 + pos] = tw_load(((uint64_t)(base_low + ((uint32_t)pos << q0)) << (SS - 1 - (q0 + j))) << lstride_log);
+    }
+    // base row of this thread's elements in the top round (natural order, mapping B)
+    const uint32_t baseT = (NR == 1) ? 0u : (((gB >> QT) << (QT + 4)) | (gB & ((1u << QT) - 1)));
+    uint32_t wip[E]; // inter-pass twiddles of the E elements this thread stores (column passes)
+    if (!DIF) {
+      const uint64_t jnext = ((uint64_t)ct * T + tB) / pd.cprime;
+#pragma unroll
+      for (int m = 0; m < E; m++) {
+        const uint32_t k = (NR == 1) ? (uint32_t)m : baseT + ((uint32_t)m << QT);
+        const uint64_t K = (pd.pidx == 0) ? (uint64_t)k : ((uint64_t)a + (uint64_t)pd.n0 * k);
+        wip[m] = tw_load(jnext * K * pd.tw_stride);
+      }
+    }
+
+    // ---- per-thread HBM offsets (in elements, times the element stride) ----------------------------
+    const uint64_t es = nl.es;
+    // column pass: slot (k, t) at in_base + k*sk + t*st on both sides
+    // row pass   : load  (k, t) at in_base + k*1  + t*st ; store K0(t) + k_out*out_sk
+    const uint64_t K0 = (pd.pidx <= 1) ? ((uint64_t)ct * T + tB) : (((uint64_t)ct * T + tB) + (uint64_t)pd.n0 * a);
+
+    const uint32_t row0 = blockIdx.y * rows_per_block;
+    for (uint32_t rr = 0; rr < rows_per_block && row0 + rr < nl.nbatch; rr++) {
+      const uint32_t bprime = row0 + rr;
+      const uint64_t boff = (uint64_t)(bprime / nl.lanes) * nl.bs + (bprime % nl.lanes);
+      const uint32_t* __restrict__ pin = in + boff;
+      uint32_t* __restrict__ pout = out + boff;
+      uint32_t* tile = lds + (size_t)(rr & 1) * L * TP;
+
+      if (!DIF) {
+        // ================= column pass, DIT =================
+#pragma unroll
+        for (int u = 0; u < G0; u++) {
+          const uint32_t gi = gB * G0 + u;
+          const uint32_t kb = (KB_BITS == 0) ? 0u : (__brev(gi) >> (32 - (KB_BITS > 0 ? KB_BITS : 1)));
+          const uint32_t* p = pin + (in_base + (uint64_t)kb * pd.in_sk + (uint64_t)tB * pd.in_st) * es;
+          const uint64_t step = (pd.in_sk << KB_BITS) * es;
+          uint32_t x[1 << NQ0];
+#pragma unroll
+          for (int m = 0; m < (1 << NQ0); m++) // slot m <- source row kb + brev(m) * 2^(s-NQ0)
+            x[m] = p[(uint64_t)brev_c<NQ0>(m) * step];
+          ntt_stages<S, NQ0, false, true>(x, w0);
+          if (NR == 1) {
+            uint32_t* q = pout + (in_base + (uint64_t)tB * pd.in_st) * es;
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              q[(uint64_t)m * pd.in_sk * es] = S::mul(x[m], wip[m]);
+          } else {
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              tile[((gi << NQ0) + m) * TP + tB] = x[m];
+          }
+        }
+        if (NR > 1) {
+          __syncthreads();
+#pragma unroll
+          for (int r = 1; r < NR; r++) {
+            const int q0 = NQ0 + 4 * (r - 1);
+            const uint32_t base = ((gB >> q0) << (q0 + 4)) | (gB & ((1u << q0) - 1));
+            uint32_t x[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+              x[m] = tile[(base + ((uint32_t)m << q0)) * TP + tB];
+            ntt_stages<S, 4, false, false>(x, wr[r - 1]);
+            if (r == NR - 1) {
+              uint32_t* q = pout + (in_base + (uint64_t)base * pd.in_sk + (uint64_t)tB * pd.in_st) * es;
+              const uint64_t step = (pd.in_sk << q0) * es;
+#pragma unroll
+              for (int m = 0; m < 16; m++)
+                q[(uint64_t)m * step] = S::mul(x[m], wip[m]);
+            } else {
+#pragma unroll
+              for (int m = 0; m < 16; m++)
+                tile[(base + ((uint32_t)m << q0)) * TP + tB] = x[m];
+              __syncthreads();
+            }
+          }
+        }
+      } else {
+        // ================= row pass (last pass), DIF =================
+        if (NR == 1) {
+          const uint32_t* p = pin + (in_base + (uint64_t)tB * pd.in_st) * es;
+          uint32_t x[1 << NQ0];
+#pragma unroll
+          for (int m = 0; m < (1 << NQ0); m++)
+            x[m] = p[(uint64_t)m * es];
+          ntt_stages<S, NQ0, true, true>(x, w0);
+          uint32_t* q = pout + K0 * es;
+          const uint64_t step = pd.out_sk * es;
+#pragma unroll
+          for (int m = 0; m < (1 << NQ0); m++)
+            q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+        } else {
+          { // top round: mapping A, natural rows k = gA + m * L/16 straight from HBM
+            const uint32_t* p = pin + (in_base + (uint64_t)gA + (uint64_t)tA * pd.in_st) * es;
+            uint32_t x[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+              x[m] = p[((uint64_t)m << QT) * es];
+            ntt_stages<S, 4, true, false>(x, wr[NR - 2]);
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+              tile[(gA + ((uint32_t)m << QT)) * TP + tA] = x[m];
+          }
+          __syncthreads();
+#pragma unroll
+          for (int r = NR - 2; r >= 1; r--) {
+            const int q0 = NQ0 + 4 * (r - 1);
+            const uint32_t base = ((gB >> q0) << (q0 + 4)) | (gB & ((1u << q0) - 1));
+            uint32_t x[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+              x[m] = tile[(base + ((uint32_t)m << q0)) * TP + tB];
+            ntt_stages<S, 4, true, false>(x, wr[r - 1]);
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+              tile[(base + ((uint32_t)m << q0)) * TP + tB] = x[m];
+            __syncthreads();
+          }
+          // lowest round: slot m of group gi holds X[kb + brev(m) * 2^(s-NQ0)], kb = brev(gi)
+#pragma unroll
+          for (int u = 0; u < G0; u++) {
+            const uint32_t gi = gB * G0 + u;
+            const uint32_t kb = (KB_BITS == 0) ? 0u : (__brev(gi) >> (32 - (KB_BITS > 0 ? KB_BITS : 1)));
+            uint32_t x[1 << NQ0];
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              x[m] = tile[((gi << NQ0) + m) * TP + tB];
+            ntt_stages<S, NQ0, true, true>(x, w0);
+            uint32_t* q = pout + (K0 + (uint64_t)kb * pd.out_sk) * es;
+            const uint64_t step = (pd.out_sk << KB_BITS) * es;
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+          }
+        }
+      }
+      // the next row uses the other LDS buffer; the barrier inside its processing orders the reuse after that
     }
   }
 
@@ -271,11 +512,41 @@ namespace icicle_hip {
 
   static void split_logn(int logn, int* parts, int* np)
   {
-    const int SMAX = 12;
+    // <= 3 passes; 2^8-point sub-transforms (2 register rounds) up to 2^24, larger ones above
+    const int SMAX = std::max(8, (logn + 2) / 3);
     const int P = std::max(1, (logn + SMAX - 1) / SMAX);
     for (int i = 0; i < P; i++)
       parts[i] = logn / P + (i < logn % P ? 1 : 0);
     *np = P;
+  }
+
+  template <class PR>
+  using pass_fn_t = void (*)(const uint32_t*, uint32_t*, const uint32_t*, PassDesc, NttLaunch, uint32_t);
+
+  template <class PR, int NQ0, int NR>
+  static pass_fn_t<PR> pick_variant(bool dif, bool inv)
+  {
+    if (!dif) return (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, false, false>;
+    return inv ? (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, true, true> : (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, true, false>;
+  }
+  template <class PR>
+  static pass_fn_t<PR> pick_pass(int s, bool dif, bool inv)
+  {
+    switch (s) {
+    case 1: return pick_variant<PR, 1, 1>(dif, inv);
+    case 2: return pick_variant<PR, 2, 1>(dif, inv);
+    case 3: return pick_variant<PR, 3, 1>(dif, inv);
+    case 4: return pick_variant<PR, 4, 1>(dif, inv);
+    case 5: return pick_variant<PR, 1, 2>(dif, inv);
+    case 6: return pick_variant<PR, 2, 2>(dif, inv);
+    case 7: return pick_variant<PR, 3, 2>(dif, inv);
+    case 8: return pick_variant<PR, 4, 2>(dif, inv);
+    case 9: return pick_variant<PR, 1, 3>(dif, inv);
+    case 10: return pick_variant<PR, 2, 3>(dif, inv);
+    case 11: return pick_variant<PR, 3, 3>(dif, inv);
+    case 12: return pick_variant<PR, 4, 3>(dif, inv);
+    }
+    return nullptr;
   }
 
   template <class PR>
@@ -356,6 +627,16 @@ namespace icicle_hip {
       LAUNCH_CHECK("k_coset_powers", st);
     }
 
+    if (logn == 0) { // size-1 transforms are the identity in every mode
+      HIP_TRY(hipMemcpyAsync(d_out, d_in, bytes, hipMemcpyDeviceToDevice, st), ICICLE_COPY_FAILED);
+      if (!cfg->are_outputs_on_device) {
+        HIP_TRY(hipMemcpyAsync(output, d_out, bytes, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
+        HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+      } else if (!cfg->is_async) {
+        HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+      }
+      return ICICLE_SUCCESS;
+    }
     int parts[3], P;
     split_logn(logn, parts, &P);
     // P >= 2: passes 0..P-2 run in a work buffer (the last pass permutes across tiles, so it can
@@ -366,8 +647,8 @@ namespace icicle_hip {
       HIP_TRY(d_work.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
       W = d_work.as<uint32_t>();
     }
-    HIP_TRY(hipFuncSetAttribute((const void*)k_ntt_pass<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072), ICICLE_INVALID_ARGUMENT);
 
+    const bool fast = !nl.in_rev && !nl.out_rev && !nl.coset;
     KernelTimer::begin(1, st);
     for (int p = 0; p < P; p++) {
       const uint32_t* src = (p == 0) ? d_in : W;
@@ -384,7 +665,11 @@ namespace icicle_hip {
         C <<= parts[q];
       pd.n0 = 1u << parts[0];
       pd.n1 = P > 1 ? (1u << parts[1]) : 1;
-      const uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, 32768 / L));
+      // fast path: block = T * L/16 threads (<= 512), LDS = 2 buffers of L*(T+1) words (<= 160 KiB)
+      const uint64_t epb = L >= 16 ? 16 : L;
+      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, 512 * epb / L));
+      while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
+        tmax >>= 1;
       if (!pd.is_last) {
         pd.T = (int)std::min<uint64_t>(tmax, C);
         pd.tiles_per_a = (uint32_t)(C / pd.T);
@@ -413,9 +698,23 @@ namespace icicle_hip {
         pd.out_sk = n >> pd.s;
         pd.out_st = 1;
       }
-      const uint32_t tot = (uint32_t)(L * pd.T);
-      const unsigned threads = std::max(64u, std::min(1024u, tot / 2));
-      k_ntt_pass<PR><<<dim3(pd.ntiles, nl.nbatch), threads, tot * 4, st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, nl);
+      if (fast) {
+        const unsigned threads = (unsigned)(pd.T * (L / epb));
+        const size_t lds_bytes = (size_t)2 * L * (pd.T + 1) * 4;
+        // rows of the batch handled by one block (twiddles are loaded once per block): aim for >= 4096 blocks
+        const uint64_t total_blocks = (uint64_t)pd.ntiles * nl.nbatch;
+        const uint32_t rpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nl.nbatch, total_blocks / 4096));
+        const uint32_t gy = (nl.nbatch + rpb - 1) / rpb;
+        pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0);
+        if (!fn) return ICICLE_INVALID_ARGUMENT;
+        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
+        fn<<<dim3(pd.ntiles, gy), threads, lds_bytes, st>>>(src, dst, dom.tw, pd, nl, rpb);
+      } else {
+        const uint32_t tot = (uint32_t)(L * pd.T);
+        const unsigned threads = std::max(64u, std::min(1024u, tot / 2));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_ntt_pass_generic<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
+        k_ntt_pass_generic<PR><<<dim3(pd.ntiles, nl.nbatch), threads, (size_t)tot * 4, st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, nl);
+      }
       LAUNCH_CHECK("k_ntt_pass", st);
     }
     KernelTimer::end(1, st);
