@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--ntt-log2", type=int, default=24, help="NTT size (headline: 24)")
     ap.add_argument("--ntt-batch", type=int, default=64)
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--msm-c", type=int, default=0, help="force the MSM window size (0 = backend default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-msm-log2", type=int, default=20)
     ap.add_argument("--cpu-ntt-log2", type=int, default=20)
@@ -102,7 +103,9 @@ def main():
     torch.cuda.synchronize()
 
     def msm_step():
-        return D.msm_sharded("bn254", scalars, bases, n, rank, world, dist, MSMConfig.default())
+        cfg = MSMConfig.default()
+        cfg.c = args.msm_c
+        return D.msm_sharded("bn254", scalars, bases, n, rank, world, dist, cfg)
 
     for _ in range(args.warmup):
         msm_step()

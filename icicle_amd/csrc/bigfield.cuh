@@ -129,6 +129,45 @@ namespace icicle_hip {
       return r;
     }
 
+    // r = (a*b + c*d)/R mod p with ONE interleaved reduction: both products share the column
+    // accumulators (3N products of < 2^58 per column: < 2^64 for N <= 21).
+    static HD fe mul_add(const fe& a, const fe& b, const fe& c, const fe& d)
+    {
+      BF_ASSERT(a.bnd <= max_bound() && b.bnd <= max_bound() && c.bnd <= max_bound() && d.bnd <= max_bound(), "mul_add input bound");
+      static_assert(N <= 21, "column accumulator would overflow");
+      fe r;
+      uint32_t m[N];
+      uint64_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+          acc += (uint64_t)a.l[i] * b.l[k - i];
+          acc += (uint64_t)c.l[i] * d.l[k - i];
+          acc += (uint64_t)m[i] * PR::P[k - i];
+        }
+        acc += (uint64_t)a.l[k] * b.l[0];
+        acc += (uint64_t)c.l[k] * d.l[0];
+        m[k] = ((uint32_t)acc * PR::PINV) & MASK;
+        acc += (uint64_t)m[k] * PR::P[0];
+        acc >>= RB;
+      }
+#pragma unroll
+      for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+          acc += (uint64_t)a.l[i] * b.l[k - i];
+          acc += (uint64_t)c.l[i] * d.l[k - i];
+          acc += (uint64_t)m[i] * PR::P[k - i];
+        }
+        r.l[k - N] = (uint32_t)acc & MASK;
+        acc >>= RB;
+      }
+      r.l[N - 1] = (uint32_t)acc;
+      BF_SET_BOUND(r, (a.bnd * b.bnd + c.bnd * d.bnd) / r_over_p() + 1.0);
+      return r;
+    }
+
     // Squaring: the a_i*a_j cross terms are computed once and doubled (N(N+1)/2 instead of N^2
     // products for the a*a half; the m*p half is unchanged).
     static HD fe sqr(const fe& a)

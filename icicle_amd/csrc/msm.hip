@@ -31,6 +31,7 @@ namespace icicle_hip {
     int pf;      // precompute factor
     int wpf;     // windows per precomputed base = target windows actually accumulated
     uint32_t nb; // buckets per window = 2^(c-1)
+    uint32_t seg; // bucket-accumulation segment size: a bucket with more points is split across threads
   };
 
   static MsmPlan make_plan(int n, int scalar_bits, const icicle_msm_config_t& cfg)
@@ -42,9 +43,11 @@ namespace icicle_hip {
     if (c <= 0) {
       // minimise  (#mixed adds) + (bucket-reduction adds, weighted for their poor parallelism)
       double best = 1e300;
-      for (int cc = 2; cc <= 16; cc++) {
+      for (int cc = 2; cc <= 22; cc++) {
         const int w = (p.bits + 1 + cc - 1) / cc;
         const int wpf = (w + p.pf - 1) / p.pf;
+        // per bucket: ~2 complete adds (14 muls each) in the reduction vs 10 muls per mixed add, plus
+        // the traffic of writing/reading the bucket; weight 8 also penalises its poorer parallelism
         const double cost = (double)w * n + 8.0 * wpf * (double)(1u << (cc - 1));
         if (cost < best) {
           best = cost;
@@ -52,11 +55,18 @@ namespace icicle_hip {
         }
       }
     }
-    c = std::min(16, std::max(2, c)); // LDS histogram holds 2^(c-1) counters
+    c = std::min(24, std::max(2, c)); // two-level sort: 2^hb partitions in LDS (pass A), 2^lb bins (pass B)
     p.c = c;
     p.nwin = (p.bits + 1 + c - 1) / c;
     p.wpf = (p.nwin + p.pf - 1) / p.pf;
     p.nb = 1u << (c - 1);
+    {
+      const double avg = (double)n * p.pf * ((double)p.nwin / p.wpf) / (double)p.nb; // points per bucket
+      uint32_t sgm = 64;
+      while ((double)sgm < 2.0 * avg)
+        sgm <<= 1;
+      p.seg = sgm;
+    }
     return p;
   }
 
@@ -80,109 +90,280 @@ namespace icicle_hip {
   }
 
   // ------------------------------------------------------------------------------------------
-  // 2. signed-digit decomposition. digit word = |d| | (d<0)<<31, |d| in [0, 2^(c-1)], 0 = skip.
+  // 2+3. signed digits and a two-level counting sort of point indices by bucket.
+  //
+  // A single-level scatter into 2^(c-1) bucket lists writes 4 bytes to a random one of 32768 open
+  // cache lines per element -- measured 29 ms of the first version's 144 ms (profiles/
+  // r01_v1_kernel_stats.txt), almost all write amplification. Two levels keep the number of open
+  // destinations per block small enough for L2 to assemble full lines:
+  //   pass A: scalars -> digits on the fly (no digit array in HBM) -> partition by the HIGH hb bits
+  //           of the bucket key; block b owns scalars [b*chunk, (b+1)*chunk); LDS holds the
+  //           wpf * 2^hb counters / cursors. Element = sign | low key bits | j | index within chunk.
+  //   pass B: one block per (window, partition): counting sort by the LOW lb key bits in LDS; the
+  //           source block of an element (needed to rebuild its global scalar index) is found by a
+  //           binary search in the partition's per-block offset row, staged in LDS.
+  // Output is what bucket accumulation consumes: count[], offs[], sorted[] (point index | sign<<31).
+  struct SortPlan {
+    int hb, lb;       // high / low bucket-key bits, hb + lb = c - 1
+    int jb;           // bits for the precompute index j
+    int chunk_log;    // scalars per pass-A block = 2^chunk_log
+    int nblk;         // pass-A blocks
+  };
+
+  // digit word: |d| | (d<0)<<31, |d| in [0, 2^(c-1)], 0 = skip. Signed recoding as cpu_msm.hpp:289-295.
+  struct DigitIter {
+    uint32_t w[9];
+    uint32_t carry = 0;
+    __device__ __forceinline__ uint32_t next(int wi, int c)
+    {
+      const int bit = wi * c;
+      const int word = bit >> 5, sh = bit & 31;
+      uint32_t v = 0;
+      if (word < 8) {
+        const uint64_t two = ((uint64_t)w[word + 1] << 32) | w[word];
+        v = (uint32_t)(two >> sh) & ((1u << c) - 1);
+      }
+      v += carry;
+      const uint32_t half = 1u << (c - 1);
+      if (v > half) {
+        carry = 1;
+        const uint32_t d = (1u << c) - v;
+        return d ? (d | 0x80000000u) : 0u;
+      }
+      carry = 0;
+      return v;
+    }
+  };
+
   template <class C>
-  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, int c, int nwin, bool scalars_refmont)
+  __device__ __forceinline__ void load_scalar(DigitIter& it, const uint32_t* __restrict__ scalars, size_t i, bool scalars_refmont)
   {
     using FR = FieldOps<typename C::fr>;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t w[FR::N32 + 1];
-#pragma unroll
-    for (int k = 0; k < FR::N32; k++)
-      w[k] = scalars[(size_t)i * FR::N32 + k];
-    if (scalars_refmont) { // x*2^(32*N32) -> x  (cpu_msm.hpp:274-275 from_montgomery)
+    static_assert(FR::N32 == 8, "scalar fields here are 8 x u32");
+    const uint4* p = reinterpret_cast<const uint4*>(scalars + i * 8);
+    const uint4 lo = p[0], hi = p[1];
+    it.w[0] = lo.x, it.w[1] = lo.y, it.w[2] = lo.z, it.w[3] = lo.w;
+    it.w[4] = hi.x, it.w[5] = hi.y, it.w[6] = hi.z, it.w[7] = hi.w;
+    if (scalars_refmont) { // x*2^256 -> x  (cpu_msm.hpp:274-275 from_montgomery)
       typename FR::fe cst;
 #pragma unroll
       for (int k = 0; k < FR::N; k++)
         cst.l[k] = C::fr::REFMONT_TO_CANON[k];
       BF_SET_BOUND(cst, 1);
-      FR::pack(w, FR::reduce(FR::mul(FR::unpack(w), cst)));
+      FR::pack(it.w, FR::reduce(FR::mul(FR::unpack(it.w), cst)));
     }
-    w[FR::N32] = 0;
-    const uint32_t half = 1u << (c - 1);
-    const uint32_t mask = (1u << c) - 1;
-    uint32_t carry = 0;
-    for (int wi = 0; wi < nwin; wi++) {
-      const int bit = wi * c;
-      const int word = bit >> 5, sh = bit & 31;
-      uint32_t v = 0;
-      if (word < FR::N32) {
-        uint64_t two = ((uint64_t)w[word + 1] << 32) | w[word];
-        v = (uint32_t)(two >> sh) & mask;
-      }
-      v += carry;
-      uint32_t d, neg;
-      if (v > half) {
-        d = (1u << c) - v;
-        neg = 1;
-        carry = 1;
-      } else {
-        d = v;
-        neg = 0;
-        carry = 0;
-      }
-      dig[(size_t)wi * n + i] = d | (d ? (neg << 31) : 0);
-    }
+    it.w[8] = 0;
+    it.carry = 0;
   }
 
-  // ------------------------------------------------------------------------------------------
-  // 3. counting sort per target window, LDS-privatised histogram / cursors.
-  //    grid = (B, wpf); block b owns scalars [b*chunk, (b+1)*chunk).
-  __global__ __launch_bounds__(1024) void k_hist(const uint32_t* __restrict__ dig, uint32_t* __restrict__ blockhist, int n, int chunk, int nwin, int wpf, int pf, uint32_t nb)
+  // pass A. COUNT: fill cntA[(wp*2^hb + h)*nblk + b]. !COUNT: scatter using the scanned offsets.
+  template <class C, bool COUNT>
+  __global__ __launch_bounds__(1024) void k_part_a(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ cntA, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int c, int nwin, int wpf, int pf, SortPlan sp, size_t cap, bool scalars_refmont)
   {
     extern __shared__ uint32_t lds[];
-    const int b = blockIdx.x, wp = blockIdx.y, B = gridDim.x;
-    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x)
-      lds[k] = 0;
+    const int b = blockIdx.x;
+    const uint32_t nparts = (uint32_t)wpf << sp.hb;
+    for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x)
+      lds[k] = COUNT ? 0u : offA[(size_t)k * sp.nblk + b];
     __syncthreads();
-    const int lo = b * chunk, hi = min(n, lo + chunk);
-    for (int j = 0; j < pf; j++) {
-      const int w = j * wpf + wp;
-      if (w >= nwin) break;
-      const uint32_t* d = dig + (size_t)w * n;
-      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t k = d[i] & 0x7fffffffu;
-        if (k) atomicAdd(&lds[k - 1], 1u);
+    const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
+    const uint32_t lmask = (1u << sp.lb) - 1;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      DigitIter it;
+      load_scalar<C>(it, scalars, (size_t)i, scalars_refmont);
+      int wp = 0, j = 0;
+      for (int wi = 0; wi < nwin; wi++) {
+        const uint32_t d = it.next(wi, c);
+        const uint32_t key = d & 0x7fffffffu;
+        if (key) {
+          const uint32_t km = key - 1;
+          const uint32_t part = ((uint32_t)wp << sp.hb) + (km >> sp.lb);
+          if (COUNT) {
+            atomicAdd(&lds[part], 1u);
+          } else {
+            const uint32_t pos = atomicAdd(&lds[part], 1u);
+            const uint32_t el = (d & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo);
+            outA[(size_t)wp * cap + pos] = el;
+          }
+        }
+        if (++wp == wpf) {
+          wp = 0;
+          j++;
+        }
       }
     }
-    __syncthreads();
-    uint32_t* out = blockhist + ((size_t)wp * B + b) * nb;
-    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x)
-      out[k] = lds[k];
+    if (COUNT) {
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x)
+        cntA[(size_t)k * sp.nblk + b] = lds[k];
+    }
   }
 
-  // exclusive prefix over blocks for every (window,bucket); total -> count
-  __global__ __launch_bounds__(256) void k_scan_blocks(uint32_t* __restrict__ blockhist, uint32_t* __restrict__ count, int B, uint32_t nb, int wpf)
+  // pass A scatter, one block per (target window, scalar chunk): a block keeps only 2^hb write streams
+  // open (the all-windows variant above would keep wpf * 2^hb, far more than L2 can assemble into
+  // full lines). blockIdx.x = window varies fastest, so the wpf blocks that re-read one scalar chunk
+  // are dispatched together and the chunk is served from the Infinity Cache after its first read.
+  template <class C>
+  __global__ __launch_bounds__(1024) void k_part_a_scatter(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int c, int nwin, int wpf, int pf, SortPlan sp, size_t cap, bool scalars_refmont)
   {
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= (size_t)wpf * nb) return;
-    const size_t wp = t / nb, k = t % nb;
-    uint32_t run = 0;
-    for (int b = 0; b < B; b++) {
-      uint32_t* p = blockhist + (wp * B + b) * nb + k;
-      const uint32_t x = *p;
-      *p = run;
+    extern __shared__ uint32_t lds[];
+    const int wp = blockIdx.x, b = blockIdx.y;
+    const uint32_t nparts_w = 1u << sp.hb;
+    for (uint32_t k = threadIdx.x; k < nparts_w; k += blockDim.x)
+      lds[k] = offA[((size_t)wp * nparts_w + k) * sp.nblk + b];
+    __syncthreads();
+    const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
+    const uint32_t lmask = (1u << sp.lb) - 1;
+    uint32_t* dst = outA + (size_t)wp * cap;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      DigitIter it;
+      load_scalar<C>(it, scalars, (size_t)i, scalars_refmont);
+      int wcur = 0, j = 0;
+      for (int wi = 0; wi < nwin; wi++) {
+        const uint32_t d = it.next(wi, c);
+        if (wcur == wp) {
+          const uint32_t key = d & 0x7fffffffu;
+          if (key) {
+            const uint32_t km = key - 1;
+            const uint32_t pos = atomicAdd(&lds[km >> sp.lb], 1u);
+            dst[pos] = (d & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo);
+          }
+        }
+        if (++wcur == wpf) {
+          wcur = 0;
+          j++;
+        }
+      }
+    }
+  }
+
+  // exclusive scan of one window's [2^hb][nblk] counters (partition-major, block-minor), in place
+  // into offA (positions relative to the window's region); one 1024-thread block per window.
+  __global__ __launch_bounds__(1024) void k_scan_a(const uint32_t* __restrict__ cntA, uint32_t* __restrict__ offA, uint32_t m)
+  {
+    __shared__ uint32_t part[1024];
+    const size_t base = (size_t)blockIdx.x * m;
+    const uint32_t per = (m + 1023) / 1024;
+    const uint32_t lo = min(m, threadIdx.x * per), hi = min(m, lo + per);
+    uint32_t s = 0;
+    for (uint32_t k = lo; k < hi; k++)
+      s += cntA[base + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t k = lo; k < hi; k++) {
+      const uint32_t x = cntA[base + k];
+      offA[base + k] = run;
       run += x;
     }
-    count[t] = run;
+    if (threadIdx.x == 1023) offA[(size_t)gridDim.x * m + blockIdx.x] = part[1023]; // window total
+  }
+
+  // pass B. A partition (window wp, high key bits h) is cut into sub-chunks of CHUNKB elements, one
+  // block each, so neither a sparse top window nor skewed scalars can serialise it on one block.
+  // k_b_plan turns partition sizes into a block -> (partition, sub-chunk) table; k_b_count adds LDS
+  // histograms of the low lb key bits into count[]; k_scan_buckets makes offs[]/cursor[];
+  // k_b_scatter reserves a range per (block, bin) with ONE global atomic and ranks inside it in LDS.
+  constexpr uint32_t CHUNKB_LOG = 17;
+
+  __global__ __launch_bounds__(1024) void k_b_plan(const uint32_t* __restrict__ offA, uint32_t* __restrict__ bstart, uint32_t nparts, int wpf, int hb, int nblk)
+  {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nparts + 1023) / 1024;
+    const uint32_t lo = min(nparts, threadIdx.x * per), hi = min(nparts, lo + per);
+    const uint32_t nparts_w = 1u << hb;
+    auto psize = [&](uint32_t p) -> uint32_t {
+      const uint32_t wp = p >> hb, h = p & (nparts_w - 1);
+      const size_t row = (size_t)p * nblk;
+      const uint32_t ps = offA[row];
+      const uint32_t pe = (h + 1 < nparts_w) ? offA[row + nblk] : offA[(size_t)wpf * nparts_w * nblk + wp];
+      return pe - ps;
+    };
+    uint32_t s = 0;
+    for (uint32_t p = lo; p < hi; p++)
+      s += (psize(p) + (1u << CHUNKB_LOG) - 1) >> CHUNKB_LOG;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t p = lo; p < hi; p++) {
+      bstart[p] = run;
+      run += (psize(p) + (1u << CHUNKB_LOG) - 1) >> CHUNKB_LOG;
+    }
+    if (threadIdx.x == 1023) bstart[nparts] = part[1023];
+  }
+
+  // block -> (partition p, element range [r0,r1) in the window's pass-A array); false if idle
+  __device__ __forceinline__ bool b_locate(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ offA, uint32_t nparts, int wpf, int hb, int nblk, uint32_t& p, uint32_t& r0, uint32_t& r1)
+  {
+    const uint32_t blk = blockIdx.x;
+    if (blk >= bstart[nparts]) return false;
+    uint32_t lo = 0, hi = nparts; // last p with bstart[p] <= blk
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (bstart[mid] <= blk) {
+        lo = mid;
+      } else {
+        hi = mid;
+      }
+    }
+    p = lo;
+    const uint32_t nparts_w = 1u << hb;
+    const uint32_t wp = p >> hb, h = p & (nparts_w - 1);
+    const size_t row = (size_t)p * nblk;
+    const uint32_t ps = offA[row];
+    const uint32_t pe = (h + 1 < nparts_w) ? offA[row + nblk] : offA[(size_t)wpf * nparts_w * nblk + wp];
+    r0 = ps + ((blk - bstart[p]) << CHUNKB_LOG);
+    r1 = min(pe, r0 + (1u << CHUNKB_LOG));
+    return r0 < r1;
+  }
+
+  __global__ __launch_bounds__(1024) void k_b_count(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ count, uint32_t nparts, int wpf, SortPlan sp, size_t cap, uint32_t nb)
+  {
+    extern __shared__ uint32_t lds[];
+    uint32_t p, r0, r1;
+    if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p, r0, r1)) return;
+    const uint32_t nbins = 1u << sp.lb;
+    for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x)
+      lds[k] = 0;
+    __syncthreads();
+    const uint32_t wp = p >> sp.hb, h = p & ((1u << sp.hb) - 1);
+    const uint32_t* src = inA + (size_t)wp * cap;
+    const int lshift = 31 - sp.lb;
+    const uint32_t lmask = nbins - 1;
+    for (uint32_t pos = r0 + threadIdx.x; pos < r1; pos += blockDim.x)
+      atomicAdd(&lds[(src[pos] >> lshift) & lmask], 1u);
+    __syncthreads();
+    uint32_t* cw = count + (size_t)wp * nb + ((size_t)h << sp.lb);
+    for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x)
+      if (lds[k]) atomicAdd(&cw[k], lds[k]);
   }
 
   // exclusive scan over the buckets of one window: one 1024-thread block per window
-  __global__ __launch_bounds__(1024) void k_scan_buckets(const uint32_t* __restrict__ count, uint32_t* __restrict__ offs, uint32_t nb)
+  __global__ __launch_bounds__(1024) void k_scan_buckets(const uint32_t* __restrict__ count, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor, uint32_t nb)
   {
     __shared__ uint32_t part[1024];
     const int wp = blockIdx.x;
     const uint32_t per = (nb + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = min(nb, lo + per);
+    const uint32_t lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
     uint32_t s = 0;
     for (uint32_t k = lo; k < hi; k++)
       s += count[(size_t)wp * nb + k];
     part[threadIdx.x] = s;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
     for (int d = 1; d < 1024; d <<= 1) {
-      uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
+      const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
       __syncthreads();
       part[threadIdx.x] += v;
       __syncthreads();
@@ -190,48 +371,125 @@ namespace icicle_hip {
     uint32_t run = part[threadIdx.x] - s;
     for (uint32_t k = lo; k < hi; k++) {
       offs[(size_t)wp * nb + k] = run;
+      cursor[(size_t)wp * nb + k] = run;
       run += count[(size_t)wp * nb + k];
     }
   }
 
-  __global__ __launch_bounds__(1024) void k_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ blockhist, const uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted, int n, int chunk, int nwin, int wpf, int pf, uint32_t nb, size_t cap)
+  __global__ __launch_bounds__(1024) void k_b_scatter(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted, uint32_t nparts, int wpf, int pf, SortPlan sp, size_t cap, uint32_t nb)
   {
-    extern __shared__ uint32_t lds[];
-    const int b = blockIdx.x, wp = blockIdx.y, B = gridDim.x;
-    const uint32_t* bh = blockhist + ((size_t)wp * B + b) * nb;
-    const uint32_t* of = offs + (size_t)wp * nb;
-    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x)
-      lds[k] = of[k] + bh[k];
+    extern __shared__ uint32_t lds[]; // [nbins] local count -> local cursor | [nbins] reserved base | [nblk+1] piece offsets
+    uint32_t p, r0, r1;
+    if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p, r0, r1)) return;
+    const uint32_t nbins = 1u << sp.lb;
+    uint32_t* lcnt = lds;
+    uint32_t* base = lds + nbins;
+    uint32_t* boffs = lds + 2 * nbins;
+    const uint32_t wp = p >> sp.hb, h = p & ((1u << sp.hb) - 1);
+    const uint32_t nparts_w = 1u << sp.hb;
+    const size_t row = (size_t)p * sp.nblk;
+    for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x)
+      lcnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k <= (uint32_t)sp.nblk; k += blockDim.x)
+      boffs[k] = (k < (uint32_t)sp.nblk) ? offA[row + k] : ((h + 1 < nparts_w) ? offA[row + sp.nblk] : offA[(size_t)wpf * nparts_w * sp.nblk + wp]);
     __syncthreads();
+    const uint32_t* src = inA + (size_t)wp * cap;
+    const int lshift = 31 - sp.lb;
+    const uint32_t lmask = nbins - 1;
+    for (uint32_t pos = r0 + threadIdx.x; pos < r1; pos += blockDim.x)
+      atomicAdd(&lcnt[(src[pos] >> lshift) & lmask], 1u);
+    __syncthreads();
+    uint32_t* cw = cursor + (size_t)wp * nb + ((size_t)h << sp.lb);
+    for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x) {
+      const uint32_t cnt = lcnt[k];
+      base[k] = cnt ? atomicAdd(&cw[k], cnt) : 0u;
+      lcnt[k] = 0;
+    }
+    __syncthreads();
+    // first source piece that reaches into [r0, r1): last b with boffs[b] <= r0
+    uint32_t blo = 0, bhi = sp.nblk;
+    while (bhi - blo > 1) {
+      const uint32_t mid = (blo + bhi) >> 1;
+      if (boffs[mid] <= r0) {
+        blo = mid;
+      } else {
+        bhi = mid;
+      }
+    }
     uint32_t* dst = sorted + (size_t)wp * cap;
-    const int lo = b * chunk, hi = min(n, lo + chunk);
-    for (int j = 0; j < pf; j++) {
-      const int w = j * wpf + wp;
-      if (w >= nwin) break;
-      const uint32_t* d = dig + (size_t)w * n;
-      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t e = d[i];
-        const uint32_t k = e & 0x7fffffffu;
-        if (k) {
-          const uint32_t pos = atomicAdd(&lds[k - 1], 1u);
-          dst[pos] = ((uint32_t)i * (uint32_t)pf + (uint32_t)j) | (e & 0x80000000u);
-        }
+    const uint32_t imask = (1u << (31 - sp.lb - sp.jb)) - 1;
+    const uint32_t jmask = (1u << sp.jb) - 1;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    // one wave per source piece: its scalar-index base is wave-uniform, no per-element search
+    for (uint32_t bsrc = blo + wave; bsrc < (uint32_t)sp.nblk; bsrc += nwaves) {
+      const uint32_t q0 = max(boffs[bsrc], r0), q1 = min(boffs[bsrc + 1], r1);
+      if (boffs[bsrc] >= r1) break;
+      const uint32_t ibase = bsrc << sp.chunk_log;
+      for (uint32_t pos = q0 + lane; pos < q1; pos += 64) {
+        const uint32_t el = src[pos];
+        const uint32_t bin = (el >> lshift) & lmask;
+        const uint32_t i = ibase + (el & imask);
+        const uint32_t j = (el >> (31 - sp.lb - sp.jb)) & jmask;
+        const uint32_t at = base[bin] + atomicAdd(&lcnt[bin], 1u);
+        dst[at] = (i * (uint32_t)pf + j) | (el & 0x80000000u);
       }
     }
   }
 
   // ------------------------------------------------------------------------------------------
-  // 4. bucket accumulation: thread per (window,bucket), XYZZ accumulator in registers.
+  // 4. bucket accumulation. Thread t < nbk owns bucket t and accumulates its first `seg` points
+  //    (XYZZ accumulator in registers); a bucket with more points (sparse top window, skewed scalars:
+  //    wrappers/rust/icicle-core/src/msm/tests.rs:256-304) gets overflow segments of `seg` points each,
+  //    planned by k_plan_overflow, accumulated by threads t >= nbk and folded in by k_fold_overflow.
+  struct OvfSeg {
+    uint32_t bucket; // global bucket id
+    uint32_t start;  // first point of this segment inside the bucket
+    uint32_t first;  // 1 if this is the first overflow segment of its bucket
+    uint32_t nextra; // number of overflow segments of the bucket (valid when first)
+  };
+
+  __global__ __launch_bounds__(256) void k_plan_overflow(const uint32_t* __restrict__ count, size_t nbk, uint32_t seg, uint32_t* __restrict__ ovf_count, OvfSeg* __restrict__ ovf, uint32_t ovf_cap)
+  {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nbk) return;
+    const uint32_t cnt = count[t];
+    if (cnt <= seg) return;
+    const uint32_t extra = (cnt + seg - 1) / seg - 1;
+    const uint32_t slot = atomicAdd(ovf_count, extra);
+    for (uint32_t sgi = 0; sgi < extra && slot + sgi < ovf_cap; sgi++) {
+      OvfSeg o;
+      o.bucket = (uint32_t)t;
+      o.start = (sgi + 1) * seg;
+      o.first = (sgi == 0);
+      o.nextra = extra;
+      ovf[slot + sgi] = o;
+    }
+  }
+
   template <class C>
-  __global__ __launch_bounds__(128) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, uint32_t nb, int wpf, size_t cap)
+  __global__ __launch_bounds__(128) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t nb, size_t nbk, size_t cap, uint32_t seg)
   {
     using E = EC<C>;
     constexpr int PW = 2 * E::N32; // words per affine point
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= (size_t)wpf * nb) return;
-    const size_t wp = t / nb;
-    const uint32_t cnt = count[t];
-    const uint32_t* src = sorted + wp * cap + offs[t];
+    size_t bucket;
+    uint32_t start;
+    typename E::Proj* dst;
+    if (t < nbk) {
+      bucket = t;
+      start = 0;
+      dst = buckets + t;
+    } else {
+      const size_t o = t - nbk;
+      if (o >= *ovf_count) return;
+      bucket = ovf[o].bucket;
+      start = ovf[o].start;
+      dst = ovf_part + o;
+    }
+    const size_t wp = bucket / nb;
+    const uint32_t total = count[bucket];
+    const uint32_t cnt = min(total - min(total, start), seg);
+    const uint32_t* src = sorted + wp * cap + offs[bucket] + start;
     typename E::XYZZ acc;
     bool empty = true;
     for (uint32_t j = 0; j < cnt; j++) {
@@ -250,7 +508,21 @@ namespace icicle_hip {
       typename E::Aff a = E::cneg(E::load_mont(w), (e >> 31) != 0);
       E::madd(acc, empty, a);
     }
-    buckets[t] = E::to_proj(acc, empty);
+    *dst = E::to_proj(acc, empty);
+  }
+
+  // buckets[b] += its overflow partials (one thread per overflowing bucket)
+  template <class C>
+  __global__ __launch_bounds__(64) void k_fold_overflow(typename EC<C>::Proj* __restrict__ buckets, const typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t ovf_cap)
+  {
+    using E = EC<C>;
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = min(*ovf_count, ovf_cap);
+    if (o >= n || !ovf[o].first) return;
+    typename E::Proj acc = buckets[ovf[o].bucket];
+    for (uint32_t k = 0; k < ovf[o].nextra && o + k < n; k++)
+      acc = E::add(acc, ovf_part[o + k]);
+    buckets[ovf[o].bucket] = acc;
   }
 
   // ------------------------------------------------------------------------------------------
@@ -276,19 +548,20 @@ namespace icicle_hip {
     segval[t] = tri;
   }
 
-  // 5b. one wave per window: each lane folds nseg/64 segment values, then a 64-wide tree through LDS
+  // 5b. one 256-thread block per window: each thread folds nseg/256 segment values, then a tree
+  //     through LDS (4 waves keep the serial part short: it is latency-, not throughput-bound)
   template <class C>
-  __global__ __launch_bounds__(64) void k_reduce_window(const typename EC<C>::Proj* __restrict__ segval, typename EC<C>::Proj* __restrict__ winsum, uint32_t nseg)
+  __global__ __launch_bounds__(256) void k_reduce_window(const typename EC<C>::Proj* __restrict__ segval, typename EC<C>::Proj* __restrict__ winsum, uint32_t nseg)
   {
     using E = EC<C>;
-    __shared__ typename E::Proj sh[64];
+    __shared__ typename E::Proj sh[256];
     const int wp = blockIdx.x, lane = threadIdx.x;
     typename E::Proj v = E::proj_identity();
-    for (uint32_t s = lane; s < nseg; s += 64)
+    for (uint32_t s = lane; s < nseg; s += 256)
       v = E::add(v, segval[(size_t)wp * nseg + s]);
     sh[lane] = v;
     __syncthreads();
-    for (int s = 32; s >= 1; s >>= 1) {
+    for (int s = 128; s >= 1; s >>= 1) {
       if (lane < s) {
         v = E::add(v, sh[lane + s]);
         sh[lane] = v;
@@ -522,24 +795,63 @@ namespace icicle_hip {
     const uint32_t nb = pl.nb;
     const int wpf = pl.wpf;
     const size_t cap = npts_one; // sorted-index capacity per target window
-    const int B = (int)std::min<size_t>(64, ((size_t)n + 16383) / 16384);
-    const int chunk = (n + B - 1) / B;
+    const size_t nbk = (size_t)wpf * nb;
+    // two-level sort geometry
+    SortPlan sp;
+    {
+      const int kb = pl.c - 1;
+      // pass A keeps wpf * 2^hb write streams open per block: few enough for L2 / Infinity Cache to
+      // assemble full lines, while pass B's 2^lb bins must fit LDS
+      int hb_cap = 10;
+      if (const char* e = getenv("ICICLE_HIP_MSM_HB")) hb_cap = atoi(e);
+      int hb = std::min(kb, hb_cap);
+      while (hb > 0 && ((size_t)wpf << hb) * 4 > 64 * 1024) // pass-A count keeps wpf * 2^hb counters in LDS
+        hb--;
+      if (kb - hb > 13) return ICICLE_INVALID_ARGUMENT;
+      sp.hb = hb;
+      sp.lb = kb - hb;
+      sp.jb = 0;
+      while ((1 << sp.jb) < pf)
+        sp.jb++;
+      int logn = 0;
+      while (((size_t)1 << logn) < (size_t)n)
+        logn++;
+      const int max_chunk = 31 - sp.lb - sp.jb;
+      if (max_chunk < 10) return ICICLE_INVALID_ARGUMENT;
+      sp.chunk_log = std::max(10, std::min(std::min(17, max_chunk), logn - 9));
+      sp.nblk = (int)(((size_t)n + ((size_t)1 << sp.chunk_log) - 1) >> sp.chunk_log);
+    }
+    const size_t nparts = (size_t)wpf << sp.hb;
+    const size_t tabA = nparts * sp.nblk + wpf; // [wp][h][b] counters + per-window totals
     const uint32_t m = std::min<uint32_t>(nb, 32);
     const uint32_t nseg = nb / m;
-    TempBuf d_mont, d_dig, d_sorted, d_bh, d_count, d_offs, d_buckets, d_seg, d_win;
+    const size_t ovf_cap_sz = ((size_t)n * pl.nwin) / pl.seg + 16;
+    const uint32_t ovf_cap = (uint32_t)std::min<size_t>(ovf_cap_sz, 0x7fffffffu);
+    const uint32_t maxblkB = (uint32_t)(nparts + (((size_t)n * pl.nwin) >> CHUNKB_LOG) + 2);
+    TempBuf d_mont, d_partA, d_sorted, d_cntA, d_offA, d_count, d_offs, d_cursor, d_bstart, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt;
+    HIP_TRY(d_cursor.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_bstart.alloc((nparts + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_mont.alloc(npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_dig.alloc((size_t)pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_partA.alloc((size_t)wpf * cap * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_sorted.alloc((size_t)wpf * cap * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_bh.alloc((size_t)wpf * B * nb * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_count.alloc((size_t)wpf * nb * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_offs.alloc((size_t)wpf * nb * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_buckets.alloc((size_t)wpf * nb * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_cntA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_offA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_count.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_offs.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_buckets.alloc(nbk * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_seg.alloc((size_t)wpf * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_win.alloc((size_t)wpf * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovfcnt.alloc(16, st), ICICLE_ALLOCATION_FAILED);
 
-    const size_t lds_bytes = (size_t)nb * 4;
-    HIP_TRY(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 131072), ICICLE_INVALID_ARGUMENT);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 131072), ICICLE_INVALID_ARGUMENT);
+    const size_t ldsA = nparts * 4;
+    const size_t ldsB = (2 * ((size_t)1 << sp.lb) + sp.nblk + 1) * 4;
+    if (ldsB > 150 * 1024 || nparts > 16384) return ICICLE_INVALID_ARGUMENT;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_part_a<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_part_a<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_b_count, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_b_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
 
     for (int b = 0; b < batch; b++) {
       if (b == 0 || !shared) {
@@ -548,25 +860,42 @@ namespace icicle_hip {
         k_bases_to_mont<C><<<dim3((unsigned)((ncoord + 255) / 256)), 256, 0, st>>>(src, d_mont.as<uint32_t>(), ncoord, cfg->are_points_montgomery_form);
         LAUNCH_CHECK("k_bases_to_mont", st);
       }
-      k_digits<C><<<(n + 255) / 256, 256, 0, st>>>(d_scalars + (size_t)b * n * FR::N32, d_dig.as<uint32_t>(), n, pl.c, pl.nwin, cfg->are_scalars_montgomery_form);
-      LAUNCH_CHECK("k_digits", st);
-      k_hist<<<dim3(B, wpf), 1024, lds_bytes, st>>>(d_dig.as<uint32_t>(), d_bh.as<uint32_t>(), n, chunk, pl.nwin, wpf, pf, nb);
-      LAUNCH_CHECK("k_hist", st);
-      const size_t nbk = (size_t)wpf * nb;
-      k_scan_blocks<<<(unsigned)((nbk + 255) / 256), 256, 0, st>>>(d_bh.as<uint32_t>(), d_count.as<uint32_t>(), B, nb, wpf);
-      LAUNCH_CHECK("k_scan_blocks", st);
-      k_scan_buckets<<<wpf, 1024, 0, st>>>(d_count.as<uint32_t>(), d_offs.as<uint32_t>(), nb);
+      const uint32_t* sc = d_scalars + (size_t)b * n * FR::N32;
+      const bool smont = cfg->are_scalars_montgomery_form;
+      k_part_a<C, true><<<sp.nblk, 1024, ldsA, st>>>(sc, d_cntA.as<uint32_t>(), nullptr, nullptr, n, pl.c, pl.nwin, wpf, pf, sp, cap, smont);
+      LAUNCH_CHECK("k_part_a<count>", st);
+      k_scan_a<<<wpf, 1024, 0, st>>>(d_cntA.as<uint32_t>(), d_offA.as<uint32_t>(), (uint32_t)(((size_t)1 << sp.hb) * sp.nblk));
+      LAUNCH_CHECK("k_scan_a", st);
+      static const bool per_window_scatter = (getenv("ICICLE_HIP_MSM_AWIN") != nullptr);
+      if (per_window_scatter) {
+        k_part_a_scatter<C><<<dim3(wpf, sp.nblk), 1024, ((size_t)1 << sp.hb) * 4, st>>>(sc, d_offA.as<uint32_t>(), d_partA.as<uint32_t>(), n, pl.c, pl.nwin, wpf, pf, sp, cap, smont);
+      } else {
+        k_part_a<C, false><<<sp.nblk, 1024, ldsA, st>>>(sc, nullptr, d_offA.as<uint32_t>(), d_partA.as<uint32_t>(), n, pl.c, pl.nwin, wpf, pf, sp, cap, smont);
+      }
+      LAUNCH_CHECK("k_part_a_scatter", st);
+      k_b_plan<<<1, 1024, 0, st>>>(d_offA.as<uint32_t>(), d_bstart.as<uint32_t>(), (uint32_t)nparts, wpf, sp.hb, sp.nblk);
+      LAUNCH_CHECK("k_b_plan", st);
+      HIP_TRY(hipMemsetAsync(d_count.ptr(), 0, nbk * 4, st), ICICLE_COPY_FAILED);
+      k_b_count<<<maxblkB, 1024, ((size_t)1 << sp.lb) * 4, st>>>(d_partA.as<uint32_t>(), d_offA.as<uint32_t>(), d_bstart.as<uint32_t>(), d_count.as<uint32_t>(), (uint32_t)nparts, wpf, sp, cap, nb);
+      LAUNCH_CHECK("k_b_count", st);
+      k_scan_buckets<<<wpf, 1024, 0, st>>>(d_count.as<uint32_t>(), d_offs.as<uint32_t>(), d_cursor.as<uint32_t>(), nb);
       LAUNCH_CHECK("k_scan_buckets", st);
-      k_scatter<<<dim3(B, wpf), 1024, lds_bytes, st>>>(d_dig.as<uint32_t>(), d_bh.as<uint32_t>(), d_offs.as<uint32_t>(), d_sorted.as<uint32_t>(), n, chunk, pl.nwin, wpf, pf, nb, cap);
-      LAUNCH_CHECK("k_scatter", st);
+      k_b_scatter<<<maxblkB, 1024, ldsB, st>>>(d_partA.as<uint32_t>(), d_offA.as<uint32_t>(), d_bstart.as<uint32_t>(), d_cursor.as<uint32_t>(), d_sorted.as<uint32_t>(), (uint32_t)nparts, wpf, pf, sp, cap, nb);
+      LAUNCH_CHECK("k_b_scatter", st);
+      HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16, st), ICICLE_COPY_FAILED);
+      k_plan_overflow<<<(unsigned)((nbk + 255) / 256), 256, 0, st>>>(d_count.as<uint32_t>(), nbk, pl.seg, d_ovfcnt.as<uint32_t>(), d_ovf.as<OvfSeg>(), ovf_cap);
+      LAUNCH_CHECK("k_plan_overflow", st);
       KernelTimer::begin(0, st);
-      k_accumulate<C><<<(unsigned)((nbk + 127) / 128), 128, 0, st>>>(d_mont.as<uint32_t>(), d_sorted.as<uint32_t>(), d_count.as<uint32_t>(), d_offs.as<uint32_t>(), d_buckets.as<typename E::Proj>(), nb, wpf, cap);
+      const size_t nthreads_acc = nbk + ovf_cap;
+      k_accumulate<C><<<(unsigned)((nthreads_acc + 127) / 128), 128, 0, st>>>(d_mont.as<uint32_t>(), d_sorted.as<uint32_t>(), d_count.as<uint32_t>(), d_offs.as<uint32_t>(), d_buckets.as<typename E::Proj>(), d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), nb, nbk, cap, pl.seg);
       LAUNCH_CHECK("k_accumulate", st);
       KernelTimer::end(0, st);
+      k_fold_overflow<C><<<(ovf_cap + 63) / 64, 64, 0, st>>>(d_buckets.as<typename E::Proj>(), d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
+      LAUNCH_CHECK("k_fold_overflow", st);
       const size_t nsg = (size_t)wpf * nseg;
       k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(d_buckets.as<typename E::Proj>(), d_seg.as<typename E::Proj>(), nb, m, wpf);
       LAUNCH_CHECK("k_reduce_segments", st);
-      k_reduce_window<C><<<wpf, 64, 0, st>>>(d_seg.as<typename E::Proj>(), d_win.as<typename E::Proj>(), nseg);
+      k_reduce_window<C><<<wpf, 256, 0, st>>>(d_seg.as<typename E::Proj>(), d_win.as<typename E::Proj>(), nseg);
       LAUNCH_CHECK("k_reduce_window", st);
       k_final<C><<<1, 128, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b * RW, wpf, pl.c);
       LAUNCH_CHECK("k_final", st);
