@@ -117,7 +117,10 @@ API_SYMBOLS = (
     [f"{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
     + [f"{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
                                                "get_root_of_unity_from_domain", "extension_ntt")]
-    + ["icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing"]
+    + ["icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device"]
+    + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
+    + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
+                                                          "get_root_of_unity_from_domain")]
 )
 
 if not os.path.exists(LIB_PATH):

@@ -1001,6 +1001,12 @@ icicle_error_t bls12_381_msm_precompute_bases(const void* input_bases, int nof_b
 {
   GUARDED(msm_precompute_run<bls12_381_g1>(input_bases, nof_bases, config, output_bases));
 }
+// Collision-free aliases for the reference-runtime plugin (plugin/): inside a process that also loads
+// the reference's libicicle_curve_<c>.so, the plain names above belong to the reference frontend.
+icicle_error_t icicle_hip_bn254_msm(const void* s, const void* b, int n, const icicle_msm_config_t* c, void* r) { GUARDED(msm_run<bn254_g1>(s, b, n, c, r)); }
+icicle_error_t icicle_hip_bn254_msm_precompute_bases(const void* i, int n, const icicle_msm_config_t* c, void* o) { GUARDED(msm_precompute_run<bn254_g1>(i, n, c, o)); }
+icicle_error_t icicle_hip_bls12_381_msm(const void* s, const void* b, int n, const icicle_msm_config_t* c, void* r) { GUARDED(msm_run<bls12_381_g1>(s, b, n, c, r)); }
+icicle_error_t icicle_hip_bls12_381_msm_precompute_bases(const void* i, int n, const icicle_msm_config_t* c, void* o) { GUARDED(msm_precompute_run<bls12_381_g1>(i, n, c, o)); }
 icicle_error_t bn254_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream)
 {
   GUARDED(proj_sum_run<bn254_g1>(points, n, out, (hipStream_t)stream));

@@ -763,5 +763,15 @@ using namespace icicle_hip;
     GUARDED(ntt_rou_from_domain_run<F##_params>(logn, rou));                                                           \
   }
 
+// collision-free aliases for the reference-runtime plugin (see msm.hip)
+#define DEFINE_NTT_ALIASES(F)                                                                                          \
+  extern "C" icicle_error_t icicle_hip_##F##_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u32_t* c, uint32_t* o) { GUARDED(ntt_run<F##_params>(i, n, d, c, o, 1)); } \
+  extern "C" icicle_error_t icicle_hip_##F##_extension_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u32_t* c, uint32_t* o) { GUARDED(ntt_run<F##_params>(i, n, d, c, o, 4)); } \
+  extern "C" icicle_error_t icicle_hip_##F##_ntt_init_domain(const uint32_t* r, const icicle_ntt_init_domain_config_t* c) { GUARDED(ntt_init_domain_run<F##_params>(r, c)); } \
+  extern "C" icicle_error_t icicle_hip_##F##_ntt_release_domain(void) { GUARDED(ntt_release_domain_run<F##_params>()); } \
+  extern "C" icicle_error_t icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t l, uint32_t* r) { GUARDED(ntt_rou_from_domain_run<F##_params>(l, r)); }
+DEFINE_NTT_ALIASES(babybear)
+DEFINE_NTT_ALIASES(koalabear)
+
 DEFINE_NTT_U32(babybear)
 DEFINE_NTT_U32(koalabear)

@@ -227,6 +227,16 @@ icicle_error_t icicle_hip_kernel_timing(int which, bool reset, double* total_ms,
   return ICICLE_SUCCESS;
 }
 
+// plugin helper: select the GPU for the calling thread without going through icicle_set_device
+// (whose name belongs to the reference runtime when both libraries live in one process)
+icicle_error_t icicle_hip_set_device(int id)
+{
+  if (id < 0 || id >= device_count_cached()) return ICICLE_INVALID_DEVICE;
+  HIP_TRY(hipSetDevice(id), ICICLE_INVALID_DEVICE);
+  t_device = id;
+  return ICICLE_SUCCESS;
+}
+
 icicle_error_t icicle_load_backend(const char*, bool) { return ICICLE_SUCCESS; }
 icicle_error_t icicle_load_backend_from_env_or_default(void) { return ICICLE_SUCCESS; }
 

@@ -179,6 +179,23 @@ icicle_error_t bls12_381_hip_projective_sum(const void* points, int n, void* out
 icicle_error_t icicle_hip_kernel_timing(int which, bool reset, double* total_ms, int* launches);
 icicle_error_t icicle_hip_enable_kernel_timing(bool enable);
 
+/* ---- collision-free aliases used by the reference-runtime plugin (plugin/):
+ * same functions as the un-prefixed names above, for processes that also load the reference's own
+ * libicicle_device / libicicle_curve_<c> / libicicle_field_<f>, which define those names. ---- */
+icicle_error_t icicle_hip_set_device(int device_id);
+icicle_error_t icicle_hip_bn254_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
+icicle_error_t icicle_hip_bn254_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
+icicle_error_t icicle_hip_bls12_381_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
+icicle_error_t icicle_hip_bls12_381_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
+#define ICICLE_HIP_DECLARE_NTT_ALIASES(F)                                                                              \
+  icicle_error_t icicle_hip_##F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* config, uint32_t* output); \
+  icicle_error_t icicle_hip_##F##_extension_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* config, uint32_t* output); \
+  icicle_error_t icicle_hip_##F##_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config); \
+  icicle_error_t icicle_hip_##F##_ntt_release_domain(void);                                                            \
+  icicle_error_t icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);
+ICICLE_HIP_DECLARE_NTT_ALIASES(babybear)
+ICICLE_HIP_DECLARE_NTT_ALIASES(koalabear)
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,64 @@ def _p(a: np.ndarray):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class Device(ctypes.Structure):  # icicle/include/icicle/device.h:14-48
+    _fields_ = [("type", ctypes.c_char * 64), ("id", ctypes.c_int)]
+
+
+class RefRuntime:
+    """The reference's own runtime C ABI (libicicle_device.so): backend loading, device selection,
+    memory. Used by tests/test_gpu_plugin.py to drive the HIP backend the way a reference user would."""
+
+    def __init__(self):
+        self.lib = _load("device")
+        self.lib.icicle_malloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        self.lib.icicle_free.argtypes = [ctypes.c_void_p]
+        for n in ("icicle_copy", "icicle_copy_to_host", "icicle_copy_to_device"):
+            getattr(self.lib, n).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self.lib.icicle_memset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        self.lib.icicle_is_host_memory.argtypes = [ctypes.c_void_p]
+        self.lib.icicle_is_active_device_memory.argtypes = [ctypes.c_void_p]
+        self.lib.icicle_load_backend.argtypes = [ctypes.c_char_p, ctypes.c_bool]
+        self.lib.icicle_get_registered_devices.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        self.lib.icicle_create_stream.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.lib.icicle_destroy_stream.argtypes = [ctypes.c_void_p]
+        self.lib.icicle_stream_synchronize.argtypes = [ctypes.c_void_p]
+
+    def load_backend(self, path: str) -> int:
+        return self.lib.icicle_load_backend(path.encode(), True)
+
+    def registered_devices(self) -> str:
+        buf = ctypes.create_string_buffer(256)
+        self.lib.icicle_get_registered_devices(buf, 256)
+        return buf.value.decode()
+
+    def set_device(self, dtype: str, did: int = 0) -> int:
+        d = Device(dtype.encode(), did)
+        return self.lib.icicle_set_device(ctypes.byref(d))
+
+    def get_device_count(self) -> int:
+        n = ctypes.c_int()
+        self.lib.icicle_get_device_count(ctypes.byref(n))
+        return n.value
+
+    def malloc(self, nbytes: int):
+        p = ctypes.c_void_p()
+        rc = self.lib.icicle_malloc(ctypes.byref(p), nbytes)
+        return rc, p.value
+
+    def free(self, ptr) -> int:
+        return self.lib.icicle_free(ptr)
+
+    def to_device(self, ptr, arr: np.ndarray) -> int:
+        return self.lib.icicle_copy_to_device(ptr, arr.ctypes.data, arr.nbytes)
+
+    def to_host(self, arr: np.ndarray, ptr) -> int:
+        return self.lib.icicle_copy_to_host(arr.ctypes.data, ptr, arr.nbytes)
+
+    def copy(self, dst, src, nbytes) -> int:
+        return self.lib.icicle_copy(dst, src, nbytes)
+
+
 class RefCurve:
     """bn254 / bls12_381 through the reference's own C ABI, on its "CPU" device."""
 
@@ -78,6 +136,7 @@ class RefCurve:
 
     def msm(self, scalars: np.ndarray, bases: np.ndarray, batch=1, shared=True, precompute_factor=1, c=0, bitsize=0,
             scalars_mont=False, points_mont=False, n_threads=0):
+        """runs on whatever device is active for the calling thread ("CPU" unless RefRuntime.set_device was used)"""
         n = scalars.size // 8 // batch
         cfg = MSMConfig(None, precompute_factor, c, bitsize, batch, shared, False, scalars_mont, False, points_mont,
                         False, False, None)
@@ -196,3 +255,10 @@ class RefNttField:
         rc = fn(_p(inp), size, direction, ctypes.byref(cfg), _p(out))
         assert rc == 0, f"reference ntt failed rc={rc}"
         return out
+
+    def ntt_device(self, d_in, d_out, size: int, direction: int, batch=1, ordering=0, coset_gen=1) -> int:
+        """device-resident operands allocated through the reference runtime (icicle_malloc)"""
+        cfg = NTTConfigU32(None, coset_gen, batch, False, ordering, True, True, False, None)
+        fn = getattr(self.lib, f"{self.name}_ntt")
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        return fn(d_in, size, direction, ctypes.byref(cfg), d_out)

@@ -1,0 +1,37 @@
+#!/usr/bin/env bash
+# Builds the reference-runtime plugin DSOs (the drop-in form of this backend) against the reference
+# headers and the reference libraries built by oracle/build_ref.sh. Needs /root/reference; outputs
+# travel to the GPU box under oracle/_ref/backend/hip/ (git-ignored):
+#   libicicle_backend_hip_device.so           "HIP" DeviceAPI            (RTLD_GLOBAL by name)
+#   libicicle_backend_hip_curve_<c>.so        msm + msm_precompute_bases
+#   libicicle_backend_hip_field_<f>.so        ntt family + extension ntt
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(dirname "$HERE")"
+R="${ICICLE_REFERENCE_DIR:-/root/reference}/icicle"
+REF="$ROOT/oracle/_ref"
+OUT="$REF/backend/hip"
+HIPLIB="$ROOT/icicle_amd/lib"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+if [ ! -d "$R" ]; then echo "build_plugin: $R not present -- using prebuilt plugin if any" >&2; exit 0; fi
+[ -f "$REF/libicicle_device.so" ] || "$ROOT/oracle/build_ref.sh"
+mkdir -p "$OUT"
+FLAGS="-std=c++17 -O2 -fPIC -shared -w -I$R/include"
+CXX="${ORACLE_CXX:-/opt/rocm/lib/llvm/bin/clang++}"   # curve/field parts are plain C++ (no HIP headers)
+RP="-Wl,-rpath,\$ORIGIN/../..:\$ORIGIN/../../../../icicle_amd/lib"
+echo "[plugin] device"
+# host-only C++ against the HIP runtime API (no kernels here): plain clang++, the HIP headers need the platform define
+$CXX $FLAGS -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$HERE/hip_backend_device.cpp" -L"$REF" -licicle_device -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib $RP -o "$OUT/libicicle_backend_hip_device.so"
+for spec in bn254:1 bls12_381:2; do
+  c=${spec%%:*}; id=${spec##*:}
+  echo "[plugin] curve $c"
+  $CXX $FLAGS -DCURVE_ID=$id -DFIELD_ID=$id -DCURVE=$c -DFIELD=$c -DICICLE_FFI_PREFIX=$c -DMSM=ON "$HERE/hip_backend_curve.cpp" \
+    -L"$REF" -licicle_curve_$c -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_curve_$c.so"
+done
+for spec in babybear:1001 koalabear:1004; do
+  f=${spec%%:*}; id=${spec##*:}
+  echo "[plugin] field $f"
+  $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$f -DICICLE_FFI_PREFIX=$f -DNTT=ON -DEXT_FIELD=ON "$HERE/hip_backend_field.cpp" \
+    -L"$REF" -licicle_field_$f -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_field_$f.so"
+done
+ls -la "$OUT"

@@ -1,0 +1,43 @@
+// Reference-runtime plugin, part 2/3: MSM for one curve (compile once per curve with the reference's
+// own defines: -DCURVE_ID=<n> -DFIELD_ID=<n> -DICICLE_FFI_PREFIX=<curve>, icicle/cmake/curve.cmake:43-76).
+// Registers functions with exactly the MsmImpl / MsmPreComputeImpl signatures
+// (icicle/include/icicle/backend/msm_backend.h:11-44) under device type "HIP"; each forwards to the
+// collision-free C entry points of libicicle_hip.so (include/icicle_hip.h). MSMConfig is passed
+// through byte-for-byte (same 40-byte layout) except `ext`, whose C++ object belongs to the reference.
+#include <cstring>
+#include "icicle/backend/msm_backend.h"
+#include "icicle/curves/curve_config.h"
+#include "icicle/utils/utils.h"
+#include "hip_c_api.h"
+
+using namespace curve_config;
+using namespace icicle;
+
+#define HIP_FN(name) CONCAT_EXPAND(CONCAT_EXPAND(icicle_hip, ICICLE_FFI_PREFIX), name)
+
+static_assert(sizeof(MSMConfig) == sizeof(hip_msm_config_t), "MSMConfig layout drifted");
+
+static hip_msm_config_t translate(const MSMConfig& c)
+{
+  hip_msm_config_t o;
+  std::memcpy(&o, &c, sizeof(o));
+  o.ext = nullptr; // foreign ConfigExtension object: tolerated and ignored
+  return o;
+}
+
+static eIcicleError hip_msm(const Device& device, const scalar_t* scalars, const affine_t* bases, int msm_size, const MSMConfig& config, projective_t* results)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_msm_config_t c = translate(config);
+  return (eIcicleError)HIP_FN(msm)(scalars, bases, msm_size, &c, results);
+}
+
+static eIcicleError hip_msm_precompute(const Device& device, const affine_t* input_bases, int nof_bases, const MSMConfig& config, affine_t* output_bases)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_msm_config_t c = translate(config);
+  return (eIcicleError)HIP_FN(msm_precompute_bases)(input_bases, nof_bases, &c, output_bases);
+}
+
+REGISTER_MSM_BACKEND("HIP", hip_msm);
+REGISTER_MSM_PRE_COMPUTE_BASES_BACKEND("HIP", hip_msm_precompute);

@@ -1,0 +1,117 @@
+// Reference-runtime plugin, part 1/3: the "HIP" DeviceAPI.
+//
+// Compiled AGAINST the reference headers (it must be: the registration ABI is C++ -- a DeviceAPI
+// subclass and std::function signatures with the reference's template types) and
+// loaded by the reference's own icicle_load_backend() (icicle/src/runtime.cpp:288-353; the file name
+// must contain "icicle_backend", and "device" so that it is opened RTLD_GLOBAL, :310-319).
+// Implements the 16 pure virtuals of icicle/include/icicle/device_api.h:44-182 directly on HIP --
+// it deliberately does NOT call libicicle_hip.so's icicle_* runtime functions, whose names collide
+// with the reference runtime living in the same process.
+// Structural model: the reference's only in-tree GPU DeviceAPI,
+// icicle/backend/cuda_pqc/src/cuda_pqc_device_api.cu:11-121 (not copied; different API, same contract).
+#include <hip/hip_runtime_api.h>
+#include "icicle/device_api.h"
+#include "icicle/errors.h"
+
+using namespace icicle;
+
+namespace {
+  eIcicleError tr(hipError_t e, eIcicleError dflt)
+  {
+    if (e == hipSuccess) return eIcicleError::SUCCESS;
+    (void)hipGetLastError();
+    switch (e) {
+    case hipErrorInvalidDevice: return eIcicleError::INVALID_DEVICE;
+    case hipErrorOutOfMemory: return eIcicleError::OUT_OF_MEMORY;
+    case hipErrorInvalidDevicePointer: return eIcicleError::INVALID_POINTER;
+    default: return dflt;
+    }
+  }
+  hipMemcpyKind kind(eCopyDirection d)
+  {
+    switch (d) {
+    case eCopyDirection::HostToDevice: return hipMemcpyHostToDevice;
+    case eCopyDirection::DeviceToHost: return hipMemcpyDeviceToHost;
+    case eCopyDirection::DeviceToDevice: return hipMemcpyDeviceToDevice;
+    default: return hipMemcpyDefault;
+    }
+  }
+} // namespace
+
+class HipDeviceAPI : public DeviceAPI
+{
+public:
+  eIcicleError set_device(const Device& device) override
+  {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+      (void)hipGetLastError();
+      return eIcicleError::INVALID_DEVICE;
+    }
+    if (device.id < 0 || device.id >= n) return eIcicleError::INVALID_DEVICE; // tests/test_device_api.cpp:183-189
+    return tr(hipSetDevice(device.id), eIcicleError::INVALID_DEVICE);
+  }
+  eIcicleError get_device_count(int& device_count) const override
+  {
+    return tr(hipGetDeviceCount(&device_count), eIcicleError::INVALID_DEVICE);
+  }
+  eIcicleError allocate_memory(void** ptr, size_t size) const override
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size > total_b) return eIcicleError::OUT_OF_MEMORY;
+    return tr(hipMalloc(ptr, size ? size : 1), eIcicleError::ALLOCATION_FAILED);
+  }
+  eIcicleError allocate_memory_async(void** ptr, size_t size, icicleStreamHandle stream) const override
+  {
+    return tr(hipMallocAsync(ptr, size ? size : 1, (hipStream_t)stream), eIcicleError::ALLOCATION_FAILED);
+  }
+  eIcicleError free_memory(void* ptr) const override { return tr(hipFree(ptr), eIcicleError::DEALLOCATION_FAILED); }
+  eIcicleError free_memory_async(void* ptr, icicleStreamHandle stream) const override
+  {
+    return tr(hipFreeAsync(ptr, (hipStream_t)stream), eIcicleError::DEALLOCATION_FAILED);
+  }
+  eIcicleError get_available_memory(size_t& total, size_t& free) const override
+  {
+    return tr(hipMemGetInfo(&free, &total), eIcicleError::INVALID_DEVICE);
+  }
+  eIcicleError memset(void* ptr, int value, size_t size) const override
+  {
+    return tr(hipMemset(ptr, value, size), eIcicleError::COPY_FAILED);
+  }
+  eIcicleError memset_async(void* ptr, int value, size_t size, icicleStreamHandle stream) const override
+  {
+    return tr(hipMemsetAsync(ptr, value, size, (hipStream_t)stream), eIcicleError::COPY_FAILED);
+  }
+  eIcicleError copy(void* dst, const void* src, size_t size, eCopyDirection direction) const override
+  {
+    return tr(hipMemcpy(dst, src, size, kind(direction)), eIcicleError::COPY_FAILED);
+  }
+  eIcicleError copy_async(void* dst, const void* src, size_t size, eCopyDirection direction, icicleStreamHandle stream) const override
+  {
+    return tr(hipMemcpyAsync(dst, src, size, kind(direction), (hipStream_t)stream), eIcicleError::COPY_FAILED);
+  }
+  eIcicleError synchronize(icicleStreamHandle stream = nullptr) const override
+  {
+    return tr(stream ? hipStreamSynchronize((hipStream_t)stream) : hipDeviceSynchronize(), eIcicleError::SYNCHRONIZATION_FAILED);
+  }
+  eIcicleError create_stream(icicleStreamHandle* stream) const override
+  {
+    hipStream_t s;
+    eIcicleError e = tr(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), eIcicleError::STREAM_CREATION_FAILED);
+    if (e == eIcicleError::SUCCESS) *stream = (icicleStreamHandle)s;
+    return e;
+  }
+  eIcicleError destroy_stream(icicleStreamHandle stream) const override
+  {
+    return tr(hipStreamDestroy((hipStream_t)stream), eIcicleError::STREAM_DESTRUCTION_FAILED);
+  }
+  eIcicleError get_device_properties(DeviceProperties& properties) const override
+  {
+    properties.using_host_memory = false;
+    properties.num_memory_regions = 0;
+    properties.supports_pinned_memory = true;
+    return eIcicleError::SUCCESS;
+  }
+};
+
+REGISTER_DEVICE_API("HIP", HipDeviceAPI);

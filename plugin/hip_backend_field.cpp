@@ -1,0 +1,68 @@
+// Reference-runtime plugin, part 3/3: NTT for one 31-bit field (compile once per field with
+// -DFIELD_ID=<n> -DICICLE_FFI_PREFIX=<field> -DNTT=ON -DEXT_FIELD=ON, icicle/cmake/field.cmake:42-79).
+// Registers all four members of the NTT API family (a missing member makes the reference dispatcher
+// THROW through its extern "C" shim) plus the extension-field NTT, with the
+// signatures of icicle/include/icicle/backend/ntt_backend.h:13-93.
+#include <cstring>
+#include "icicle/backend/ntt_backend.h"
+#include "icicle/fields/field_config.h"
+#include "icicle/utils/utils.h"
+#include "hip_c_api.h"
+
+using namespace field_config;
+using namespace icicle;
+
+#define HIP_FN(name) CONCAT_EXPAND(CONCAT_EXPAND(icicle_hip, ICICLE_FFI_PREFIX), name)
+
+static_assert(sizeof(scalar_t) == 4, "this plugin covers the 31-bit NTT fields");
+static_assert(sizeof(NTTConfig<scalar_t>) == sizeof(hip_ntt_config_u32_t), "NTTConfig layout drifted");
+static_assert(sizeof(NTTInitDomainConfig) == sizeof(hip_ntt_init_domain_config_t), "NTTInitDomainConfig layout drifted");
+
+static hip_ntt_config_u32_t translate(const NTTConfig<scalar_t>& c)
+{
+  hip_ntt_config_u32_t o;
+  std::memcpy(&o, &c, sizeof(o));
+  o.ext = nullptr;
+  return o;
+}
+
+static eIcicleError hip_ntt(const Device& device, const scalar_t* input, int size, NTTDir dir, const NTTConfig<scalar_t>& config, scalar_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_ntt_config_u32_t c = translate(config);
+  return (eIcicleError)HIP_FN(ntt)((const uint32_t*)input, size, (int)dir, &c, (uint32_t*)output);
+}
+
+static eIcicleError hip_ext_ntt(const Device& device, const extension_t* input, int size, NTTDir dir, const NTTConfig<scalar_t>& config, extension_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_ntt_config_u32_t c = translate(config);
+  return (eIcicleError)HIP_FN(extension_ntt)((const uint32_t*)input, size, (int)dir, &c, (uint32_t*)output);
+}
+
+static eIcicleError hip_ntt_init_domain(const Device& device, const scalar_t& primitive_root, const NTTInitDomainConfig& config)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  hip_ntt_init_domain_config_t c;
+  std::memcpy(&c, &config, sizeof(c));
+  c.ext = nullptr;
+  return (eIcicleError)HIP_FN(ntt_init_domain)((const uint32_t*)&primitive_root, &c);
+}
+
+static eIcicleError hip_ntt_release_domain(const Device& device, const scalar_t&)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  return (eIcicleError)HIP_FN(ntt_release_domain)();
+}
+
+static eIcicleError hip_get_rou_from_domain(const Device& device, uint64_t logn, scalar_t* rou)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  return (eIcicleError)HIP_FN(get_root_of_unity_from_domain)(logn, (uint32_t*)rou);
+}
+
+REGISTER_NTT_INIT_DOMAIN_BACKEND("HIP", hip_ntt_init_domain);
+REGISTER_NTT_RELEASE_DOMAIN_BACKEND("HIP", hip_ntt_release_domain);
+REGISTER_NTT_GET_ROU_FROM_DOMAIN_BACKEND("HIP", hip_get_rou_from_domain);
+REGISTER_NTT_BACKEND("HIP", hip_ntt);
+REGISTER_NTT_EXT_FIELD_BACKEND("HIP", hip_ext_ntt);

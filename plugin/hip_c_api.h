@@ -1,0 +1,46 @@
+// Prototypes of the collision-free libicicle_hip.so entry points the plugin forwards to. This is the
+// subset of include/icicle_hip.h that can coexist with the reference headers in one translation unit
+// (the full header re-declares the icicle_* runtime names with C types).
+#pragma once
+#include <stdint.h>
+
+extern "C" {
+typedef struct {
+  void* stream;
+  int precompute_factor, c, bitsize, batch_size;
+  bool are_points_shared_in_batch, are_scalars_on_device, are_scalars_montgomery_form, are_points_on_device,
+    are_points_montgomery_form, are_results_on_device, is_async;
+  void* ext;
+} hip_msm_config_t; // == icicle_msm_config_t == icicle::MSMConfig (40 bytes)
+
+typedef struct {
+  void* stream;
+  uint32_t coset_gen;
+  int batch_size;
+  bool columns_batch;
+  int ordering;
+  bool are_inputs_on_device, are_outputs_on_device, is_async;
+  void* ext;
+} hip_ntt_config_u32_t; // == icicle_ntt_config_u32_t == icicle::NTTConfig<4-byte S> (40 bytes)
+
+typedef struct {
+  void* stream;
+  bool is_async;
+  void* ext;
+} hip_ntt_init_domain_config_t;
+
+int icicle_hip_set_device(int device_id);
+#define HIP_DECLARE_CURVE(C)                                                                                           \
+  int icicle_hip_##C##_msm(const void*, const void*, int, const hip_msm_config_t*, void*);                              \
+  int icicle_hip_##C##_msm_precompute_bases(const void*, int, const hip_msm_config_t*, void*);
+HIP_DECLARE_CURVE(bn254)
+HIP_DECLARE_CURVE(bls12_381)
+#define HIP_DECLARE_FIELD(F)                                                                                           \
+  int icicle_hip_##F##_ntt(const uint32_t*, int, int, const hip_ntt_config_u32_t*, uint32_t*);                         \
+  int icicle_hip_##F##_extension_ntt(const uint32_t*, int, int, const hip_ntt_config_u32_t*, uint32_t*);               \
+  int icicle_hip_##F##_ntt_init_domain(const uint32_t*, const hip_ntt_init_domain_config_t*);                          \
+  int icicle_hip_##F##_ntt_release_domain(void);                                                                       \
+  int icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t, uint32_t*);
+HIP_DECLARE_FIELD(babybear)
+HIP_DECLARE_FIELD(koalabear)
+}

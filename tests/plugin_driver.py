@@ -1,0 +1,105 @@
+"""Runs in its OWN process (spawned by tests/test_gpu_plugin.py): drives the HIP backend the way a user
+of the reference does -- reference runtime + reference frontend libraries, backend found by
+icicle_load_backend(), device selected by icicle_set_device({"HIP",0}) -- and checks it against the
+reference's "CPU" device in the same process (the reference's own differential pattern,
+icicle/tests/test_base.h:22-63, test_curve_api.cpp:36-79, test_mod_arithmetic_api.h:614-695,
+test_device_api.cpp:17-259). Prints 'PLUGIN OK' on success."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyref, ref  # noqa: E402
+from tests.util import cached_points, points_to_array, rand_scalars, to_words  # noqa: E402
+
+
+def main():
+    rt = ref.RefRuntime()
+    curve = ref.RefCurve("bn254")
+    bls = ref.RefCurve("bls12_381")
+    field = ref.RefNttField("babybear")
+    koala = ref.RefNttField("koalabear")
+    assert "HIP" not in rt.registered_devices()
+    assert rt.load_backend(os.path.join(ref.REF_DIR, "backend", "hip")) == 0
+    devs = rt.registered_devices()
+    assert "HIP" in devs and "CPU" in devs, devs
+
+    # ---- device API behaviour (test_device_api.cpp) ----
+    assert rt.set_device("HIP", 10) == 1          # INVALID_DEVICE, thread keeps its device (:183-189)
+    assert rt.set_device("HIP", 0) == 0
+    assert rt.get_device_count() >= 1
+    rc, _ = rt.malloc((1 << 64) - 1)
+    assert rc != 0                                # :157-165
+    rc, d = rt.malloc(1 << 20)
+    assert rc == 0
+    assert rt.lib.icicle_is_active_device_memory(d) == 0 and rt.lib.icicle_is_host_memory(d) != 0
+    a = np.arange(4096, dtype=np.uint32)
+    b = np.zeros_like(a)
+    assert rt.to_device(d + 1024, a) == 0         # interior pointers (:76-96)
+    rc2, d2 = rt.malloc(1 << 20)
+    assert rt.copy(d2, d + 1024, a.nbytes) == 0   # D2D, direction inferred from the tracker (:53-74)
+    assert rt.copy(b.ctypes.data, d2, a.nbytes) == 0
+    assert np.array_equal(a, b)
+    assert rt.lib.icicle_memset(d2, 0, a.nbytes) == 0
+    rt.to_host(b, d2)
+    assert not b.any()
+    assert rt.free(d) == 0 and rt.free(d2) == 0
+
+    # ---- MSM: HIP vs CPU through the reference frontend ----
+    rng = np.random.default_rng(42)
+    for cobj, C in ((curve, pyref.BN254), (bls, pyref.BLS12_381)):
+        n = 3000
+        pts = list(cached_points(C, n))
+        pts[7] = pyref.INF
+        bases = points_to_array(C, pts)
+        sc = to_words(rand_scalars(rng, n * 2, C.r), 8)
+        assert rt.set_device("HIP", 0) == 0
+        got = cobj.msm(sc, bases, batch=2)
+        pre = cobj.precompute_bases(bases, 4)
+        got_pre = cobj.msm(sc, pre, batch=2, precompute_factor=4)
+        assert rt.set_device("CPU", 0) == 0
+        exp = cobj.msm(sc, bases, batch=2)
+        assert np.array_equal(cobj.to_affine(got), cobj.to_affine(exp))
+        assert np.array_equal(cobj.to_affine(got_pre), cobj.to_affine(exp))
+        for bidx in range(2):
+            assert cobj.projective_eq(got[bidx], exp[bidx]) and cobj.is_on_curve(got[bidx])
+
+    # ---- NTT: HIP (device buffers from the reference's icicle_malloc) vs CPU ----
+    for fobj, F in ((field, pyref.BABYBEAR), (koala, pyref.KOALABEAR)):
+        logn, batch = 14, 3
+        n = 1 << logn
+        root = fobj.get_root_of_unity(1 << (logn + 2))
+        x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+        assert rt.set_device("CPU", 0) == 0
+        fobj.init_domain(root)
+        exp_f = fobj.ntt(x, n, 0, batch=batch)
+        exp_i = fobj.ntt(x, n, 1, batch=batch, ordering=2, coset_gen=5)
+        exp_e = fobj.ntt(x[: 4 * 256], 256, 0, extension=True)
+        assert rt.set_device("HIP", 0) == 0
+        fobj.init_domain(root)
+        assert fobj.get_root_of_unity_from_domain(logn) == pyref.omega(F, logn)
+        assert np.array_equal(fobj.ntt(x, n, 0, batch=batch), exp_f)
+        assert np.array_equal(fobj.ntt(x, n, 1, batch=batch, ordering=2, coset_gen=5), exp_i)
+        assert np.array_equal(fobj.ntt(x[: 4 * 256], 256, 0, extension=True), exp_e)
+        rc, d_in = rt.malloc(x.nbytes)
+        rc, d_out = rt.malloc(x.nbytes)
+        rt.to_device(d_in, x)
+        assert fobj.ntt_device(d_in, d_out, n, 0, batch=batch) == 0
+        y = np.zeros_like(x)
+        rt.to_host(y, d_out)
+        assert np.array_equal(y, exp_f)
+        assert fobj.ntt_device(d_out, d_out, n, 1, batch=batch) == 0  # in place on device
+        rt.to_host(y, d_out)
+        assert np.array_equal(y, x)
+        rt.free(d_in)
+        rt.free(d_out)
+        fobj.release_domain()
+        assert rt.set_device("CPU", 0) == 0
+        fobj.release_domain()
+    print("PLUGIN OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,11 @@ def declared_symbols():
     for f in re.findall(r"ICICLE_HIP_DECLARE_NTT_U32\((\w+)\)", text):
         if f != "F":
             names |= {f"{f}_{m}" for m in macro}
+    amacro = re.findall(r"icicle_error_t icicle_hip_##F##_(\w+)\(", text)
+    for f in re.findall(r"ICICLE_HIP_DECLARE_NTT_ALIASES\((\w+)\)", text):
+        if f != "F":
+            names |= {f"icicle_hip_{f}_{m}" for m in amacro}
+    names = {n for n in names if "##" not in n and n != "icicle_hip_"}
     return sorted(n for n in names if not n.startswith("F##"))
 
 
