@@ -77,6 +77,10 @@ namespace icicle_hip {
     uint32_t log_max;
     uint32_t ninv_mont;  // N^-1 (Montgomery) for inverse
     int coset;           // multiply by powers table (forward: on first load; inverse: on last store)
+    // row-group execution (fast path): this launch covers rows [row0, row0 + nrows_launch); a buffer
+    // flagged "relative" holds only the current group (its row r lives at offset of row r - row0)
+    uint32_t row0 = 0, nrows_launch = 0;
+    int src_rel = 0, dst_rel = 0;
   };
 
   __device__ __forceinline__ uint64_t bitrev64(uint64_t x, uint32_t bits)
@@ -283,12 +287,14 @@ namespace icicle_hip {
     // row pass   : load  (k, t) at in_base + k*1  + t*st ; store K0(t) + k_out*out_sk
     const uint64_t K0 = (pd.pidx <= 1) ? ((uint64_t)ct * T + tB) : (((uint64_t)ct * T + tB) + (uint64_t)pd.n0 * a);
 
-    const uint32_t row0 = blockIdx.y * rows_per_block;
-    for (uint32_t rr = 0; rr < rows_per_block && row0 + rr < nl.nbatch; rr++) {
-      const uint32_t bprime = row0 + rr;
-      const uint64_t boff = (uint64_t)(bprime / nl.lanes) * nl.bs + (bprime % nl.lanes);
-      const uint32_t* __restrict__ pin = in + boff;
-      uint32_t* __restrict__ pout = out + boff;
+    const uint32_t rloc0 = blockIdx.y * rows_per_block;
+    for (uint32_t rr = 0; rr < rows_per_block && rloc0 + rr < nl.nrows_launch; rr++) {
+      const uint32_t rloc = rloc0 + rr;         // row inside this launch's group
+      const uint32_t bprime = nl.row0 + rloc;   // absolute row
+      const uint64_t boff_abs = (uint64_t)(bprime / nl.lanes) * nl.bs + (bprime % nl.lanes);
+      const uint64_t boff_rel = (uint64_t)(rloc / nl.lanes) * nl.bs + (rloc % nl.lanes);
+      const uint32_t* __restrict__ pin = in + (nl.src_rel ? boff_rel : boff_abs);
+      uint32_t* __restrict__ pout = out + (nl.dst_rel ? boff_rel : boff_abs);
       uint32_t* tile = lds + (size_t)(rr & 1) * L * TP;
 
       if (!DIF) {
@@ -643,16 +649,36 @@ namespace icicle_hip {
     // never be in place; this also makes input == output legal, test_mod_arithmetic_api.h:627,679)
     TempBuf d_work;
     uint32_t* W = nullptr;
-    if (P >= 2) {
-      HIP_TRY(d_work.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
-      W = d_work.as<uint32_t>();
-    }
 
     const bool fast = !nl.in_rev && !nl.out_rev && !nl.coset;
+    // Row groups (experimental, OFF by default: ICICLE_HIP_NTT_GROUP_MB=<MiB>): a group of rows runs
+    // through ALL passes before the next group starts so that pass p+1 could read pass p's output from
+    // the 256 MiB Infinity Cache. Measured on MI355X (profiles/r01_notes.md): 3.4x SLOWER at 64-192 MiB
+    // groups, because a block then serves 1-2 rows and the per-block twiddle gathers (46 per thread)
+    // are no longer amortised over the batch. Kept for experiments only.
+    uint32_t rows_per_group = nl.nbatch;
+    if (fast && P >= 2 && !cfg->columns_batch && lanes == 1) {
+      size_t group_mb = 0;
+      if (const char* e = getenv("ICICLE_HIP_NTT_GROUP_MB")) group_mb = (size_t)atoi(e);
+      if (group_mb > 0) {
+        const size_t row_bytes = (size_t)n * 4;
+        rows_per_group = (uint32_t)std::max<size_t>(1, std::min<size_t>(nl.nbatch, (group_mb << 20) / row_bytes));
+      }
+    }
+    const bool grouped = rows_per_group < nl.nbatch;
+    if (P >= 2) {
+      HIP_TRY(d_work.alloc(grouped ? (size_t)rows_per_group * n * 4 : bytes, st), ICICLE_ALLOCATION_FAILED);
+      W = d_work.as<uint32_t>();
+    }
     KernelTimer::begin(1, st);
+    for (uint32_t g0 = 0; g0 < nl.nbatch; g0 += rows_per_group) {
+    nl.row0 = g0;
+    nl.nrows_launch = std::min<uint32_t>(rows_per_group, nl.nbatch - g0);
     for (int p = 0; p < P; p++) {
       const uint32_t* src = (p == 0) ? d_in : W;
       uint32_t* dst = (p == P - 1) ? d_out : W;
+      nl.src_rel = (grouped && p != 0) ? 1 : 0;
+      nl.dst_rel = (grouped && p != P - 1) ? 1 : 0;
       PassDesc pd{};
       pd.s = parts[p];
       pd.pidx = p;
@@ -702,9 +728,9 @@ namespace icicle_hip {
         const unsigned threads = (unsigned)(pd.T * (L / epb));
         const size_t lds_bytes = (size_t)2 * L * (pd.T + 1) * 4;
         // rows of the batch handled by one block (twiddles are loaded once per block): aim for >= 4096 blocks
-        const uint64_t total_blocks = (uint64_t)pd.ntiles * nl.nbatch;
-        const uint32_t rpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nl.nbatch, total_blocks / 4096));
-        const uint32_t gy = (nl.nbatch + rpb - 1) / rpb;
+        const uint64_t total_blocks = (uint64_t)pd.ntiles * nl.nrows_launch;
+        const uint32_t rpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nl.nrows_launch, total_blocks / 4096));
+        const uint32_t gy = (nl.nrows_launch + rpb - 1) / rpb;
         pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0);
         if (!fn) return ICICLE_INVALID_ARGUMENT;
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
@@ -716,6 +742,7 @@ namespace icicle_hip {
         k_ntt_pass_generic<PR><<<dim3(pd.ntiles, nl.nbatch), threads, (size_t)tot * 4, st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, nl);
       }
       LAUNCH_CHECK("k_ntt_pass", st);
+    }
     }
     KernelTimer::end(1, st);
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
