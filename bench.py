@@ -131,6 +131,18 @@ def main():
         "traffic": None, "avg_launch_ms": acc_ms, "launches": cnt.value,
         "note": "MSM is integer-ALU bound (v_mad_u64_u32), not HBM bound; see DESIGN.md and 'alu'",
     }
+    # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (bench.py cannot
+    # run rocprofv3 on itself); only attached when the workload matches the profiled one
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+    except Exception:
+        pmc = {}
+    if args.size_log2 == 26 and args.msm_c == 0 and "msm_bn254_2^26" in pmc:
+        m = pmc["msm_bn254_2^26"]
+        roofline["traffic"] = (m["fetch_size_kb_raw"] * m["fetch_correction"] + m["write_size_kb"]) * 1024 / 1e9
+        roofline["traffic_unit"] = "GB per launch (FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)"
     # secondary: integer-ALU view. mixed adds per MSM = n * windows(c=16 -> 16); 10 field muls each
     nwin = 16
     madds = n * nwin
@@ -194,6 +206,10 @@ def main():
                          "frac": ntt_bytes / (ntt_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": ntt_call_ms, "launches": cnt.value},
         }
+        if logn == 24 and rows == 64 and "ntt_babybear_2^24x64_one_direction" in pmc:
+            m = pmc["ntt_babybear_2^24x64_one_direction"]
+            out["ntt"]["roofline"]["traffic"] = m["passes"] * (m["fetch_size_kb_raw_per_pass"] * m["fetch_correction"] + m["write_size_kb_per_pass"]) * 1024 / 1e9
+            out["ntt"]["roofline"]["traffic_unit"] = "GB per direction (3 pass launches; FETCH_SIZE corrected x1.12, profiles/r01_pmc_traffic.json)"
         N.release_domain("babybear")
 
     # ---------------- CPU baseline: the reference CPU backend on this box's host cores ----------------

@@ -158,11 +158,13 @@ namespace icicle_hip {
 
   // pass A. COUNT: fill cntA[(wp*2^hb + h)*nblk + b]. !COUNT: scatter using the scanned offsets.
   template <class C, bool COUNT>
-  __global__ __launch_bounds__(1024) void k_part_a(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ cntA, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int c, int nwin, int wpf, int pf, SortPlan sp, size_t cap, bool scalars_refmont)
+  __global__ __launch_bounds__(1024) void k_part_a(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ cntA, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int c, int nwin, int wpf, int w0, int nw, int pf, SortPlan sp, size_t cap, bool scalars_refmont)
   {
+    // handles the target windows [w0, w0+nw) of the wpf; cntA/offA/outA are the GROUP's tables
+    // (group-local window index wl = wp - w0)
     extern __shared__ uint32_t lds[];
     const int b = blockIdx.x;
-    const uint32_t nparts = (uint32_t)wpf << sp.hb;
+    const uint32_t nparts = (uint32_t)nw << sp.hb;
     for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x)
       lds[k] = COUNT ? 0u : offA[(size_t)k * sp.nblk + b];
     __syncthreads();
@@ -175,15 +177,16 @@ namespace icicle_hip {
       for (int wi = 0; wi < nwin; wi++) {
         const uint32_t d = it.next(wi, c);
         const uint32_t key = d & 0x7fffffffu;
-        if (key) {
+        const int wl = wp - w0;
+        if (key && wl >= 0 && wl < nw) {
           const uint32_t km = key - 1;
-          const uint32_t part = ((uint32_t)wp << sp.hb) + (km >> sp.lb);
+          const uint32_t part = ((uint32_t)wl << sp.hb) + (km >> sp.lb);
           if (COUNT) {
             atomicAdd(&lds[part], 1u);
           } else {
             const uint32_t pos = atomicAdd(&lds[part], 1u);
             const uint32_t el = (d & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo);
-            outA[(size_t)wp * cap + pos] = el;
+            outA[(size_t)wl * cap + pos] = el;
           }
         }
         if (++wp == wpf) {
@@ -196,44 +199,6 @@ namespace icicle_hip {
       __syncthreads();
       for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x)
         cntA[(size_t)k * sp.nblk + b] = lds[k];
-    }
-  }
-
-  // pass A scatter, one block per (target window, scalar chunk): a block keeps only 2^hb write streams
-  // open (the all-windows variant above would keep wpf * 2^hb, far more than L2 can assemble into
-  // full lines). blockIdx.x = window varies fastest, so the wpf blocks that re-read one scalar chunk
-  // are dispatched together and the chunk is served from the Infinity Cache after its first read.
-  template <class C>
-  __global__ __launch_bounds__(1024) void k_part_a_scatter(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int c, int nwin, int wpf, int pf, SortPlan sp, size_t cap, bool scalars_refmont)
-  {
-    extern __shared__ uint32_t lds[];
-    const int wp = blockIdx.x, b = blockIdx.y;
-    const uint32_t nparts_w = 1u << sp.hb;
-    for (uint32_t k = threadIdx.x; k < nparts_w; k += blockDim.x)
-      lds[k] = offA[((size_t)wp * nparts_w + k) * sp.nblk + b];
-    __syncthreads();
-    const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
-    const uint32_t lmask = (1u << sp.lb) - 1;
-    uint32_t* dst = outA + (size_t)wp * cap;
-    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      DigitIter it;
-      load_scalar<C>(it, scalars, (size_t)i, scalars_refmont);
-      int wcur = 0, j = 0;
-      for (int wi = 0; wi < nwin; wi++) {
-        const uint32_t d = it.next(wi, c);
-        if (wcur == wp) {
-          const uint32_t key = d & 0x7fffffffu;
-          if (key) {
-            const uint32_t km = key - 1;
-            const uint32_t pos = atomicAdd(&lds[km >> sp.lb], 1u);
-            dst[pos] = (d & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo);
-          }
-        }
-        if (++wcur == wpf) {
-          wcur = 0;
-          j++;
-        }
-      }
     }
   }
 
@@ -800,12 +765,11 @@ namespace icicle_hip {
     SortPlan sp;
     {
       const int kb = pl.c - 1;
-      // pass A keeps wpf * 2^hb write streams open per block: few enough for L2 / Infinity Cache to
-      // assemble full lines, while pass B's 2^lb bins must fit LDS
+      // pass B's 2^lb bins must fit LDS; pass A keeps (windows in a group) * 2^hb counters in LDS
       int hb_cap = 10;
       if (const char* e = getenv("ICICLE_HIP_MSM_HB")) hb_cap = atoi(e);
       int hb = std::min(kb, hb_cap);
-      while (hb > 0 && ((size_t)wpf << hb) * 4 > 64 * 1024) // pass-A count keeps wpf * 2^hb counters in LDS
+      while (hb > 0 && ((size_t)wpf << hb) * 4 > 64 * 1024)
         hb--;
       if (kb - hb > 13) return ICICLE_INVALID_ARGUMENT;
       sp.hb = hb;
@@ -821,84 +785,141 @@ namespace icicle_hip {
       sp.chunk_log = std::max(10, std::min(std::min(17, max_chunk), logn - 9));
       sp.nblk = (int)(((size_t)n + ((size_t)1 << sp.chunk_log) - 1) >> sp.chunk_log);
     }
-    const size_t nparts = (size_t)wpf << sp.hb;
-    const size_t tabA = nparts * sp.nblk + wpf; // [wp][h][b] counters + per-window totals
+    const size_t nparts_w = (size_t)1 << sp.hb;
+    // Window groups: the sort of group g+1 (LDS-atomic / memory bound, on a second stream) overlaps the
+    // bucket accumulation of group g (VALU-issue bound, on the caller's stream).
+    // Measured (profiles/r01_notes.md): with pass A re-reading the scalars once per group the extra
+    // sort work outweighs the overlap (105 / 110 / 127 ms for 1 / 2 / 4 groups at 2^26), so the default
+    // is ONE group (no second stream); ICICLE_HIP_MSM_GROUPS=<g> keeps the experiment reproducible.
+    int G = 1;
+    if (const char* e = getenv("ICICLE_HIP_MSM_GROUPS")) G = std::max(1, std::min(wpf, atoi(e)));
+    struct Group {
+      int w0, nw;
+      size_t tabA, nparts;
+      uint32_t maxblkB, ovf_cap;
+    };
+    std::vector<Group> groups(G);
+    for (int g = 0; g < G; g++) {
+      Group& gr = groups[g];
+      gr.w0 = (int)((size_t)wpf * g / G);
+      gr.nw = (int)((size_t)wpf * (g + 1) / G) - gr.w0;
+      gr.nparts = (size_t)gr.nw << sp.hb;
+      gr.tabA = gr.nparts * sp.nblk + gr.nw;
+      const size_t elems = (size_t)n * pl.nwin * gr.nw / wpf + 1;
+      gr.maxblkB = (uint32_t)(gr.nparts + (elems >> CHUNKB_LOG) + 2);
+      gr.ovf_cap = (uint32_t)std::min<size_t>(elems / pl.seg + 16, 0x7fffffffu);
+    }
     const uint32_t m = std::min<uint32_t>(nb, 32);
     const uint32_t nseg = nb / m;
-    const size_t ovf_cap_sz = ((size_t)n * pl.nwin) / pl.seg + 16;
-    const uint32_t ovf_cap = (uint32_t)std::min<size_t>(ovf_cap_sz, 0x7fffffffu);
-    const uint32_t maxblkB = (uint32_t)(nparts + (((size_t)n * pl.nwin) >> CHUNKB_LOG) + 2);
-    TempBuf d_mont, d_partA, d_sorted, d_cntA, d_offA, d_count, d_offs, d_cursor, d_bstart, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt;
-    HIP_TRY(d_cursor.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_bstart.alloc((nparts + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
+    TempBuf d_mont, d_partA, d_sorted, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win;
+    std::vector<TempBuf> d_cntA(G), d_offA(G), d_bstart(G), d_ovf(G), d_ovfpart(G), d_ovfcnt(G);
     HIP_TRY(d_mont.alloc(npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_partA.alloc((size_t)wpf * cap * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_sorted.alloc((size_t)wpf * cap * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_cntA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_offA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_count.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_offs.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_cursor.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_buckets.alloc(nbk * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_seg.alloc((size_t)wpf * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_win.alloc((size_t)wpf * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_ovfcnt.alloc(16, st), ICICLE_ALLOCATION_FAILED);
+    for (int g = 0; g < G; g++) {
+      HIP_TRY(d_cntA[g].alloc(groups[g].tabA * 4, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(d_offA[g].alloc(groups[g].tabA * 4, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(d_bstart[g].alloc((groups[g].nparts + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(d_ovf[g].alloc((size_t)groups[g].ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(d_ovfpart[g].alloc((size_t)groups[g].ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(d_ovfcnt[g].alloc(16, st), ICICLE_ALLOCATION_FAILED);
+    }
 
-    const size_t ldsA = nparts * 4;
     const size_t ldsB = (2 * ((size_t)1 << sp.lb) + sp.nblk + 1) * 4;
-    if (ldsB > 150 * 1024 || nparts > 16384) return ICICLE_INVALID_ARGUMENT;
+    if (ldsB > 150 * 1024) return ICICLE_INVALID_ARGUMENT;
+    for (int g = 0; g < G; g++)
+      if (groups[g].nparts > 16384 || groups[g].nparts * 4 > 64 * 1024) return ICICLE_INVALID_ARGUMENT;
     HIP_TRY(hipFuncSetAttribute((const void*)k_part_a<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_part_a<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_b_count, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_b_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
 
+    // second stream for the sort stages + events (leased per call, cached per device)
+    AuxStream aux;
+    hipStream_t ss = st;
+    if (G > 1) {
+      HIP_TRY(aux.acquire(G), ICICLE_STREAM_CREATION_FAILED);
+      ss = aux.stream();
+    }
+
     for (int b = 0; b < batch; b++) {
+      const uint32_t* sc = d_scalars + (size_t)b * n * FR::N32;
+      const bool smont = cfg->are_scalars_montgomery_form;
+      if (G > 1) { // the sort stream starts after everything already queued on the caller's stream
+        HIP_TRY(hipEventRecord(aux.ev_start(), st), ICICLE_SYNCHRONIZATION_FAILED);
+        HIP_TRY(hipStreamWaitEvent(ss, aux.ev_start(), 0), ICICLE_SYNCHRONIZATION_FAILED);
+      }
+      // ---- sort stages, all groups back to back on the sort stream
+      for (int g = 0; g < G; g++) {
+        const Group& gr = groups[g];
+        uint32_t* cntA = d_cntA[g].as<uint32_t>();
+        uint32_t* offA = d_offA[g].as<uint32_t>();
+        uint32_t* partA = d_partA.as<uint32_t>() + (size_t)gr.w0 * cap;
+        uint32_t* sorted = d_sorted.as<uint32_t>() + (size_t)gr.w0 * cap;
+        uint32_t* count = d_count.as<uint32_t>() + (size_t)gr.w0 * nb;
+        uint32_t* offs = d_offs.as<uint32_t>() + (size_t)gr.w0 * nb;
+        uint32_t* cursor = d_cursor.as<uint32_t>() + (size_t)gr.w0 * nb;
+        const size_t ldsA = gr.nparts * 4;
+        k_part_a<C, true><<<sp.nblk, 1024, ldsA, ss>>>(sc, cntA, nullptr, nullptr, n, pl.c, pl.nwin, wpf, gr.w0, gr.nw, pf, sp, cap, smont);
+        LAUNCH_CHECK("k_part_a<count>", ss);
+        k_scan_a<<<gr.nw, 1024, 0, ss>>>(cntA, offA, (uint32_t)(nparts_w * sp.nblk));
+        LAUNCH_CHECK("k_scan_a", ss);
+        k_part_a<C, false><<<sp.nblk, 1024, ldsA, ss>>>(sc, nullptr, offA, partA, n, pl.c, pl.nwin, wpf, gr.w0, gr.nw, pf, sp, cap, smont);
+        LAUNCH_CHECK("k_part_a<scatter>", ss);
+        k_b_plan<<<1, 1024, 0, ss>>>(offA, d_bstart[g].as<uint32_t>(), (uint32_t)gr.nparts, gr.nw, sp.hb, sp.nblk);
+        LAUNCH_CHECK("k_b_plan", ss);
+        HIP_TRY(hipMemsetAsync(count, 0, (size_t)gr.nw * nb * 4, ss), ICICLE_COPY_FAILED);
+        k_b_count<<<gr.maxblkB, 1024, ((size_t)1 << sp.lb) * 4, ss>>>(partA, offA, d_bstart[g].as<uint32_t>(), count, (uint32_t)gr.nparts, gr.nw, sp, cap, nb);
+        LAUNCH_CHECK("k_b_count", ss);
+        k_scan_buckets<<<gr.nw, 1024, 0, ss>>>(count, offs, cursor, nb);
+        LAUNCH_CHECK("k_scan_buckets", ss);
+        k_b_scatter<<<gr.maxblkB, 1024, ldsB, ss>>>(partA, offA, d_bstart[g].as<uint32_t>(), cursor, sorted, (uint32_t)gr.nparts, gr.nw, pf, sp, cap, nb);
+        LAUNCH_CHECK("k_b_scatter", ss);
+        HIP_TRY(hipMemsetAsync(d_ovfcnt[g].ptr(), 0, 16, ss), ICICLE_COPY_FAILED);
+        k_plan_overflow<<<(unsigned)(((size_t)gr.nw * nb + 255) / 256), 256, 0, ss>>>(count, (size_t)gr.nw * nb, pl.seg, d_ovfcnt[g].as<uint32_t>(), d_ovf[g].as<OvfSeg>(), gr.ovf_cap);
+        LAUNCH_CHECK("k_plan_overflow", ss);
+        if (G > 1) HIP_TRY(hipEventRecord(aux.ev_sorted(g), ss), ICICLE_SYNCHRONIZATION_FAILED);
+      }
+      // ---- compute stages on the caller's stream
       if (b == 0 || !shared) {
         const uint32_t* src = d_bases + (shared ? 0 : (size_t)b * npts_one * PW);
         const size_t ncoord = npts_one * 2;
         k_bases_to_mont<C><<<dim3((unsigned)((ncoord + 255) / 256)), 256, 0, st>>>(src, d_mont.as<uint32_t>(), ncoord, cfg->are_points_montgomery_form);
         LAUNCH_CHECK("k_bases_to_mont", st);
       }
-      const uint32_t* sc = d_scalars + (size_t)b * n * FR::N32;
-      const bool smont = cfg->are_scalars_montgomery_form;
-      k_part_a<C, true><<<sp.nblk, 1024, ldsA, st>>>(sc, d_cntA.as<uint32_t>(), nullptr, nullptr, n, pl.c, pl.nwin, wpf, pf, sp, cap, smont);
-      LAUNCH_CHECK("k_part_a<count>", st);
-      k_scan_a<<<wpf, 1024, 0, st>>>(d_cntA.as<uint32_t>(), d_offA.as<uint32_t>(), (uint32_t)(((size_t)1 << sp.hb) * sp.nblk));
-      LAUNCH_CHECK("k_scan_a", st);
-      static const bool per_window_scatter = (getenv("ICICLE_HIP_MSM_AWIN") != nullptr);
-      if (per_window_scatter) {
-        k_part_a_scatter<C><<<dim3(wpf, sp.nblk), 1024, ((size_t)1 << sp.hb) * 4, st>>>(sc, d_offA.as<uint32_t>(), d_partA.as<uint32_t>(), n, pl.c, pl.nwin, wpf, pf, sp, cap, smont);
-      } else {
-        k_part_a<C, false><<<sp.nblk, 1024, ldsA, st>>>(sc, nullptr, d_offA.as<uint32_t>(), d_partA.as<uint32_t>(), n, pl.c, pl.nwin, wpf, pf, sp, cap, smont);
+      for (int g = 0; g < G; g++) {
+        const Group& gr = groups[g];
+        const size_t gbk = (size_t)gr.nw * nb;
+        uint32_t* sorted = d_sorted.as<uint32_t>() + (size_t)gr.w0 * cap;
+        uint32_t* count = d_count.as<uint32_t>() + (size_t)gr.w0 * nb;
+        uint32_t* offs = d_offs.as<uint32_t>() + (size_t)gr.w0 * nb;
+        typename E::Proj* buckets = d_buckets.as<typename E::Proj>() + (size_t)gr.w0 * nb;
+        if (G > 1) HIP_TRY(hipStreamWaitEvent(st, aux.ev_sorted(g), 0), ICICLE_SYNCHRONIZATION_FAILED);
+        KernelTimer::begin(0, st);
+        const size_t nthreads_acc = gbk + gr.ovf_cap;
+        k_accumulate<C><<<(unsigned)((nthreads_acc + 127) / 128), 128, 0, st>>>(d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart[g].as<typename E::Proj>(), d_ovf[g].as<OvfSeg>(), d_ovfcnt[g].as<uint32_t>(), nb, gbk, cap, pl.seg);
+        LAUNCH_CHECK("k_accumulate", st);
+        KernelTimer::end(0, st);
+        k_fold_overflow<C><<<(gr.ovf_cap + 63) / 64, 64, 0, st>>>(buckets, d_ovfpart[g].as<typename E::Proj>(), d_ovf[g].as<OvfSeg>(), d_ovfcnt[g].as<uint32_t>(), gr.ovf_cap);
+        LAUNCH_CHECK("k_fold_overflow", st);
+        const size_t nsg = (size_t)gr.nw * nseg;
+        typename E::Proj* seg = d_seg.as<typename E::Proj>() + (size_t)gr.w0 * nseg;
+        k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(buckets, seg, nb, m, gr.nw);
+        LAUNCH_CHECK("k_reduce_segments", st);
+        k_reduce_window<C><<<gr.nw, 256, 0, st>>>(seg, d_win.as<typename E::Proj>() + gr.w0, nseg);
+        LAUNCH_CHECK("k_reduce_window", st);
       }
-      LAUNCH_CHECK("k_part_a_scatter", st);
-      k_b_plan<<<1, 1024, 0, st>>>(d_offA.as<uint32_t>(), d_bstart.as<uint32_t>(), (uint32_t)nparts, wpf, sp.hb, sp.nblk);
-      LAUNCH_CHECK("k_b_plan", st);
-      HIP_TRY(hipMemsetAsync(d_count.ptr(), 0, nbk * 4, st), ICICLE_COPY_FAILED);
-      k_b_count<<<maxblkB, 1024, ((size_t)1 << sp.lb) * 4, st>>>(d_partA.as<uint32_t>(), d_offA.as<uint32_t>(), d_bstart.as<uint32_t>(), d_count.as<uint32_t>(), (uint32_t)nparts, wpf, sp, cap, nb);
-      LAUNCH_CHECK("k_b_count", st);
-      k_scan_buckets<<<wpf, 1024, 0, st>>>(d_count.as<uint32_t>(), d_offs.as<uint32_t>(), d_cursor.as<uint32_t>(), nb);
-      LAUNCH_CHECK("k_scan_buckets", st);
-      k_b_scatter<<<maxblkB, 1024, ldsB, st>>>(d_partA.as<uint32_t>(), d_offA.as<uint32_t>(), d_bstart.as<uint32_t>(), d_cursor.as<uint32_t>(), d_sorted.as<uint32_t>(), (uint32_t)nparts, wpf, pf, sp, cap, nb);
-      LAUNCH_CHECK("k_b_scatter", st);
-      HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16, st), ICICLE_COPY_FAILED);
-      k_plan_overflow<<<(unsigned)((nbk + 255) / 256), 256, 0, st>>>(d_count.as<uint32_t>(), nbk, pl.seg, d_ovfcnt.as<uint32_t>(), d_ovf.as<OvfSeg>(), ovf_cap);
-      LAUNCH_CHECK("k_plan_overflow", st);
-      KernelTimer::begin(0, st);
-      const size_t nthreads_acc = nbk + ovf_cap;
-      k_accumulate<C><<<(unsigned)((nthreads_acc + 127) / 128), 128, 0, st>>>(d_mont.as<uint32_t>(), d_sorted.as<uint32_t>(), d_count.as<uint32_t>(), d_offs.as<uint32_t>(), d_buckets.as<typename E::Proj>(), d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), nb, nbk, cap, pl.seg);
-      LAUNCH_CHECK("k_accumulate", st);
-      KernelTimer::end(0, st);
-      k_fold_overflow<C><<<(ovf_cap + 63) / 64, 64, 0, st>>>(d_buckets.as<typename E::Proj>(), d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
-      LAUNCH_CHECK("k_fold_overflow", st);
-      const size_t nsg = (size_t)wpf * nseg;
-      k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(d_buckets.as<typename E::Proj>(), d_seg.as<typename E::Proj>(), nb, m, wpf);
-      LAUNCH_CHECK("k_reduce_segments", st);
-      k_reduce_window<C><<<wpf, 256, 0, st>>>(d_seg.as<typename E::Proj>(), d_win.as<typename E::Proj>(), nseg);
-      LAUNCH_CHECK("k_reduce_window", st);
       k_final<C><<<1, 128, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b * RW, wpf, pl.c);
       LAUNCH_CHECK("k_final", st);
+      if (G > 1 && b + 1 < batch) { // the next batch element's sort must not overwrite lists still being read
+        HIP_TRY(hipEventRecord(aux.ev_start(), st), ICICLE_SYNCHRONIZATION_FAILED);
+      }
     }
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
 
