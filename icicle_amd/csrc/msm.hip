@@ -43,7 +43,7 @@ namespace icicle_hip {
     if (c <= 0) {
       // minimise  (#mixed adds) + (bucket-reduction adds, weighted for their poor parallelism)
       double best = 1e300;
-      for (int cc = 2; cc <= 22; cc++) {
+      for (int cc = 2; cc <= 21; cc++) {
         const int w = (p.bits + 1 + cc - 1) / cc;
         const int wpf = (w + p.pf - 1) / p.pf;
         // per bucket: ~2 complete adds (14 muls each) in the reduction vs 10 muls per mixed add, plus
@@ -55,7 +55,7 @@ namespace icicle_hip {
         }
       }
     }
-    c = std::min(24, std::max(2, c)); // two-level sort: 2^hb partitions in LDS (pass A), 2^lb bins (pass B)
+    c = std::min(21, std::max(2, c)); // two-level sort: 2^hb partitions (pass A) x 2^lb bins (pass B), hb, lb <= 10
     p.c = c;
     p.nwin = (p.bits + 1 + c - 1) / c;
     p.wpf = (p.nwin + p.pf - 1) / p.pf;
@@ -156,49 +156,155 @@ namespace icicle_hip {
     it.carry = 0;
   }
 
-  // pass A. COUNT: fill cntA[(wp*2^hb + h)*nblk + b]. !COUNT: scatter using the scanned offsets.
-  template <class C, bool COUNT>
-  __global__ __launch_bounds__(1024) void k_part_a(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ cntA, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int c, int nwin, int wpf, int w0, int nw, int pf, SortPlan sp, size_t cap, bool scalars_refmont)
+  // digits of all windows, dig[wi*n + i] (coalesced 4-byte writes; read back window by window)
+  template <class C>
+  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, int c, int nwin, bool scalars_refmont)
   {
-    // handles the target windows [w0, w0+nw) of the wpf; cntA/offA/outA are the GROUP's tables
-    // (group-local window index wl = wp - w0)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DigitIter it;
+    load_scalar<C>(it, scalars, (size_t)i, scalars_refmont);
+    for (int wi = 0; wi < nwin; wi++)
+      dig[(size_t)wi * n + i] = it.next(wi, c);
+  }
+
+  // exclusive prefix of one value per thread over the block (blockDim.x a multiple of 64, <= 1024);
+  // wsum: >= 17 words of LDS scratch
+  __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wsum)
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+      const uint32_t t = lane < nwv ? wsum[lane] : 0;
+      uint32_t sft = t;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t y = __shfl_up(sft, d);
+        if (lane >= d) sft += y;
+      }
+      if (lane < nwv) wsum[lane] = sft - t;
+    }
+    __syncthreads();
+    const uint32_t r = x - v + wsum[wave];
+    __syncthreads();
+    return r;
+  }
+
+  // Tile sort in LDS: a block ranks TS = 16 * blockDim elements by destination, stages them sorted,
+  // and writes each destination's run contiguously -- HBM sees >= 64-byte runs instead of 4-byte
+  // scatters (the unstaged scatter wrote 30 GB to place 3.5 GB, profiles/r01_notes.md).
+  constexpr int SORT_EPT = 16;                 // elements per thread per tile
+  constexpr uint32_t SORT_TS = 1024 * SORT_EPT; // tile size with 1024 threads
+  struct TileLds {
+    uint32_t* cnt;   // [D] per-destination count of this tile -> reused as tile-local offset
+    uint32_t* gbase; // [D] global position of this tile's run per destination
+    uint32_t* stage; // [SORT_TS]
+    uint16_t* sdest; // [SORT_TS]
+    uint32_t* wsum;  // [32]
+  };
+  __device__ __forceinline__ TileLds tile_lds(uint32_t* lds, uint32_t D)
+  {
+    TileLds t;
+    t.cnt = lds;
+    t.gbase = lds + D;
+    t.stage = lds + 2 * D;
+    t.sdest = reinterpret_cast<uint16_t*>(lds + 2 * D + SORT_TS);
+    t.wsum = lds + 2 * D + SORT_TS + SORT_TS / 2;
+    return t;
+  }
+  __host__ __device__ static inline size_t tile_lds_bytes(uint32_t D) { return ((size_t)2 * D + SORT_TS + SORT_TS / 2 + 32) * 4; }
+
+  // pass A count: block (b, wl) histograms the high key bits of scalar chunk b for target window w0+wl
+  __global__ __launch_bounds__(1024) void k_a_count(const uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int nwin, int wpf, int w0, int pf, SortPlan sp)
+  {
     extern __shared__ uint32_t lds[];
-    const int b = blockIdx.x;
-    const uint32_t nparts = (uint32_t)nw << sp.hb;
-    for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x)
-      lds[k] = COUNT ? 0u : offA[(size_t)k * sp.nblk + b];
+    const int b = blockIdx.x, wl = blockIdx.y, wp = w0 + wl;
+    const uint32_t D = 1u << sp.hb;
+    for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
+      lds[k] = 0;
+    __syncthreads();
+    const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
+    for (int j = 0; j < pf; j++) {
+      const int wi = j * wpf + wp;
+      if (wi >= nwin) break;
+      const uint32_t* d = dig + (size_t)wi * n;
+      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t key = d[i] & 0x7fffffffu;
+        if (key) atomicAdd(&lds[(key - 1) >> sp.lb], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
+      cntA[(((size_t)wl << sp.hb) + k) * sp.nblk + b] = lds[k];
+  }
+
+  // pass A scatter: element = sign | low key bits | j | index within chunk, into partition runs
+  __global__ __launch_bounds__(1024) void k_a_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int nwin, int wpf, int w0, int pf, SortPlan sp, size_t cap)
+  {
+    extern __shared__ uint32_t lds[];
+    const int b = blockIdx.x, wl = blockIdx.y, wp = w0 + wl;
+    const uint32_t D = 1u << sp.hb;
+    TileLds t = tile_lds(lds, D);
+    uint32_t* cursor = lds + tile_lds_bytes(D) / 4; // [D] running write position per destination
+    for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
+      cursor[k] = offA[(((size_t)wl << sp.hb) + k) * sp.nblk + b];
     __syncthreads();
     const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
     const uint32_t lmask = (1u << sp.lb) - 1;
-    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      DigitIter it;
-      load_scalar<C>(it, scalars, (size_t)i, scalars_refmont);
-      int wp = 0, j = 0;
-      for (int wi = 0; wi < nwin; wi++) {
-        const uint32_t d = it.next(wi, c);
-        const uint32_t key = d & 0x7fffffffu;
-        const int wl = wp - w0;
-        if (key && wl >= 0 && wl < nw) {
-          const uint32_t km = key - 1;
-          const uint32_t part = ((uint32_t)wl << sp.hb) + (km >> sp.lb);
-          if (COUNT) {
-            atomicAdd(&lds[part], 1u);
-          } else {
-            const uint32_t pos = atomicAdd(&lds[part], 1u);
-            const uint32_t el = (d & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo);
-            outA[(size_t)wl * cap + pos] = el;
+    uint32_t* dst = outA + (size_t)wl * cap;
+    for (int j = 0; j < pf; j++) {
+      const int wi = j * wpf + wp;
+      if (wi >= nwin) break;
+      const uint32_t* d = dig + (size_t)wi * n;
+      for (int tile0 = lo; tile0 < hi; tile0 += SORT_TS) {
+        if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t el[SORT_EPT], dr[SORT_EPT]; // element, (dest << 16 | rank)
+#pragma unroll
+        for (int it = 0; it < SORT_EPT; it++) {
+          const int i = tile0 + it * 1024 + threadIdx.x;
+          dr[it] = 0xffffffffu;
+          if (i < hi) {
+            const uint32_t dv = d[i];
+            const uint32_t key = dv & 0x7fffffffu;
+            if (key) {
+              const uint32_t km = key - 1, h = km >> sp.lb;
+              el[it] = (dv & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo);
+              dr[it] = (h << 16) | atomicAdd(&t.cnt[h], 1u);
+            }
           }
         }
-        if (++wp == wpf) {
-          wp = 0;
-          j++;
+        __syncthreads();
+        const uint32_t mycnt = threadIdx.x < D ? t.cnt[threadIdx.x] : 0;
+        const uint32_t toff = block_exscan(mycnt, t.wsum);
+        if (threadIdx.x < D) {
+          t.cnt[threadIdx.x] = toff; // now the tile-local offset
+          t.gbase[threadIdx.x] = cursor[threadIdx.x];
+          cursor[threadIdx.x] += mycnt;
         }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SORT_EPT; it++)
+          if (dr[it] != 0xffffffffu) {
+            const uint32_t h = dr[it] >> 16, pos = t.cnt[h] + (dr[it] & 0xffffu);
+            t.stage[pos] = el[it];
+            t.sdest[pos] = (uint16_t)h;
+          }
+        __syncthreads();
+        const uint32_t ntile = t.cnt[D - 1] + (cursor[D - 1] - t.gbase[D - 1]);
+        for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += blockDim.x) {
+          const uint32_t h = t.sdest[sidx];
+          dst[t.gbase[h] + (sidx - t.cnt[h])] = t.stage[sidx];
+        }
+        __syncthreads();
       }
-    }
-    if (COUNT) {
-      __syncthreads();
-      for (uint32_t k = threadIdx.x; k < nparts; k += blockDim.x)
-        cntA[(size_t)k * sp.nblk + b] = lds[k];
     }
   }
 
@@ -343,61 +449,74 @@ namespace icicle_hip {
 
   __global__ __launch_bounds__(1024) void k_b_scatter(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted, uint32_t nparts, int wpf, int pf, SortPlan sp, size_t cap, uint32_t nb)
   {
-    extern __shared__ uint32_t lds[]; // [nbins] local count -> local cursor | [nbins] reserved base | [nblk+1] piece offsets
+    extern __shared__ uint32_t lds[]; // tile-sort arrays | [nblk+1] piece offsets of this partition
     uint32_t p, r0, r1;
     if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p, r0, r1)) return;
-    const uint32_t nbins = 1u << sp.lb;
-    uint32_t* lcnt = lds;
-    uint32_t* base = lds + nbins;
-    uint32_t* boffs = lds + 2 * nbins;
+    const uint32_t D = 1u << sp.lb;
+    TileLds t = tile_lds(lds, D);
+    uint32_t* boffs = lds + tile_lds_bytes(D) / 4;
     const uint32_t wp = p >> sp.hb, h = p & ((1u << sp.hb) - 1);
     const uint32_t nparts_w = 1u << sp.hb;
     const size_t row = (size_t)p * sp.nblk;
-    for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x)
-      lcnt[k] = 0;
     for (uint32_t k = threadIdx.x; k <= (uint32_t)sp.nblk; k += blockDim.x)
       boffs[k] = (k < (uint32_t)sp.nblk) ? offA[row + k] : ((h + 1 < nparts_w) ? offA[row + sp.nblk] : offA[(size_t)wpf * nparts_w * sp.nblk + wp]);
     __syncthreads();
     const uint32_t* src = inA + (size_t)wp * cap;
-    const int lshift = 31 - sp.lb;
-    const uint32_t lmask = nbins - 1;
-    for (uint32_t pos = r0 + threadIdx.x; pos < r1; pos += blockDim.x)
-      atomicAdd(&lcnt[(src[pos] >> lshift) & lmask], 1u);
-    __syncthreads();
-    uint32_t* cw = cursor + (size_t)wp * nb + ((size_t)h << sp.lb);
-    for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x) {
-      const uint32_t cnt = lcnt[k];
-      base[k] = cnt ? atomicAdd(&cw[k], cnt) : 0u;
-      lcnt[k] = 0;
-    }
-    __syncthreads();
-    // first source piece that reaches into [r0, r1): last b with boffs[b] <= r0
-    uint32_t blo = 0, bhi = sp.nblk;
-    while (bhi - blo > 1) {
-      const uint32_t mid = (blo + bhi) >> 1;
-      if (boffs[mid] <= r0) {
-        blo = mid;
-      } else {
-        bhi = mid;
-      }
-    }
     uint32_t* dst = sorted + (size_t)wp * cap;
+    uint32_t* cw = cursor + (size_t)wp * nb + ((size_t)h << sp.lb);
+    const int lshift = 31 - sp.lb;
+    const uint32_t lmask = D - 1;
     const uint32_t imask = (1u << (31 - sp.lb - sp.jb)) - 1;
     const uint32_t jmask = (1u << sp.jb) - 1;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    // one wave per source piece: its scalar-index base is wave-uniform, no per-element search
-    for (uint32_t bsrc = blo + wave; bsrc < (uint32_t)sp.nblk; bsrc += nwaves) {
-      const uint32_t q0 = max(boffs[bsrc], r0), q1 = min(boffs[bsrc + 1], r1);
-      if (boffs[bsrc] >= r1) break;
-      const uint32_t ibase = bsrc << sp.chunk_log;
-      for (uint32_t pos = q0 + lane; pos < q1; pos += 64) {
-        const uint32_t el = src[pos];
-        const uint32_t bin = (el >> lshift) & lmask;
-        const uint32_t i = ibase + (el & imask);
-        const uint32_t j = (el >> (31 - sp.lb - sp.jb)) & jmask;
-        const uint32_t at = base[bin] + atomicAdd(&lcnt[bin], 1u);
-        dst[at] = (i * (uint32_t)pf + j) | (el & 0x80000000u);
+    for (uint32_t tile0 = r0; tile0 < r1; tile0 += SORT_TS) {
+      if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
+      __syncthreads();
+      uint32_t el[SORT_EPT], dr[SORT_EPT];
+#pragma unroll
+      for (int it = 0; it < SORT_EPT; it++) {
+        const uint32_t pos = tile0 + it * 1024 + threadIdx.x;
+        dr[it] = 0xffffffffu;
+        if (pos < r1) {
+          const uint32_t e = src[pos];
+          // source block (scalar chunk) of this element: last bsrc with boffs[bsrc] <= pos
+          uint32_t blo = 0, bhi = sp.nblk;
+          while (bhi - blo > 1) {
+            const uint32_t mid = (blo + bhi) >> 1;
+            if (boffs[mid] <= pos) {
+              blo = mid;
+            } else {
+              bhi = mid;
+            }
+          }
+          const uint32_t i = (blo << sp.chunk_log) + (e & imask);
+          const uint32_t j = (e >> (31 - sp.lb - sp.jb)) & jmask;
+          const uint32_t bin = (e >> lshift) & lmask;
+          el[it] = (i * (uint32_t)pf + j) | (e & 0x80000000u);
+          dr[it] = (bin << 16) | atomicAdd(&t.cnt[bin], 1u);
+        }
       }
+      __syncthreads();
+      const uint32_t mycnt = threadIdx.x < D ? t.cnt[threadIdx.x] : 0;
+      const uint32_t toff = block_exscan(mycnt, t.wsum);
+      if (threadIdx.x < D) {
+        t.cnt[threadIdx.x] = toff;
+        t.gbase[threadIdx.x] = mycnt ? atomicAdd(&cw[threadIdx.x], mycnt) : 0u; // reserve the run in the bucket list
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < SORT_EPT; it++)
+        if (dr[it] != 0xffffffffu) {
+          const uint32_t bin = dr[it] >> 16, pos = t.cnt[bin] + (dr[it] & 0xffffu);
+          t.stage[pos] = el[it];
+          t.sdest[pos] = (uint16_t)bin;
+        }
+      __syncthreads();
+      const uint32_t ntile = min(r1 - tile0, SORT_TS);
+      for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += blockDim.x) {
+        const uint32_t bin = t.sdest[sidx];
+        dst[t.gbase[bin] + (sidx - t.cnt[bin])] = t.stage[sidx];
+      }
+      __syncthreads();
     }
   }
 
@@ -431,8 +550,8 @@ namespace icicle_hip {
     }
   }
 
-  template <class C>
-  __global__ __launch_bounds__(128) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t nb, size_t nbk, size_t cap, uint32_t seg)
+  template <class C, int MINW>
+  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t nb, size_t nbk, size_t cap, uint32_t seg)
   {
     using E = EC<C>;
     constexpr int PW = 2 * E::N32; // words per affine point
@@ -481,13 +600,14 @@ namespace icicle_hip {
   __global__ __launch_bounds__(64) void k_fold_overflow(typename EC<C>::Proj* __restrict__ buckets, const typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t ovf_cap)
   {
     using E = EC<C>;
-    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = min(*ovf_count, ovf_cap);
-    if (o >= n || !ovf[o].first) return;
-    typename E::Proj acc = buckets[ovf[o].bucket];
-    for (uint32_t k = 0; k < ovf[o].nextra && o + k < n; k++)
-      acc = E::add(acc, ovf_part[o + k]);
-    buckets[ovf[o].bucket] = acc;
+    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
+      if (!ovf[o].first) continue;
+      typename E::Proj acc = buckets[ovf[o].bucket];
+      for (uint32_t k = 0; k < ovf[o].nextra && o + k < n; k++)
+        acc = E::add(acc, ovf_part[o + k]);
+      buckets[ovf[o].bucket] = acc;
+    }
   }
 
   // ------------------------------------------------------------------------------------------
@@ -765,13 +885,11 @@ namespace icicle_hip {
     SortPlan sp;
     {
       const int kb = pl.c - 1;
-      // pass B's 2^lb bins must fit LDS; pass A keeps (windows in a group) * 2^hb counters in LDS
-      int hb_cap = 10;
-      if (const char* e = getenv("ICICLE_HIP_MSM_HB")) hb_cap = atoi(e);
-      int hb = std::min(kb, hb_cap);
-      while (hb > 0 && ((size_t)wpf << hb) * 4 > 64 * 1024)
-        hb--;
-      if (kb - hb > 13) return ICICLE_INVALID_ARGUMENT;
+      // each tile-sorted pass ranks into <= 1024 destinations (one per thread of the block)
+      int hb = (kb + 1) / 2;
+      if (const char* e = getenv("ICICLE_HIP_MSM_HB")) hb = atoi(e);
+      hb = std::max(kb - 10, std::min(std::min(kb, 10), hb));
+      if (hb < 0 || hb > 10 || kb - hb > 10) return ICICLE_INVALID_ARGUMENT;
       sp.hb = hb;
       sp.lb = kb - hb;
       sp.jb = 0;
@@ -782,7 +900,8 @@ namespace icicle_hip {
         logn++;
       const int max_chunk = 31 - sp.lb - sp.jb;
       if (max_chunk < 10) return ICICLE_INVALID_ARGUMENT;
-      sp.chunk_log = std::max(10, std::min(std::min(17, max_chunk), logn - 9));
+      sp.chunk_log = std::max(10, std::min(max_chunk, std::max(17, logn - 9)));
+      if (sp.chunk_log < logn - 9) return ICICLE_INVALID_ARGUMENT; // would need more than 512 pass-A blocks per window
       sp.nblk = (int)(((size_t)n + ((size_t)1 << sp.chunk_log) - 1) >> sp.chunk_log);
     }
     const size_t nparts_w = (size_t)1 << sp.hb;
@@ -811,7 +930,8 @@ namespace icicle_hip {
     }
     const uint32_t m = std::min<uint32_t>(nb, 32);
     const uint32_t nseg = nb / m;
-    TempBuf d_mont, d_partA, d_sorted, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win;
+    TempBuf d_mont, d_dig, d_partA, d_sorted, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win;
+    HIP_TRY(d_dig.alloc((size_t)pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
     std::vector<TempBuf> d_cntA(G), d_offA(G), d_bstart(G), d_ovf(G), d_ovfpart(G), d_ovfcnt(G);
     HIP_TRY(d_mont.alloc(npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_partA.alloc((size_t)wpf * cap * 4, st), ICICLE_ALLOCATION_FAILED);
@@ -831,12 +951,10 @@ namespace icicle_hip {
       HIP_TRY(d_ovfcnt[g].alloc(16, st), ICICLE_ALLOCATION_FAILED);
     }
 
-    const size_t ldsB = (2 * ((size_t)1 << sp.lb) + sp.nblk + 1) * 4;
-    if (ldsB > 150 * 1024) return ICICLE_INVALID_ARGUMENT;
-    for (int g = 0; g < G; g++)
-      if (groups[g].nparts > 16384 || groups[g].nparts * 4 > 64 * 1024) return ICICLE_INVALID_ARGUMENT;
-    HIP_TRY(hipFuncSetAttribute((const void*)k_part_a<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_part_a<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
+    const size_t ldsA = tile_lds_bytes(1u << sp.hb) + ((size_t)4 << sp.hb);
+    const size_t ldsB = tile_lds_bytes(1u << sp.lb) + ((size_t)sp.nblk + 1) * 4;
+    if (ldsA > 156 * 1024 || ldsB > 156 * 1024) return ICICLE_INVALID_ARGUMENT;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_b_count, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_b_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
 
@@ -856,6 +974,8 @@ namespace icicle_hip {
         HIP_TRY(hipStreamWaitEvent(ss, aux.ev_start(), 0), ICICLE_SYNCHRONIZATION_FAILED);
       }
       // ---- sort stages, all groups back to back on the sort stream
+      k_digits<C><<<(n + 255) / 256, 256, 0, ss>>>(sc, d_dig.as<uint32_t>(), n, pl.c, pl.nwin, smont);
+      LAUNCH_CHECK("k_digits", ss);
       for (int g = 0; g < G; g++) {
         const Group& gr = groups[g];
         uint32_t* cntA = d_cntA[g].as<uint32_t>();
@@ -865,13 +985,12 @@ namespace icicle_hip {
         uint32_t* count = d_count.as<uint32_t>() + (size_t)gr.w0 * nb;
         uint32_t* offs = d_offs.as<uint32_t>() + (size_t)gr.w0 * nb;
         uint32_t* cursor = d_cursor.as<uint32_t>() + (size_t)gr.w0 * nb;
-        const size_t ldsA = gr.nparts * 4;
-        k_part_a<C, true><<<sp.nblk, 1024, ldsA, ss>>>(sc, cntA, nullptr, nullptr, n, pl.c, pl.nwin, wpf, gr.w0, gr.nw, pf, sp, cap, smont);
-        LAUNCH_CHECK("k_part_a<count>", ss);
+        k_a_count<<<dim3(sp.nblk, gr.nw), 1024, ((size_t)4 << sp.hb), ss>>>(d_dig.as<uint32_t>(), cntA, n, pl.nwin, wpf, gr.w0, pf, sp);
+        LAUNCH_CHECK("k_a_count", ss);
         k_scan_a<<<gr.nw, 1024, 0, ss>>>(cntA, offA, (uint32_t)(nparts_w * sp.nblk));
         LAUNCH_CHECK("k_scan_a", ss);
-        k_part_a<C, false><<<sp.nblk, 1024, ldsA, ss>>>(sc, nullptr, offA, partA, n, pl.c, pl.nwin, wpf, gr.w0, gr.nw, pf, sp, cap, smont);
-        LAUNCH_CHECK("k_part_a<scatter>", ss);
+        k_a_scatter<<<dim3(sp.nblk, gr.nw), 1024, ldsA, ss>>>(d_dig.as<uint32_t>(), offA, partA, n, pl.nwin, wpf, gr.w0, pf, sp, cap);
+        LAUNCH_CHECK("k_a_scatter", ss);
         k_b_plan<<<1, 1024, 0, ss>>>(offA, d_bstart[g].as<uint32_t>(), (uint32_t)gr.nparts, gr.nw, sp.hb, sp.nblk);
         LAUNCH_CHECK("k_b_plan", ss);
         HIP_TRY(hipMemsetAsync(count, 0, (size_t)gr.nw * nb * 4, ss), ICICLE_COPY_FAILED);
@@ -903,10 +1022,21 @@ namespace icicle_hip {
         if (G > 1) HIP_TRY(hipStreamWaitEvent(st, aux.ev_sorted(g), 0), ICICLE_SYNCHRONIZATION_FAILED);
         KernelTimer::begin(0, st);
         const size_t nthreads_acc = gbk + gr.ovf_cap;
-        k_accumulate<C><<<(unsigned)((nthreads_acc + 127) / 128), 128, 0, st>>>(d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart[g].as<typename E::Proj>(), d_ovf[g].as<OvfSeg>(), d_ovfcnt[g].as<uint32_t>(), nb, gbk, cap, pl.seg);
+        {
+          // waves per SIMD the register allocator must leave room for: 3 fits BN254 (157 VGPRs) without
+          // spilling, 2 fits BLS12-381 (14-limb elements)
+          static const int minw = getenv("ICICLE_HIP_MSM_ACC_WAVES") ? atoi(getenv("ICICLE_HIP_MSM_ACC_WAVES")) : (E::F::N <= 9 ? 3 : 2);
+          const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
+#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart[g].as<typename E::Proj>(), d_ovf[g].as<OvfSeg>(), d_ovfcnt[g].as<uint32_t>(), nb, gbk, cap, pl.seg
+          if (minw == 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
+          else if (minw == 4) k_accumulate<C, 4><<<gridn, 128, 0, st>>>(ACC_ARGS);
+          else if (minw == 1) k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
+          else k_accumulate<C, 3><<<gridn, 128, 0, st>>>(ACC_ARGS);
+#undef ACC_ARGS
+        }
         LAUNCH_CHECK("k_accumulate", st);
         KernelTimer::end(0, st);
-        k_fold_overflow<C><<<(gr.ovf_cap + 63) / 64, 64, 0, st>>>(buckets, d_ovfpart[g].as<typename E::Proj>(), d_ovf[g].as<OvfSeg>(), d_ovfcnt[g].as<uint32_t>(), gr.ovf_cap);
+        k_fold_overflow<C><<<std::min<uint32_t>((gr.ovf_cap + 63) / 64, 2048), 64, 0, st>>>(buckets, d_ovfpart[g].as<typename E::Proj>(), d_ovf[g].as<OvfSeg>(), d_ovfcnt[g].as<uint32_t>(), gr.ovf_cap);
         LAUNCH_CHECK("k_fold_overflow", st);
         const size_t nsg = (size_t)gr.nw * nseg;
         typename E::Proj* seg = d_seg.as<typename E::Proj>() + (size_t)gr.w0 * nseg;
