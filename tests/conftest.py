@@ -15,6 +15,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def hip():
     """The product library bound to GPU 0. GPU tests fail loudly (no CPU fallback) if it is absent."""
+    # torch (used by a few GPU tests for device tensors) ships its own HIP runtime: initialise it BEFORE
+    # libicicle_hip.so pulls in /opt/rocm's, exactly as bench.py does, so the process has one runtime
+    try:
+        import torch
+
+        torch.cuda.is_available() and torch.cuda.init()
+    except Exception:
+        pass
     import icicle_amd
     from icicle_amd import runtime
 

@@ -227,3 +227,59 @@ def test_generated_points_are_distinct_multiples_of_g(hip):
     pts = M.generate_affine_points("bn254", 100, k0=5)
     exp = points_to_array(C, pyref.gen_points(C, 100, k0=5))
     assert np.array_equal(pts, exp)
+
+
+def test_msm_full_size_split_property(hip):
+    """BASELINE config 1 size (2^26 BN254, inputs resident in HBM): a size-independent property instead of
+    the CPU oracle -- MSM(all) == MSM(first half) + MSM(second half), with the halves combined by the
+    reference's own ecadd, plus a reference check on a 2^16 prefix of the same inputs."""
+    import ctypes
+    import torch
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib, check
+
+    refc = ref.RefCurve("bn254")
+    n = 1 << 26
+    dev = torch.device("cuda", 0)
+    bases = torch.empty((n, 16), dtype=torch.int32, device=dev)
+    check(lib.bn254_hip_generate_affine_points(bases.data_ptr(), n, 12345, True, None))
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    sc = torch.randint(-(2 ** 31), 2 ** 31, (n, 8), dtype=torch.int32, device=dev, generator=g)
+    sc[:, 7] = torch.randint(0, 0x30644E72, (n,), dtype=torch.int32, device=dev, generator=g)
+    torch.cuda.synchronize()
+
+    def run(lo, hi):
+        cfg = hip.MSMConfig.default()
+        out = np.zeros((1, 24), dtype=np.uint32)
+        M.msm("bn254", sc[lo:hi].data_ptr(), bases[lo:hi].data_ptr(), cfg, results=out, msm_size=hi - lo)
+        return out
+
+    full, a, b = run(0, n), run(0, n // 2), run(n // 2, n)
+    s = np.zeros(24, dtype=np.uint32)
+    refc.lib.bn254_ecadd(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(s.ctypes.data))
+    assert np.array_equal(refc.to_affine(full), refc.to_affine(s.reshape(1, 24)))
+    assert refc.is_on_curve(full[0])
+    m = 1 << 16
+    hs = np.ascontiguousarray(sc[:m].cpu().numpy().view(np.uint32))
+    hb = np.ascontiguousarray(bases[:m].cpu().numpy().view(np.uint32))
+    assert np.array_equal(refc.to_affine(run(0, m)), refc.to_affine(refc.msm(hs, hb)))
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_skewed_large_overflow_segments(hip, cname):
+    """2^18 scalars, almost all equal to 1 or 2 (msm/tests.rs:256-304 style skew): two buckets hold ~2^17
+    points each, far beyond the per-thread segment, so the overflow-segment path carries the result."""
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(31)
+    n = 1 << 18
+    bases = M.generate_affine_points(cname, n, k0=999)
+    vals = rng.integers(1, 3, size=n)
+    sc = np.zeros((n, 8), dtype=np.uint32)
+    sc[:, 0] = vals
+    sc[::1000] = to_words(rand_scalars(rng, len(sc[::1000]), C.r), 8)
+    _check(hip, cname, sc, bases, refc)
+    _check(hip, cname, sc, bases, refc, c=16)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Timing matrix over the BASELINE configs' shapes on one GPU (device-resident inputs, hipEvents via
+torch): prints one line per case. Used to fill profiles/rNN_perf_matrix.txt."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import icicle_amd  # noqa: E402
+from icicle_amd import msm as M, ntt as N, runtime  # noqa: E402
+from icicle_amd._lib import MSMConfig, NTTConfigU32, lib, check  # noqa: E402
+
+runtime.set_device(0)
+dev = torch.device("cuda", 0)
+TOP = {"bn254": 0x30644E72, "bls12_381": 0x73EDA753}
+
+
+def time_it(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def msm_case(curve, logn, batch=1, pf=1):
+    n = 1 << logn
+    L = M.LIMBS[curve]
+    bases = torch.empty((n, 2 * L), dtype=torch.int32, device=dev)
+    check(getattr(lib, f"{curve}_hip_generate_affine_points")(bases.data_ptr(), n, 1, True, None))
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    sc = torch.randint(-(2 ** 31), 2 ** 31, (n * batch, 8), dtype=torch.int32, device=dev, generator=g)
+    sc[:, 7] = torch.randint(0, TOP[curve], (n * batch,), dtype=torch.int32, device=dev, generator=g)
+    res = torch.empty((batch, 3 * L), dtype=torch.int32, device=dev)
+    cfg = MSMConfig.default()
+    cfg.batch_size = batch
+    cfg.is_async = True
+    ms = time_it(lambda: M.msm(curve, sc.data_ptr(), bases.data_ptr(), cfg, results=res.data_ptr(), msm_size=n))
+    print(f"msm {curve:10s} 2^{logn:<2d} batch {batch:<4d} {ms:9.3f} ms  {batch * n / ms / 1e6:8.2f} Gpoint/s", flush=True)
+
+
+def ntt_case(field, logn, batch):
+    n = 1 << logn
+    N.init_domain(field, N.get_root_of_unity(field, n))
+    p = {"babybear": 0x78000001, "koalabear": 0x7F000001}[field]
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    x = torch.randint(0, p, (batch, n), dtype=torch.int32, device=dev, generator=g)
+    y = torch.empty_like(x)
+    cfg = NTTConfigU32.default()
+    cfg.batch_size = batch
+    cfg.is_async = True
+    ms = time_it(lambda: N.ntt(field, x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n))
+    gbs = 2 * batch * n * 4 / ms / 1e6
+    print(f"ntt {field:10s} 2^{logn:<2d} batch {batch:<5d} {ms:9.3f} ms  {batch / ms * 1e3:10.0f} NTT/s  {gbs:7.0f} GB/s algorithmic", flush=True)
+    N.release_domain(field)
+
+
+if __name__ == "__main__":
+    for logn in (12, 16, 20, 22, 24, 26):
+        msm_case("bn254", logn)
+    msm_case("bn254", 12, batch=1024)
+    for logn in (20, 24, 25):
+        msm_case("bls12_381", logn)
+    for logn, batch in ((12, 4096), (16, 1024), (20, 256), (24, 64), (27, 4)):
+        ntt_case("babybear", logn, batch)
+    for logn, batch in ((22, 128), (22, 1024), (24, 64)):
+        ntt_case("koalabear", logn, batch)
