@@ -158,14 +158,16 @@ namespace icicle_hip {
 
   // digits of all windows, dig[wi*n + i] (coalesced 4-byte writes; read back window by window)
   template <class C>
-  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, int c, int nwin, bool scalars_refmont)
+  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, size_t nscal, int c, int nwin, bool scalars_refmont)
   {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    // nscal = (MSMs in this launch) * n scalars; row (b*nwin + wi) of `dig` holds window wi of MSM b
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nscal) return;
+    const size_t b = t / n, i = t - b * n;
     DigitIter it;
-    load_scalar<C>(it, scalars, (size_t)i, scalars_refmont);
+    load_scalar<C>(it, scalars, t, scalars_refmont);
     for (int wi = 0; wi < nwin; wi++)
-      dig[(size_t)wi * n + i] = it.next(wi, c);
+      dig[(b * nwin + wi) * n + i] = it.next(wi, c);
   }
 
   // exclusive prefix of one value per thread over the block (blockDim.x a multiple of 64, <= 1024);
@@ -222,10 +224,12 @@ namespace icicle_hip {
   __host__ __device__ static inline size_t tile_lds_bytes(uint32_t D) { return ((size_t)2 * D + SORT_TS + SORT_TS / 2 + 32) * 4; }
 
   // pass A count: block (b, wl) histograms the high key bits of scalar chunk b for target window w0+wl
-  __global__ __launch_bounds__(1024) void k_a_count(const uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int nwin, int wpf, int w0, int pf, SortPlan sp)
+  __global__ __launch_bounds__(1024) void k_a_count(const uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int nwin, int wpf, int pf, SortPlan sp)
   {
+    // wl = (MSM index in this launch) * wpf + target window
     extern __shared__ uint32_t lds[];
-    const int b = blockIdx.x, wl = blockIdx.y, wp = w0 + wl;
+    const int b = blockIdx.x, wl = blockIdx.y, wp = wl % wpf;
+    const size_t rowbase = (size_t)(wl / wpf) * nwin;
     const uint32_t D = 1u << sp.hb;
     for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
       lds[k] = 0;
@@ -234,7 +238,7 @@ namespace icicle_hip {
     for (int j = 0; j < pf; j++) {
       const int wi = j * wpf + wp;
       if (wi >= nwin) break;
-      const uint32_t* d = dig + (size_t)wi * n;
+      const uint32_t* d = dig + (rowbase + wi) * n;
       for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t key = d[i] & 0x7fffffffu;
         if (key) atomicAdd(&lds[(key - 1) >> sp.lb], 1u);
@@ -246,10 +250,13 @@ namespace icicle_hip {
   }
 
   // pass A scatter: element = sign | low key bits | j | index within chunk, into partition runs
-  __global__ __launch_bounds__(1024) void k_a_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int nwin, int wpf, int w0, int pf, SortPlan sp, size_t cap)
+  // FINAL: single-level sort (lb == 0): the element is already the bucket-list entry (point index | sign)
+  template <bool FINAL>
+  __global__ __launch_bounds__(1024) void k_a_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int nwin, int wpf, int pf, SortPlan sp, size_t cap)
   {
     extern __shared__ uint32_t lds[];
-    const int b = blockIdx.x, wl = blockIdx.y, wp = w0 + wl;
+    const int b = blockIdx.x, wl = blockIdx.y, wp = wl % wpf;
+    const size_t rowbase = (size_t)(wl / wpf) * nwin;
     const uint32_t D = 1u << sp.hb;
     TileLds t = tile_lds(lds, D);
     uint32_t* cursor = lds + tile_lds_bytes(D) / 4; // [D] running write position per destination
@@ -262,7 +269,7 @@ namespace icicle_hip {
     for (int j = 0; j < pf; j++) {
       const int wi = j * wpf + wp;
       if (wi >= nwin) break;
-      const uint32_t* d = dig + (size_t)wi * n;
+      const uint32_t* d = dig + (rowbase + wi) * n;
       for (int tile0 = lo; tile0 < hi; tile0 += SORT_TS) {
         if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
         __syncthreads();
@@ -276,7 +283,8 @@ namespace icicle_hip {
             const uint32_t key = dv & 0x7fffffffu;
             if (key) {
               const uint32_t km = key - 1, h = km >> sp.lb;
-              el[it] = (dv & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo);
+              el[it] = FINAL ? (((uint32_t)i * (uint32_t)pf + (uint32_t)j) | (dv & 0x80000000u))
+                             : ((dv & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo));
               dr[it] = (h << 16) | atomicAdd(&t.cnt[h], 1u);
             }
           }
@@ -334,6 +342,19 @@ namespace icicle_hip {
       run += x;
     }
     if (threadIdx.x == 1023) offA[(size_t)gridDim.x * m + blockIdx.x] = part[1023]; // window total
+  }
+
+  // single-level sort (lb == 0): bucket k of window wl IS partition k; count/offs come from pass A's table
+  __global__ __launch_bounds__(256) void k_tables_from_a(const uint32_t* __restrict__ offA, uint32_t* __restrict__ count, uint32_t* __restrict__ offs, size_t nbk, uint32_t nb, int nblk, size_t totals_base)
+  {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nbk) return;
+    const size_t wl = t / nb;
+    const uint32_t k = (uint32_t)(t - wl * nb);
+    const uint32_t ps = offA[t * nblk];
+    const uint32_t pe = (k + 1 < nb) ? offA[(t + 1) * nblk] : offA[totals_base + wl];
+    offs[t] = ps;
+    count[t] = pe - ps;
   }
 
   // pass B. A partition (window wp, high key bits h) is cut into sub-chunks of CHUNKB elements, one
@@ -551,8 +572,9 @@ namespace icicle_hip {
   }
 
   template <class C, int MINW>
-  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t nb, size_t nbk, size_t cap, uint32_t seg)
+  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
   {
+    // bases_stride: words between the base arrays of consecutive MSMs of a batch (0 = shared bases)
     using E = EC<C>;
     constexpr int PW = 2 * E::N32; // words per affine point
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -570,7 +592,8 @@ namespace icicle_hip {
       start = ovf[o].start;
       dst = ovf_part + o;
     }
-    const size_t wp = bucket / nb;
+    const size_t wp = bucket / nb; // window index within the launch = (MSM index) * wpf + target window
+    bases_mont += (wp / wpf) * bases_stride;
     const uint32_t total = count[bucket];
     const uint32_t cnt = min(total - min(total, start), seg);
     const uint32_t* src = sorted + wp * cap + offs[bucket] + start;
@@ -595,18 +618,33 @@ namespace icicle_hip {
     *dst = E::to_proj(acc, empty);
   }
 
-  // buckets[b] += its overflow partials (one thread per overflowing bucket)
+  // buckets[b] += its overflow partials: one 64-lane block per overflowing bucket at a time (lanes fold
+  // strided partials, then a tree through LDS), so a bucket with thousands of segments -- a 1-bit top
+  // window, all-equal scalars -- costs log-depth, not a serial chain.
   template <class C>
   __global__ __launch_bounds__(64) void k_fold_overflow(typename EC<C>::Proj* __restrict__ buckets, const typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t ovf_cap)
   {
     using E = EC<C>;
+    __shared__ typename E::Proj sh[64];
     const uint32_t n = min(*ovf_count, ovf_cap);
-    for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {
-      if (!ovf[o].first) continue;
-      typename E::Proj acc = buckets[ovf[o].bucket];
-      for (uint32_t k = 0; k < ovf[o].nextra && o + k < n; k++)
-        acc = E::add(acc, ovf_part[o + k]);
-      buckets[ovf[o].bucket] = acc;
+    const int lane = threadIdx.x;
+    for (uint32_t o = blockIdx.x; o < n; o += gridDim.x) {
+      if (!ovf[o].first) continue; // block-uniform
+      const uint32_t ne = min(ovf[o].nextra, n - o);
+      typename E::Proj v = E::proj_identity();
+      for (uint32_t k = lane; k < ne; k += 64)
+        v = E::add(v, ovf_part[o + k]);
+      sh[lane] = v;
+      __syncthreads();
+      for (int s = 32; s >= 1; s >>= 1) {
+        if (lane < s) {
+          v = E::add(v, sh[lane + s]);
+          sh[lane] = v;
+        }
+        __syncthreads();
+      }
+      if (lane == 0) buckets[ovf[o].bucket] = E::add(buckets[ovf[o].bucket], v);
+      __syncthreads();
     }
   }
 
@@ -668,6 +706,8 @@ namespace icicle_hip {
     using E = EC<C>;
     __shared__ typename E::Proj sh[128];
     const int lane = threadIdx.x;
+    winsum += (size_t)blockIdx.x * wpf;
+    result += (size_t)blockIdx.x * 3 * E::N32;
     typename E::Proj v = E::proj_identity();
     if (lane < wpf) {
       v = winsum[lane];
@@ -876,17 +916,16 @@ namespace icicle_hip {
       d_bases = d_b_tmp.as<uint32_t>();
     }
 
-    // ---- temporaries
+    // ---- geometry
     const uint32_t nb = pl.nb;
     const int wpf = pl.wpf;
-    const size_t cap = npts_one; // sorted-index capacity per target window
-    const size_t nbk = (size_t)wpf * nb;
-    // two-level sort geometry
+    const size_t cap = npts_one; // bucket-list capacity per target window
     SortPlan sp;
     {
       const int kb = pl.c - 1;
-      // each tile-sorted pass ranks into <= 1024 destinations (one per thread of the block)
-      int hb = (kb + 1) / 2;
+      // each tile-sorted pass ranks into <= 1024 destinations (one per thread of the block); small
+      // windows (kb <= 10) need a single level: pass A already produces the bucket lists
+      int hb = kb <= 10 ? kb : (kb + 1) / 2;
       if (const char* e = getenv("ICICLE_HIP_MSM_HB")) hb = atoi(e);
       hb = std::max(kb - 10, std::min(std::min(kb, 10), hb));
       if (hb < 0 || hb > 10 || kb - hb > 10) return ICICLE_INVALID_ARGUMENT;
@@ -904,152 +943,135 @@ namespace icicle_hip {
       if (sp.chunk_log < logn - 9) return ICICLE_INVALID_ARGUMENT; // would need more than 512 pass-A blocks per window
       sp.nblk = (int)(((size_t)n + ((size_t)1 << sp.chunk_log) - 1) >> sp.chunk_log);
     }
+    const bool single_level = (sp.lb == 0);
     const size_t nparts_w = (size_t)1 << sp.hb;
-    // Window groups: the sort of group g+1 (LDS-atomic / memory bound, on a second stream) overlaps the
-    // bucket accumulation of group g (VALU-issue bound, on the caller's stream).
-    // Measured (profiles/r01_notes.md): with pass A re-reading the scalars once per group the extra
-    // sort work outweighs the overlap (105 / 110 / 127 ms for 1 / 2 / 4 groups at 2^26), so the default
-    // is ONE group (no second stream); ICICLE_HIP_MSM_GROUPS=<g> keeps the experiment reproducible.
-    int G = 1;
-    if (const char* e = getenv("ICICLE_HIP_MSM_GROUPS")) G = std::max(1, std::min(wpf, atoi(e)));
-    struct Group {
-      int w0, nw;
-      size_t tabA, nparts;
-      uint32_t maxblkB, ovf_cap;
-    };
-    std::vector<Group> groups(G);
-    for (int g = 0; g < G; g++) {
-      Group& gr = groups[g];
-      gr.w0 = (int)((size_t)wpf * g / G);
-      gr.nw = (int)((size_t)wpf * (g + 1) / G) - gr.w0;
-      gr.nparts = (size_t)gr.nw << sp.hb;
-      gr.tabA = gr.nparts * sp.nblk + gr.nw;
-      const size_t elems = (size_t)n * pl.nwin * gr.nw / wpf + 1;
-      gr.maxblkB = (uint32_t)(gr.nparts + (elems >> CHUNKB_LOG) + 2);
-      gr.ovf_cap = (uint32_t)std::min<size_t>(elems / pl.seg + 16, 0x7fffffffu);
-    }
     const uint32_t m = std::min<uint32_t>(nb, 32);
     const uint32_t nseg = nb / m;
-    TempBuf d_mont, d_dig, d_partA, d_sorted, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win;
-    HIP_TRY(d_dig.alloc((size_t)pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
-    std::vector<TempBuf> d_cntA(G), d_offA(G), d_bstart(G), d_ovf(G), d_ovfpart(G), d_ovfcnt(G);
-    HIP_TRY(d_mont.alloc(npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_partA.alloc((size_t)wpf * cap * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_sorted.alloc((size_t)wpf * cap * 4, st), ICICLE_ALLOCATION_FAILED);
+
+    // ---- batch folding: BB MSMs of the batch run as ONE launch sequence with BB*wpf windows
+    // (wrappers/rust/icicle-core/src/msm/tests.rs:92-254 batches; small MSMs would otherwise leave the
+    // GPU idle). BB is bounded by a memory budget and by the grid.y limit.
+    const size_t per_msm_bytes = (size_t)pl.nwin * n * 4 + (single_level ? 1 : 2) * (size_t)wpf * cap * 4 + (size_t)wpf * nb * (sizeof(typename E::Proj) + 12) +
+                                 (size_t)wpf * nparts_w * sp.nblk * 8 + (shared ? 0 : npts_one * PW * 4);
+    size_t budget = (size_t)48 << 30;
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 2);
+    }
+    int BB = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / std::max<size_t>(per_msm_bytes, 1)));
+    BB = std::min(BB, std::max(1, 60000 / wpf));
+    const size_t TW = (size_t)BB * wpf; // windows per launch
+    const size_t nbk = TW * nb;
+    const size_t nparts = TW << sp.hb;
+    const size_t tabA = nparts * sp.nblk + TW; // [wl][h][b] counters + per-window totals
+    const size_t elems_max = (size_t)BB * n * pl.nwin + 1;
+    const uint32_t maxblkB = (uint32_t)std::min<size_t>(nparts + (elems_max >> CHUNKB_LOG) + 2, 0x7fffffffu);
+    const uint32_t ovf_cap = (uint32_t)std::min<size_t>(elems_max / pl.seg + 16, 0x7fffffffu);
+
+    TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt;
+    HIP_TRY(d_mont.alloc((shared ? 1 : (size_t)BB) * npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_dig.alloc((size_t)BB * pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
+    if (!single_level) HIP_TRY(d_partA.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_sorted.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_cntA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_offA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_bstart.alloc((nparts + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_count.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_offs.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_cursor.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_buckets.alloc(nbk * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_seg.alloc((size_t)wpf * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_win.alloc((size_t)wpf * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    for (int g = 0; g < G; g++) {
-      HIP_TRY(d_cntA[g].alloc(groups[g].tabA * 4, st), ICICLE_ALLOCATION_FAILED);
-      HIP_TRY(d_offA[g].alloc(groups[g].tabA * 4, st), ICICLE_ALLOCATION_FAILED);
-      HIP_TRY(d_bstart[g].alloc((groups[g].nparts + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
-      HIP_TRY(d_ovf[g].alloc((size_t)groups[g].ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
-      HIP_TRY(d_ovfpart[g].alloc((size_t)groups[g].ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-      HIP_TRY(d_ovfcnt[g].alloc(16, st), ICICLE_ALLOCATION_FAILED);
-    }
+    HIP_TRY(d_seg.alloc(TW * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_win.alloc(TW * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovfcnt.alloc(16, st), ICICLE_ALLOCATION_FAILED);
 
     const size_t ldsA = tile_lds_bytes(1u << sp.hb) + ((size_t)4 << sp.hb);
     const size_t ldsB = tile_lds_bytes(1u << sp.lb) + ((size_t)sp.nblk + 1) * 4;
     if (ldsA > 156 * 1024 || ldsB > 156 * 1024) return ICICLE_INVALID_ARGUMENT;
-    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_b_count, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_b_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
 
-    // second stream for the sort stages + events (leased per call, cached per device)
-    AuxStream aux;
-    hipStream_t ss = st;
-    if (G > 1) {
-      HIP_TRY(aux.acquire(G), ICICLE_STREAM_CREATION_FAILED);
-      ss = aux.stream();
-    }
+    uint32_t* dig = d_dig.as<uint32_t>();
+    uint32_t* cntA = d_cntA.as<uint32_t>();
+    uint32_t* offA = d_offA.as<uint32_t>();
+    uint32_t* sorted = d_sorted.as<uint32_t>();
+    uint32_t* count = d_count.as<uint32_t>();
+    uint32_t* offs = d_offs.as<uint32_t>();
+    typename E::Proj* buckets = d_buckets.as<typename E::Proj>();
 
-    for (int b = 0; b < batch; b++) {
-      const uint32_t* sc = d_scalars + (size_t)b * n * FR::N32;
-      const bool smont = cfg->are_scalars_montgomery_form;
-      if (G > 1) { // the sort stream starts after everything already queued on the caller's stream
-        HIP_TRY(hipEventRecord(aux.ev_start(), st), ICICLE_SYNCHRONIZATION_FAILED);
-        HIP_TRY(hipStreamWaitEvent(ss, aux.ev_start(), 0), ICICLE_SYNCHRONIZATION_FAILED);
-      }
-      // ---- sort stages, all groups back to back on the sort stream
-      k_digits<C><<<(n + 255) / 256, 256, 0, ss>>>(sc, d_dig.as<uint32_t>(), n, pl.c, pl.nwin, smont);
-      LAUNCH_CHECK("k_digits", ss);
-      for (int g = 0; g < G; g++) {
-        const Group& gr = groups[g];
-        uint32_t* cntA = d_cntA[g].as<uint32_t>();
-        uint32_t* offA = d_offA[g].as<uint32_t>();
-        uint32_t* partA = d_partA.as<uint32_t>() + (size_t)gr.w0 * cap;
-        uint32_t* sorted = d_sorted.as<uint32_t>() + (size_t)gr.w0 * cap;
-        uint32_t* count = d_count.as<uint32_t>() + (size_t)gr.w0 * nb;
-        uint32_t* offs = d_offs.as<uint32_t>() + (size_t)gr.w0 * nb;
-        uint32_t* cursor = d_cursor.as<uint32_t>() + (size_t)gr.w0 * nb;
-        k_a_count<<<dim3(sp.nblk, gr.nw), 1024, ((size_t)4 << sp.hb), ss>>>(d_dig.as<uint32_t>(), cntA, n, pl.nwin, wpf, gr.w0, pf, sp);
-        LAUNCH_CHECK("k_a_count", ss);
-        k_scan_a<<<gr.nw, 1024, 0, ss>>>(cntA, offA, (uint32_t)(nparts_w * sp.nblk));
-        LAUNCH_CHECK("k_scan_a", ss);
-        k_a_scatter<<<dim3(sp.nblk, gr.nw), 1024, ldsA, ss>>>(d_dig.as<uint32_t>(), offA, partA, n, pl.nwin, wpf, gr.w0, pf, sp, cap);
-        LAUNCH_CHECK("k_a_scatter", ss);
-        k_b_plan<<<1, 1024, 0, ss>>>(offA, d_bstart[g].as<uint32_t>(), (uint32_t)gr.nparts, gr.nw, sp.hb, sp.nblk);
-        LAUNCH_CHECK("k_b_plan", ss);
-        HIP_TRY(hipMemsetAsync(count, 0, (size_t)gr.nw * nb * 4, ss), ICICLE_COPY_FAILED);
-        k_b_count<<<gr.maxblkB, 1024, ((size_t)1 << sp.lb) * 4, ss>>>(partA, offA, d_bstart[g].as<uint32_t>(), count, (uint32_t)gr.nparts, gr.nw, sp, cap, nb);
-        LAUNCH_CHECK("k_b_count", ss);
-        k_scan_buckets<<<gr.nw, 1024, 0, ss>>>(count, offs, cursor, nb);
-        LAUNCH_CHECK("k_scan_buckets", ss);
-        k_b_scatter<<<gr.maxblkB, 1024, ldsB, ss>>>(partA, offA, d_bstart[g].as<uint32_t>(), cursor, sorted, (uint32_t)gr.nparts, gr.nw, pf, sp, cap, nb);
-        LAUNCH_CHECK("k_b_scatter", ss);
-        HIP_TRY(hipMemsetAsync(d_ovfcnt[g].ptr(), 0, 16, ss), ICICLE_COPY_FAILED);
-        k_plan_overflow<<<(unsigned)(((size_t)gr.nw * nb + 255) / 256), 256, 0, ss>>>(count, (size_t)gr.nw * nb, pl.seg, d_ovfcnt[g].as<uint32_t>(), d_ovf[g].as<OvfSeg>(), gr.ovf_cap);
-        LAUNCH_CHECK("k_plan_overflow", ss);
-        if (G > 1) HIP_TRY(hipEventRecord(aux.ev_sorted(g), ss), ICICLE_SYNCHRONIZATION_FAILED);
-      }
-      // ---- compute stages on the caller's stream
-      if (b == 0 || !shared) {
-        const uint32_t* src = d_bases + (shared ? 0 : (size_t)b * npts_one * PW);
-        const size_t ncoord = npts_one * 2;
+    for (int b0 = 0; b0 < batch; b0 += BB) {
+      const int bb = std::min(BB, batch - b0); // MSMs in this launch sequence
+      const size_t tw = (size_t)bb * wpf;
+      const size_t gbk = tw * nb;
+      const size_t gparts = tw << sp.hb;
+      if (b0 == 0 || !shared) {
+        const uint32_t* src = d_bases + (shared ? 0 : (size_t)b0 * npts_one * PW);
+        const size_t ncoord = (shared ? 1 : (size_t)bb) * npts_one * 2;
         k_bases_to_mont<C><<<dim3((unsigned)((ncoord + 255) / 256)), 256, 0, st>>>(src, d_mont.as<uint32_t>(), ncoord, cfg->are_points_montgomery_form);
         LAUNCH_CHECK("k_bases_to_mont", st);
       }
-      for (int g = 0; g < G; g++) {
-        const Group& gr = groups[g];
-        const size_t gbk = (size_t)gr.nw * nb;
-        uint32_t* sorted = d_sorted.as<uint32_t>() + (size_t)gr.w0 * cap;
-        uint32_t* count = d_count.as<uint32_t>() + (size_t)gr.w0 * nb;
-        uint32_t* offs = d_offs.as<uint32_t>() + (size_t)gr.w0 * nb;
-        typename E::Proj* buckets = d_buckets.as<typename E::Proj>() + (size_t)gr.w0 * nb;
-        if (G > 1) HIP_TRY(hipStreamWaitEvent(st, aux.ev_sorted(g), 0), ICICLE_SYNCHRONIZATION_FAILED);
-        KernelTimer::begin(0, st);
-        const size_t nthreads_acc = gbk + gr.ovf_cap;
-        {
-          // waves per SIMD the register allocator must leave room for: 3 fits BN254 (157 VGPRs) without
-          // spilling, 2 fits BLS12-381 (14-limb elements)
-          static const int minw = getenv("ICICLE_HIP_MSM_ACC_WAVES") ? atoi(getenv("ICICLE_HIP_MSM_ACC_WAVES")) : (E::F::N <= 9 ? 3 : 2);
-          const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
-#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart[g].as<typename E::Proj>(), d_ovf[g].as<OvfSeg>(), d_ovfcnt[g].as<uint32_t>(), nb, gbk, cap, pl.seg
-          if (minw == 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
-          else if (minw == 4) k_accumulate<C, 4><<<gridn, 128, 0, st>>>(ACC_ARGS);
-          else if (minw == 1) k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
-          else k_accumulate<C, 3><<<gridn, 128, 0, st>>>(ACC_ARGS);
+      const uint32_t* sc = d_scalars + (size_t)b0 * n * FR::N32;
+      const size_t nscal = (size_t)bb * n;
+      k_digits<C><<<(unsigned)((nscal + 255) / 256), 256, 0, st>>>(sc, dig, n, nscal, pl.c, pl.nwin, cfg->are_scalars_montgomery_form);
+      LAUNCH_CHECK("k_digits", st);
+      // the per-window totals live right after the [tw][2^hb][nblk] table of THIS launch
+      k_a_count<<<dim3(sp.nblk, (unsigned)tw), 1024, ((size_t)4 << sp.hb), st>>>(dig, cntA, n, pl.nwin, wpf, pf, sp);
+      LAUNCH_CHECK("k_a_count", st);
+      k_scan_a<<<(unsigned)tw, 1024, 0, st>>>(cntA, offA, (uint32_t)(nparts_w * sp.nblk));
+      LAUNCH_CHECK("k_scan_a", st);
+      if (single_level) {
+        k_a_scatter<true><<<dim3(sp.nblk, (unsigned)tw), 1024, ldsA, st>>>(dig, offA, sorted, n, pl.nwin, wpf, pf, sp, cap);
+        LAUNCH_CHECK("k_a_scatter<final>", st);
+        k_tables_from_a<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(offA, count, offs, gbk, nb, sp.nblk, gparts * sp.nblk);
+        LAUNCH_CHECK("k_tables_from_a", st);
+      } else {
+        uint32_t* partA = d_partA.as<uint32_t>();
+        const size_t elems = (size_t)bb * n * pl.nwin + 1;
+        const uint32_t nblkB = (uint32_t)std::min<size_t>(gparts + (elems >> CHUNKB_LOG) + 2, maxblkB);
+        k_a_scatter<false><<<dim3(sp.nblk, (unsigned)tw), 1024, ldsA, st>>>(dig, offA, partA, n, pl.nwin, wpf, pf, sp, cap);
+        LAUNCH_CHECK("k_a_scatter", st);
+        k_b_plan<<<1, 1024, 0, st>>>(offA, d_bstart.as<uint32_t>(), (uint32_t)gparts, (int)tw, sp.hb, sp.nblk);
+        LAUNCH_CHECK("k_b_plan", st);
+        HIP_TRY(hipMemsetAsync(count, 0, gbk * 4, st), ICICLE_COPY_FAILED);
+        k_b_count<<<nblkB, 1024, ((size_t)1 << sp.lb) * 4, st>>>(partA, offA, d_bstart.as<uint32_t>(), count, (uint32_t)gparts, (int)tw, sp, cap, nb);
+        LAUNCH_CHECK("k_b_count", st);
+        k_scan_buckets<<<(unsigned)tw, 1024, 0, st>>>(count, offs, d_cursor.as<uint32_t>(), nb);
+        LAUNCH_CHECK("k_scan_buckets", st);
+        k_b_scatter<<<nblkB, 1024, ldsB, st>>>(partA, offA, d_bstart.as<uint32_t>(), d_cursor.as<uint32_t>(), sorted, (uint32_t)gparts, (int)tw, pf, sp, cap, nb);
+        LAUNCH_CHECK("k_b_scatter", st);
+      }
+      HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16, st), ICICLE_COPY_FAILED);
+      k_plan_overflow<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(count, gbk, pl.seg, d_ovfcnt.as<uint32_t>(), d_ovf.as<OvfSeg>(), ovf_cap);
+      LAUNCH_CHECK("k_plan_overflow", st);
+      KernelTimer::begin(0, st);
+      {
+        // waves per SIMD the register allocator must leave room for: 3 fits BN254 (157 VGPRs) without
+        // spilling, 2 fits BLS12-381 (14-limb elements)
+        static const int minw = getenv("ICICLE_HIP_MSM_ACC_WAVES") ? atoi(getenv("ICICLE_HIP_MSM_ACC_WAVES")) : (E::F::N <= 9 ? 3 : 2);
+        const size_t nthreads_acc = gbk + ovf_cap;
+        const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
+        const size_t bstride = shared ? 0 : npts_one * PW;
+#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), nb, gbk, cap, pl.seg, wpf, bstride
+        if (minw == 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
+        else if (minw == 4) k_accumulate<C, 4><<<gridn, 128, 0, st>>>(ACC_ARGS);
+        else if (minw == 1) k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
+        else k_accumulate<C, 3><<<gridn, 128, 0, st>>>(ACC_ARGS);
 #undef ACC_ARGS
-        }
-        LAUNCH_CHECK("k_accumulate", st);
-        KernelTimer::end(0, st);
-        k_fold_overflow<C><<<std::min<uint32_t>((gr.ovf_cap + 63) / 64, 2048), 64, 0, st>>>(buckets, d_ovfpart[g].as<typename E::Proj>(), d_ovf[g].as<OvfSeg>(), d_ovfcnt[g].as<uint32_t>(), gr.ovf_cap);
-        LAUNCH_CHECK("k_fold_overflow", st);
-        const size_t nsg = (size_t)gr.nw * nseg;
-        typename E::Proj* seg = d_seg.as<typename E::Proj>() + (size_t)gr.w0 * nseg;
-        k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(buckets, seg, nb, m, gr.nw);
-        LAUNCH_CHECK("k_reduce_segments", st);
-        k_reduce_window<C><<<gr.nw, 256, 0, st>>>(seg, d_win.as<typename E::Proj>() + gr.w0, nseg);
-        LAUNCH_CHECK("k_reduce_window", st);
       }
-      k_final<C><<<1, 128, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b * RW, wpf, pl.c);
+      LAUNCH_CHECK("k_accumulate", st);
+      KernelTimer::end(0, st);
+      k_fold_overflow<C><<<std::min<uint32_t>(ovf_cap, 4096), 64, 0, st>>>(buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
+      LAUNCH_CHECK("k_fold_overflow", st);
+      const size_t nsg = tw * nseg;
+      k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(buckets, d_seg.as<typename E::Proj>(), nb, m, (int)tw);
+      LAUNCH_CHECK("k_reduce_segments", st);
+      k_reduce_window<C><<<(unsigned)tw, 256, 0, st>>>(d_seg.as<typename E::Proj>(), d_win.as<typename E::Proj>(), nseg);
+      LAUNCH_CHECK("k_reduce_window", st);
+      k_final<C><<<bb, 128, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c);
       LAUNCH_CHECK("k_final", st);
-      if (G > 1 && b + 1 < batch) { // the next batch element's sort must not overwrite lists still being read
-        HIP_TRY(hipEventRecord(aux.ev_start(), st), ICICLE_SYNCHRONIZATION_FAILED);
-      }
     }
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
 
