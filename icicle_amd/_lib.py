@@ -83,6 +83,24 @@ class NTTConfigU32(ctypes.Structure):
         return cls(None, 1, 1, False, 0, False, False, False, None)
 
 
+class VecOpsConfig(ctypes.Structure):
+    """icicle::VecOpsConfig (include/icicle/vec_ops.h:19-37), 32 bytes."""
+    _fields_ = [
+        ("stream", ctypes.c_void_p),
+        ("is_a_on_device", ctypes.c_bool),
+        ("is_b_on_device", ctypes.c_bool),
+        ("is_result_on_device", ctypes.c_bool),
+        ("is_async", ctypes.c_bool),
+        ("batch_size", ctypes.c_int),
+        ("columns_batch", ctypes.c_bool),
+        ("ext", ctypes.c_void_p),
+    ]
+
+    @classmethod
+    def default(cls):
+        return cls(None, False, False, False, False, 1, False, None)
+
+
 class NTTInitDomainConfig(ctypes.Structure):
     _fields_ = [("stream", ctypes.c_void_p), ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p)]
 
@@ -95,6 +113,7 @@ assert ctypes.sizeof(Device) == 68 and Device.id.offset == 64
 assert ctypes.sizeof(MSMConfig) == 40 and MSMConfig.ext.offset == 32
 assert ctypes.sizeof(NTTConfigU32) == 40 and NTTConfigU32.ordering.offset == 20
 assert ctypes.sizeof(NTTInitDomainConfig) == 24
+assert ctypes.sizeof(VecOpsConfig) == 32 and VecOpsConfig.batch_size.offset == 12 and VecOpsConfig.ext.offset == 24
 
 # every symbol include/icicle_hip.h declares (tests/test_abi.py checks the header against this)
 RUNTIME_SYMBOLS = [
@@ -121,6 +140,9 @@ API_SYMBOLS = (
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
                                                           "get_root_of_unity_from_domain")]
+    + [f"{pre}{f}_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in CURVES + NTT_FIELDS]
+    + [f"{pre}{f}_extension_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in NTT_FIELDS]
+    + [f"{pre}{c}_{k}_convert_montgomery" for pre in ("", "icicle_hip_") for c in CURVES for k in ("affine", "projective")]
 )
 
 if not os.path.exists(LIB_PATH):
@@ -170,5 +192,8 @@ for _f in NTT_FIELDS:
     getattr(lib, f"{_f}_ntt_init_domain").argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(NTTInitDomainConfig)]
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
+for _n in API_SYMBOLS:
+    if _n.endswith("convert_montgomery"):
+        getattr(lib, _n).argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_bool, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
 lib.icicle_hip_kernel_timing.argtypes = [ctypes.c_int, ctypes.c_bool, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
 lib.icicle_hip_enable_kernel_timing.argtypes = [ctypes.c_bool]

@@ -1,0 +1,46 @@
+"""Montgomery-form conversion on device: mirror of wrappers/rust/icicle-core/src/vec_ops (convert_montgomery)
+and icicle-core/src/curve (Affine/Projective to_mont / from_mont)."""
+import ctypes
+import numpy as np
+from ._lib import lib, check, VecOpsConfig
+from .runtime import DeviceVec
+
+
+def _ptr(x):
+    if isinstance(x, DeviceVec):
+        return x.ptr, True
+    if isinstance(x, int):
+        return x, True
+    assert isinstance(x, np.ndarray) and x.dtype == np.uint32 and x.flags["C_CONTIGUOUS"]
+    return x.ctypes.data, False
+
+
+def _run(symbol, inp, count, to_montgomery, cfg, out):
+    cfg = cfg or VecOpsConfig.default()
+    ip, i_dev = _ptr(inp)
+    cfg.is_a_on_device = i_dev
+    if out is None:
+        out = np.zeros_like(inp)
+    op, o_dev = _ptr(out)
+    cfg.is_result_on_device = o_dev
+    check(getattr(lib, symbol)(ip, count, to_montgomery, ctypes.byref(cfg), op), symbol)
+    return out
+
+
+def scalar_convert_montgomery(field: str, inp, to_montgomery: bool, cfg=None, out=None, size=None, extension=False):
+    """field in {bn254, bls12_381, babybear, koalabear}; `size` = elements per batch entry"""
+    words = {"bn254": 8, "bls12_381": 8, "babybear": 1, "koalabear": 1}[field] * (4 if extension else 1)
+    if size is None:
+        size = inp.size // words // max(1, (cfg.batch_size if cfg else 1))
+    sym = f"{field}_extension_scalar_convert_montgomery" if extension else f"{field}_scalar_convert_montgomery"
+    return _run(sym, inp, size, to_montgomery, cfg, out)
+
+
+def affine_convert_montgomery(curve: str, inp, to_montgomery: bool, cfg=None, out=None, n=None):
+    L = {"bn254": 8, "bls12_381": 12}[curve]
+    return _run(f"{curve}_affine_convert_montgomery", inp, n if n is not None else inp.size // (2 * L), to_montgomery, cfg, out)
+
+
+def projective_convert_montgomery(curve: str, inp, to_montgomery: bool, cfg=None, out=None, n=None):
+    L = {"bn254": 8, "bls12_381": 12}[curve]
+    return _run(f"{curve}_projective_convert_montgomery", inp, n if n is not None else inp.size // (3 * L), to_montgomery, cfg, out)

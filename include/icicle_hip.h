@@ -163,6 +163,36 @@ typedef struct {
 ICICLE_HIP_DECLARE_NTT_U32(babybear)
 ICICLE_HIP_DECLARE_NTT_U32(koalabear)
 
+/* ======================================================================================
+ * Montgomery-form conversion (vec-ops): include/icicle/vec_ops.h:19-37 (VecOpsConfig, 32 bytes),
+ * src/vec_ops.cpp:404-408,421-425 (<prefix>_scalar_convert_montgomery, _extension_scalar_convert_montgomery),
+ * src/curves/montgomery_conversion.cpp:12-16,46-50 (<curve>_affine/_projective_convert_montgomery).
+ * x -> x*R (is_to_montgomery) or x*R^-1 mod p, R = 2^(32*limbs); element-wise, any layout.
+ * ====================================================================================== */
+typedef struct {
+  icicleStreamHandle stream;      /* 0  */
+  bool is_a_on_device;            /* 8  */
+  bool is_b_on_device;            /* 9  */
+  bool is_result_on_device;       /* 10 */
+  bool is_async;                  /* 11 */
+  int batch_size;                 /* 12 */
+  bool columns_batch;             /* 16 */
+  icicle_config_extension_t* ext; /* 24 */
+} icicle_vec_ops_config_t;
+
+#define ICICLE_HIP_DECLARE_CONVERT(P)                                                                                  \
+  icicle_error_t P##_scalar_convert_montgomery(const void* input, uint64_t size, bool is_to_montgomery, const icicle_vec_ops_config_t* config, void* output);
+ICICLE_HIP_DECLARE_CONVERT(bn254)
+ICICLE_HIP_DECLARE_CONVERT(bls12_381)
+ICICLE_HIP_DECLARE_CONVERT(babybear)
+ICICLE_HIP_DECLARE_CONVERT(koalabear)
+icicle_error_t babybear_extension_scalar_convert_montgomery(const void* input, uint64_t size, bool is_to_montgomery, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t koalabear_extension_scalar_convert_montgomery(const void* input, uint64_t size, bool is_to_montgomery, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t bn254_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t bn254_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t bls12_381_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t bls12_381_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+
 /* ---- backend-specific helpers (not part of the reference ABI) ---- */
 const char* icicle_hip_version(void);
 /* Device-side synthetic input generator for benchmarks: fills `out` (device or host per flag) with
@@ -195,6 +225,16 @@ icicle_error_t icicle_hip_bls12_381_msm_precompute_bases(const void* input_bases
   icicle_error_t icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);
 ICICLE_HIP_DECLARE_NTT_ALIASES(babybear)
 ICICLE_HIP_DECLARE_NTT_ALIASES(koalabear)
+ICICLE_HIP_DECLARE_CONVERT(icicle_hip_bn254)
+ICICLE_HIP_DECLARE_CONVERT(icicle_hip_bls12_381)
+ICICLE_HIP_DECLARE_CONVERT(icicle_hip_babybear)
+ICICLE_HIP_DECLARE_CONVERT(icicle_hip_koalabear)
+icicle_error_t icicle_hip_babybear_extension_scalar_convert_montgomery(const void* input, uint64_t size, bool is_to_montgomery, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_koalabear_extension_scalar_convert_montgomery(const void* input, uint64_t size, bool is_to_montgomery, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_bn254_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_bn254_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_bls12_381_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_bls12_381_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,27 @@ class RefRuntime:
         return self.lib.icicle_copy(dst, src, nbytes)
 
 
+class VecOpsConfig(ctypes.Structure):  # icicle/include/icicle/vec_ops.h:19-37
+    _fields_ = [("stream", ctypes.c_void_p), ("is_a_on_device", ctypes.c_bool), ("is_b_on_device", ctypes.c_bool),
+                ("is_result_on_device", ctypes.c_bool), ("is_async", ctypes.c_bool), ("batch_size", ctypes.c_int),
+                ("columns_batch", ctypes.c_bool), ("ext", ctypes.c_void_p)]
+
+
+def ref_convert_montgomery(libname: str, symbol: str, arr: np.ndarray, count: int, to_mont: bool) -> np.ndarray:
+    """<prefix>_scalar_convert_montgomery / _affine_ / _projective_convert_montgomery of the reference, on
+    the calling thread's active device (host buffers)."""
+    lib = _load(libname) if libname in ("bn254", "bls12_381", "babybear", "koalabear") and symbol.find("scalar") < 0 else None
+    if lib is None:
+        lib = ctypes.CDLL(os.path.join(REF_DIR, f"libicicle_field_{libname}.so")) if "scalar" in symbol else _load(libname)
+    cfg = VecOpsConfig(None, False, False, False, False, 1, False, None)
+    out = np.zeros_like(arr)
+    fn = getattr(lib, symbol)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_bool, ctypes.c_void_p, ctypes.c_void_p]
+    rc = fn(arr.ctypes.data, count, to_mont, ctypes.byref(cfg), out.ctypes.data)
+    assert rc == 0, f"{symbol} rc={rc}"
+    return out
+
+
 class RefCurve:
     """bn254 / bls12_381 through the reference's own C ABI, on its "CPU" device."""
 

@@ -6,6 +6,7 @@
 // through byte-for-byte (same 40-byte layout) except `ext`, whose C++ object belongs to the reference.
 #include <cstring>
 #include "icicle/backend/msm_backend.h"
+#include "icicle/curves/montgomery_conversion.h"
 #include "icicle/curves/curve_config.h"
 #include "icicle/utils/utils.h"
 #include "hip_c_api.h"
@@ -38,6 +39,30 @@ static eIcicleError hip_msm_precompute(const Device& device, const affine_t* inp
   const hip_msm_config_t c = translate(config);
   return (eIcicleError)HIP_FN(msm_precompute_bases)(input_bases, nof_bases, &c, output_bases);
 }
+
+static_assert(sizeof(VecOpsConfig) == sizeof(hip_vec_ops_config_t), "VecOpsConfig layout drifted");
+static hip_vec_ops_config_t translate(const VecOpsConfig& c)
+{
+  hip_vec_ops_config_t o;
+  std::memcpy(&o, &c, sizeof(o));
+  o.ext = nullptr;
+  return o;
+}
+// affine / projective Montgomery conversion (icicle/include/icicle/curves/montgomery_conversion.h:21-52)
+static eIcicleError hip_affine_convert(const Device& device, const affine_t* input, size_t n, bool is_into, const VecOpsConfig& config, affine_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_vec_ops_config_t c = translate(config);
+  return (eIcicleError)HIP_FN(affine_convert_montgomery)(input, n, is_into, &c, output);
+}
+static eIcicleError hip_projective_convert(const Device& device, const projective_t* input, size_t n, bool is_into, const VecOpsConfig& config, projective_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_vec_ops_config_t c = translate(config);
+  return (eIcicleError)HIP_FN(projective_convert_montgomery)(input, n, is_into, &c, output);
+}
+REGISTER_AFFINE_CONVERT_MONTGOMERY_BACKEND("HIP", hip_affine_convert);
+REGISTER_PROJECTIVE_CONVERT_MONTGOMERY_BACKEND("HIP", hip_projective_convert);
 
 REGISTER_MSM_BACKEND("HIP", hip_msm);
 REGISTER_MSM_PRE_COMPUTE_BASES_BACKEND("HIP", hip_msm_precompute);

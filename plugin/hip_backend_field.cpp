@@ -1,10 +1,13 @@
-// Reference-runtime plugin, part 3/3: NTT for one 31-bit field (compile once per field with
+// Reference-runtime plugin, part 3/3: per-field APIs. Every field (incl. the curves' scalar fields,
+// compile with -DHIP_PLUGIN_NO_NTT) gets scalar_convert_montgomery; the 31-bit fields also get NTT.
+// NTT for one 31-bit field (compile once per field with
 // -DFIELD_ID=<n> -DICICLE_FFI_PREFIX=<field> -DNTT=ON -DEXT_FIELD=ON, icicle/cmake/field.cmake:42-79).
 // Registers all four members of the NTT API family (a missing member makes the reference dispatcher
 // THROW through its extern "C" shim) plus the extension-field NTT, with the
 // signatures of icicle/include/icicle/backend/ntt_backend.h:13-93.
 #include <cstring>
 #include "icicle/backend/ntt_backend.h"
+#include "icicle/backend/vec_ops_backend.h"
 #include "icicle/fields/field_config.h"
 #include "icicle/utils/utils.h"
 #include "hip_c_api.h"
@@ -14,7 +17,20 @@ using namespace icicle;
 
 #define HIP_FN(name) CONCAT_EXPAND(CONCAT_EXPAND(icicle_hip, ICICLE_FFI_PREFIX), name)
 
-static_assert(sizeof(scalar_t) == 4, "this plugin covers the 31-bit NTT fields");
+static_assert(sizeof(VecOpsConfig) == sizeof(hip_vec_ops_config_t), "VecOpsConfig layout drifted");
+// scalar Montgomery conversion (icicle/include/icicle/backend/vec_ops_backend.h:144-151)
+static eIcicleError hip_scalar_convert(const Device& device, const scalar_t* input, uint64_t size, bool is_to_montgomery, const VecOpsConfig& config, scalar_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  hip_vec_ops_config_t c;
+  std::memcpy(&c, &config, sizeof(c));
+  c.ext = nullptr;
+  return (eIcicleError)HIP_FN(scalar_convert_montgomery)(input, size, is_to_montgomery, &c, output);
+}
+REGISTER_CONVERT_MONTGOMERY_BACKEND("HIP", hip_scalar_convert);
+
+#ifndef HIP_PLUGIN_NO_NTT
+static_assert(sizeof(scalar_t) == 4, "the NTT part of this plugin covers the 31-bit fields");
 static_assert(sizeof(NTTConfig<scalar_t>) == sizeof(hip_ntt_config_u32_t), "NTTConfig layout drifted");
 static_assert(sizeof(NTTInitDomainConfig) == sizeof(hip_ntt_init_domain_config_t), "NTTInitDomainConfig layout drifted");
 
@@ -66,3 +82,14 @@ REGISTER_NTT_RELEASE_DOMAIN_BACKEND("HIP", hip_ntt_release_domain);
 REGISTER_NTT_GET_ROU_FROM_DOMAIN_BACKEND("HIP", hip_get_rou_from_domain);
 REGISTER_NTT_BACKEND("HIP", hip_ntt);
 REGISTER_NTT_EXT_FIELD_BACKEND("HIP", hip_ext_ntt);
+
+static eIcicleError hip_ext_scalar_convert(const Device& device, const extension_t* input, uint64_t size, bool is_to_montgomery, const VecOpsConfig& config, extension_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  hip_vec_ops_config_t c;
+  std::memcpy(&c, &config, sizeof(c));
+  c.ext = nullptr;
+  return (eIcicleError)HIP_FN(extension_scalar_convert_montgomery)(input, size, is_to_montgomery, &c, output);
+}
+REGISTER_CONVERT_MONTGOMERY_EXT_FIELD_BACKEND("HIP", hip_ext_scalar_convert);
+#endif // HIP_PLUGIN_NO_NTT

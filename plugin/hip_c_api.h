@@ -29,7 +29,28 @@ typedef struct {
   void* ext;
 } hip_ntt_init_domain_config_t;
 
+typedef struct {
+  void* stream;
+  bool is_a_on_device, is_b_on_device, is_result_on_device, is_async;
+  int batch_size;
+  bool columns_batch;
+  void* ext;
+} hip_vec_ops_config_t; // == icicle_vec_ops_config_t == icicle::VecOpsConfig (32 bytes)
+
 int icicle_hip_set_device(int device_id);
+#define HIP_DECLARE_CONVERT(P)                                                                                         \
+  int icicle_hip_##P##_scalar_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
+HIP_DECLARE_CONVERT(bn254)
+HIP_DECLARE_CONVERT(bls12_381)
+HIP_DECLARE_CONVERT(babybear)
+HIP_DECLARE_CONVERT(koalabear)
+int icicle_hip_babybear_extension_scalar_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
+int icicle_hip_koalabear_extension_scalar_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
+#define HIP_DECLARE_POINT_CONVERT(C)                                                                                   \
+  int icicle_hip_##C##_affine_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);     \
+  int icicle_hip_##C##_projective_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
+HIP_DECLARE_POINT_CONVERT(bn254)
+HIP_DECLARE_POINT_CONVERT(bls12_381)
 #define HIP_DECLARE_CURVE(C)                                                                                           \
   int icicle_hip_##C##_msm(const void*, const void*, int, const hip_msm_config_t*, void*);                              \
   int icicle_hip_##C##_msm_precompute_bases(const void*, int, const hip_msm_config_t*, void*);

@@ -66,6 +66,21 @@ def main():
         for bidx in range(2):
             assert cobj.projective_eq(got[bidx], exp[bidx]) and cobj.is_on_curve(got[bidx])
 
+    # ---- the Rust MSM test flow through the reference frontend: scalars converted to Montgomery form ON
+    # the main device (wrappers/rust/icicle-core/src/msm/tests.rs:54-59), then msm with the flag set
+    C = pyref.BN254
+    n = 2000
+    bases = points_to_array(C, cached_points(C, n))
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    assert rt.set_device("HIP", 0) == 0
+    scm = ref.ref_convert_montgomery("bn254", "bn254_scalar_convert_montgomery", sc, n, True)
+    got = curve.msm(scm, bases, scalars_mont=True)
+    am = ref.ref_convert_montgomery("bn254", "bn254_affine_convert_montgomery", bases, n, True)
+    assert rt.set_device("CPU", 0) == 0
+    assert np.array_equal(scm, ref.ref_convert_montgomery("bn254", "bn254_scalar_convert_montgomery", sc, n, True))
+    assert np.array_equal(am, ref.ref_convert_montgomery("bn254", "bn254_affine_convert_montgomery", bases, n, True))
+    assert np.array_equal(curve.to_affine(got), curve.to_affine(curve.msm(sc, bases)))
+
     # ---- NTT: HIP (device buffers from the reference's icicle_malloc) vs CPU ----
     for fobj, F in ((field, pyref.BABYBEAR), (koala, pyref.KOALABEAR)):
         logn, batch = 14, 3

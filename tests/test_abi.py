@@ -10,20 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "icicle_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = set(re.findall(r"\b(?:icicle_error_t|const char\*|void|int|bool|icicle_config_extension_t\*)\s+(\w+)\s*\(", text))
-    names -= {"F##_ntt"}
-    macro = re.findall(r"icicle_error_t F##_(\w+)\(", text)
-    for f in re.findall(r"ICICLE_HIP_DECLARE_NTT_U32\((\w+)\)", text):
-        if f != "F":
-            names |= {f"{f}_{m}" for m in macro}
-    amacro = re.findall(r"icicle_error_t icicle_hip_##F##_(\w+)\(", text)
-    for f in re.findall(r"ICICLE_HIP_DECLARE_NTT_ALIASES\((\w+)\)", text):
-        if f != "F":
-            names |= {f"icicle_hip_{f}_{m}" for m in amacro}
-    names = {n for n in names if "##" not in n and n != "icicle_hip_"}
-    return sorted(n for n in names if not n.startswith("F##"))
+    """every function the header declares, after macro expansion by the C preprocessor"""
+    import subprocess
+
+    text = subprocess.check_output(["gcc", "-E", "-P", os.path.join(ROOT, "include", "icicle_hip.h")], text=True)
+    names = set(re.findall(r"\b(?:icicle_error_t|const char\s*\*|void|int|_Bool|icicle_config_extension_t\s*\*)\s+(\w+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

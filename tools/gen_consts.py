@@ -61,6 +61,8 @@ def gen_big(name, p, l32):
     s.append(f"  static constexpr uint32_t REFMONT_TO_CANON[{nl}] = {arr(limbs(c1, nl))}; // R/2^{32*l32}")
     c2 = R * R * pow(r32, -1, p) % p
     s.append(f"  static constexpr uint32_t REFMONT_TO_MONT[{nl}] = {arr(limbs(c2, nl))}; // R^2/2^{32*l32}")
+    c4 = r32 * R % p  # canonical x -> reference-Montgomery x*2^(32 l32): montmul(x, C) = x*C/R
+    s.append(f"  static constexpr uint32_t CANON_TO_REFMONT[{nl}] = {arr(limbs(c4, nl))}; // 2^{32*l32} * R mod p")
     c3 = r32 % p  # our-Montgomery x*R -> reference-Montgomery: montmul(xR, C) = x*C => C = 2^(32 l32)
     s.append(f"  static constexpr uint32_t MONT_TO_REFMONT[{nl}] = {arr(limbs(c3, nl))}; // 2^{32*l32} mod p")
     s.append("};")
