@@ -212,6 +212,30 @@ def main():
             out["ntt"]["roofline"]["traffic_unit"] = "GB per direction (3 pass launches; FETCH_SIZE corrected x1.12, profiles/r01_pmc_traffic.json)"
         N.release_domain("babybear")
 
+    # ---------------- N > 1 only: ONE large NTT split over the ranks (4-step, all-to-all over RCCL/xGMI) -----
+    if world > 1 and not args.no_ntt:
+        try:
+            slog = 26
+            N.init_domain("babybear", N.get_root_of_unity("babybear", 1 << slog))
+            gsp = torch.Generator(device=dev)
+            gsp.manual_seed(5 + rank)
+            chunk = torch.randint(0, 0x78000001, ((1 << slog) // world,), dtype=torch.int32, device=dev, generator=gsp)
+            fwd = D.ntt_distributed("babybear", chunk, slog, False, rank, world, dist)
+            back = D.ntt_distributed("babybear", fwd, slog, True, rank, world, dist)
+            ok = bool(torch.equal(back, chunk))
+            barrier_sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fwd = D.ntt_distributed("babybear", chunk, slog, False, rank, world, dist)
+            barrier_sync()
+            dts = max_over_ranks(time.perf_counter() - t0)
+            out["ntt_split"] = {"metric": f"babybear_single_ntt_2^{slog}_split_over_{world}_gpus_per_sec", "value": args.steps / dts,
+                                "unit": "NTT/s", "ms_per_step": dts / args.steps * 1e3, "roundtrip_ok": ok,
+                                "exchange": "3 x all_to_all_single (natural-order output), RCCL"}
+            N.release_domain("babybear")
+        except Exception as e:  # never lose the primary line to the secondary experiment
+            out["ntt_split"] = {"error": repr(e)}
+
     # ---------------- CPU baseline: the reference CPU backend on this box's host cores ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

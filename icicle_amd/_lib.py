@@ -135,7 +135,7 @@ NTT_FIELDS = ["babybear", "koalabear"]
 API_SYMBOLS = (
     [f"{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
     + [f"{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
-                                               "get_root_of_unity_from_domain", "extension_ntt")]
+                                               "get_root_of_unity_from_domain", "extension_ntt", "hip_twiddle_rows")]
     + ["icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device"]
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
@@ -190,6 +190,7 @@ for _f in NTT_FIELDS:
     getattr(lib, f"{_f}_ntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU32), ctypes.c_void_p]
     getattr(lib, f"{_f}_extension_ntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU32), ctypes.c_void_p]
     getattr(lib, f"{_f}_ntt_init_domain").argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(NTTInitDomainConfig)]
+    getattr(lib, f"{_f}_hip_twiddle_rows").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_bool, ctypes.c_void_p]
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
 for _n in API_SYMBOLS:

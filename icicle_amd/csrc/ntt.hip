@@ -424,6 +424,43 @@ namespace icicle_hip {
     }
   }
 
+  // data[r][c] *= w_N^(+-(row0 + r) * c): the inter-step twiddle of a 4-step transform whose two steps run
+  // on different GPUs (icicle_amd/dist.py ntt_distributed); w_N = tw[max/N]
+  template <class PR>
+  __global__ __launch_bounds__(256) void k_twiddle_rows(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t logn_total, uint32_t log_max, int inverse)
+  {
+    using S = SmallField<PR>;
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= rows * cols) return;
+    const uint64_t r = t / cols, c = t - r * cols;
+    const uint64_t nmask = ((uint64_t)1 << logn_total) - 1;
+    const uint64_t e = ((row0 + r) * c) & nmask; // exponent mod N
+    uint64_t idx = e << (log_max - logn_total);
+    const uint64_t max_mask = ((uint64_t)1 << log_max) - 1;
+    if (inverse) idx = (((uint64_t)1 << log_max) - idx) & max_mask;
+    data[t] = S::mul(data[t], tw[idx]);
+  }
+
+  template <class PR>
+  static icicle_error_t twiddle_rows_run(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t logn_total, bool inverse, hipStream_t st)
+  {
+    if (!data) return ICICLE_INVALID_POINTER;
+    ICICLE_TRY(bind_current_device());
+    NttDomain dom;
+    {
+      std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
+      auto it = DomainStore<PR>::map().find(current_device_id());
+      if (it == DomainStore<PR>::map().end() || !it->second.tw) return ICICLE_INVALID_ARGUMENT;
+      dom = it->second;
+    }
+    if ((int)logn_total > dom.log_max) return ICICLE_INVALID_ARGUMENT;
+    const uint64_t tot = rows * cols;
+    if (tot == 0) return ICICLE_SUCCESS;
+    k_twiddle_rows<PR><<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(data, dom.tw, rows, cols, row0, logn_total, (uint32_t)dom.log_max, inverse ? 1 : 0);
+    LAUNCH_CHECK("k_twiddle_rows", st);
+    return ICICLE_SUCCESS;
+  }
+
   // n == 1 and pure-copy helper with strides
   __global__ void k_copy_strided(const uint32_t* in, uint32_t* out, uint64_t count)
   {
@@ -791,6 +828,14 @@ using namespace icicle_hip;
   }
 
 // collision-free aliases for the reference-runtime plugin (see msm.hip)
+#define DEFINE_NTT_HELPERS(F)                                                                                          \
+  extern "C" icicle_error_t F##_hip_twiddle_rows(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t logn_total, bool inverse, icicleStreamHandle stream) \
+  {                                                                                                                    \
+    GUARDED(twiddle_rows_run<F##_params>(data, rows, cols, row0, logn_total, inverse, (hipStream_t)stream));           \
+  }
+DEFINE_NTT_HELPERS(babybear)
+DEFINE_NTT_HELPERS(koalabear)
+
 #define DEFINE_NTT_ALIASES(F)                                                                                          \
   extern "C" icicle_error_t icicle_hip_##F##_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u32_t* c, uint32_t* o) { GUARDED(ntt_run<F##_params>(i, n, d, c, o, 1)); } \
   extern "C" icicle_error_t icicle_hip_##F##_extension_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u32_t* c, uint32_t* o) { GUARDED(ntt_run<F##_params>(i, n, d, c, o, 4)); } \

@@ -64,6 +64,81 @@ def ntt_batch_shard(batch: int, rank: int, world: int):
     return shard_range(batch, rank, world)
 
 
+def _exchange_transpose(mat, world, dist):
+    """mat: [R_local, C] with C divisible by world; rows are this rank's slice of a [R, C] matrix distributed
+    by rows. Returns the [C/world, R] slice of the TRANSPOSE (row index = global column, in this rank's
+    column slice). One all_to_all_single: every rank talks to all peers at once, which on xGMI's
+    point-to-point links uses all 7 links instead of a ring's one."""
+    import torch
+
+    rl, c = mat.shape
+    cl = c // world
+    send = mat.reshape(rl, world, cl).permute(1, 0, 2).contiguous()  # [world][rl][cl]
+    if world > 1:
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv.reshape(-1), send.reshape(-1))
+    else:
+        recv = send
+    return recv.permute(2, 0, 1).reshape(cl, world * rl).contiguous()
+
+
+def ntt_distributed(field: str, chunk, logn: int, inverse: bool, rank: int, world: int, dist, natural_output: bool = True, compute=None):
+    """ONE transform of size N = 2^logn whose input is distributed over `world` ranks in contiguous natural-order
+    chunks (`chunk`: torch int32 [N/world]). 4-step (Bailey): N = N1*N2, j = j1*N2 + j2, k = k1 + N1*k2
+      exchange  -> columns j2 on this rank        (all-to-all #1)
+      N1-point NTTs over j1, twiddle w_N^(j2*k1)
+      exchange  -> rows k1 on this rank           (all-to-all #2)
+      N2-point NTTs over j2                       -> X[k1 + N1*k2] at [k1][k2]  ("mixed" order, kNM)
+      exchange  -> natural chunks                 (all-to-all #3, only if natural_output)
+    The NTT domain of `field` must be initialised with a root of order >= N on every rank.
+    `compute` = (local_ntt(mat2d, inverse) -> mat2d, twiddle(mat2d, row0, logn, inverse) -> mat2d) lets the CPU
+    gloo test inject the oracle; default = this backend on the current GPU."""
+    import torch
+
+    n = 1 << logn
+    log_w = world.bit_length() - 1
+    assert world == 1 << log_w and chunk.numel() == n // world
+    a = max((logn + 1) // 2, log_w)
+    b = logn - a
+    assert b >= log_w, "transform too small for this many ranks"
+    n1, n2 = 1 << a, 1 << b
+    if compute is None:
+        compute = _gpu_compute(field)
+    local_ntt, twiddle = compute
+    l0 = chunk.reshape(n1 // world, n2)
+    t1 = _exchange_transpose(l0, world, dist)             # [n2/world][n1], row = global j2
+    y = local_ntt(t1, inverse)                            # over j1 -> k1
+    y = twiddle(y, rank * (n2 // world), logn, inverse)   # *= w_N^(+-j2*k1)
+    t2 = _exchange_transpose(y, world, dist)              # [n1/world][n2], row = global k1
+    z = local_ntt(t2, inverse)                            # over j2 -> k2 : X[k1 + n1*k2]
+    if not natural_output:
+        return z.reshape(-1)
+    return _exchange_transpose(z, world, dist).reshape(-1)  # [n2/world][n1]: k = k1 + n1*k2 natural
+
+
+def _gpu_compute(field: str):
+    import ctypes
+    import torch
+    from . import ntt as N
+    from ._lib import NTTConfigU32, lib, check
+
+    def local_ntt(mat, inverse):
+        rows, size = mat.shape
+        out = torch.empty_like(mat)
+        cfg = NTTConfigU32.default()
+        cfg.batch_size = rows
+        cfg.is_async = True
+        N.ntt(field, mat.data_ptr(), N.INVERSE if inverse else N.FORWARD, cfg, out=out.data_ptr(), size=size)
+        return out
+
+    def twiddle(mat, row0, logn, inverse):
+        rows, cols = mat.shape
+        check(getattr(lib, f"{field}_hip_twiddle_rows")(mat.data_ptr(), rows, cols, row0, logn, inverse, None), "twiddle_rows")
+        return mat
+
+    return local_ntt, twiddle
+
+
 def combine_partials_host(curve: str, partials: np.ndarray):
     """Host-side definition of the combine step (used by the gloo CPU tests): sum of projective
     partials via the pure-Python oracle. partials: [world, 3*L] uint32."""

@@ -203,6 +203,10 @@ icicle_error_t bls12_381_hip_generate_affine_points(void* out, int n, uint64_t k
  * base-sharded multi-GPU MSM after the RCCL all-gather of per-GPU partial results. */
 icicle_error_t bn254_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);
 icicle_error_t bls12_381_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);
+/* data[r][c] *= w_N^(+-(row0+r)*c) on device (N = 2^logn_total, w_N from the initialised domain): the inter-step
+ * twiddle of a 4-step NTT whose two steps run on different GPUs (icicle_amd/dist.py, all-to-all over RCCL). */
+icicle_error_t babybear_hip_twiddle_rows(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t logn_total, bool inverse, icicleStreamHandle stream);
+icicle_error_t koalabear_hip_twiddle_rows(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t logn_total, bool inverse, icicleStreamHandle stream);
 /* Average device time (ms) of the dominant kernel's launches since the last reset, measured with
  * hipEvents on the launch stream (bench.py's live roofline figure). which: 0 = MSM bucket
  * accumulation, 1 = NTT pass kernels. */

@@ -130,3 +130,19 @@ def test_ntt_roundtrip_large(env, hip):
     assert np.array_equal(fs, ((fa.astype(np.uint64) + fb) % F.p).astype(np.uint32))
     # one row checked against the reference
     assert np.array_equal(fa[:n], rf.ntt(a[:n], n, 0))
+
+
+def test_distributed_ntt_single_rank_path(env, hip):
+    """world_size 1 run of the multi-GPU 4-step transform (local transposes instead of all-to-all): exercises
+    the twiddle helper and the two local batched NTTs on the GPU against the plain single-call transform."""
+    import torch
+    from icicle_amd import dist as D
+
+    fname, F, rf, N = env
+    rng = np.random.default_rng(21)
+    for logn, inverse in ((12, False), (15, True), (18, False)):
+        n = 1 << logn
+        x = rng.integers(0, F.p, size=n, dtype=np.uint32)
+        chunk = torch.from_numpy(x.view(np.int32).copy()).cuda()
+        got = D.ntt_distributed(fname, chunk, logn, inverse, 0, 1, None).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, N.ntt(fname, x, N.INVERSE if inverse else N.FORWARD))
