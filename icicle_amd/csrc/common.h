@@ -139,40 +139,6 @@ namespace icicle_hip {
     hipStream_t m_stream = nullptr;
   };
 
-  // A leased second stream plus events (cached per device): lets one API call overlap two of its
-  // own stages without creating/destroying streams per call.
-  struct AuxRes {
-    int device = 0;
-    bool busy = false;
-    hipStream_t stream = nullptr;
-    hipEvent_t start = nullptr;
-    std::vector<hipEvent_t> ev;
-  };
-  AuxRes* aux_acquire(int nevents);
-  void aux_release(AuxRes* r);
-  class AuxStream
-  {
-  public:
-    AuxStream() = default;
-    AuxStream(const AuxStream&) = delete;
-    AuxStream& operator=(const AuxStream&) = delete;
-    ~AuxStream()
-    {
-      if (m_r) aux_release(m_r);
-    }
-    hipError_t acquire(int nevents)
-    {
-      m_r = aux_acquire(nevents);
-      return m_r ? hipSuccess : hipErrorOutOfMemory;
-    }
-    hipStream_t stream() const { return m_r->stream; }
-    hipEvent_t ev_start() const { return m_r->start; }
-    hipEvent_t ev_sorted(int g) const { return m_r->ev[g]; }
-
-  private:
-    AuxRes* m_r = nullptr;
-  };
-
   // ---- dominant-kernel timing with hipEvents on the launch stream (bench.py roofline figure) ----
   struct KernelTimer {
     static bool enabled();

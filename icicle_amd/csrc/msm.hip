@@ -5,19 +5,24 @@
 // The CPU backend gives each worker private buckets and random-access RMWs into them; on MI355X
 // the same sum is reorganised so that the only random access left is a read-only gather:
 //
-//   1. bases -> packed Montgomery copy in HBM (one pass, 2 field muls per point)
-//   2. scalars -> signed c-bit digits, one u32 per (window, scalar), coalesced writes
-//   3. per window: counting sort of point indices by bucket. Histogram and cursors live in LDS
-//      (2^(c-1) u32 counters = 128 KiB at c = 16, of gfx950's 160 KiB/CU); ds_add_rtn runs at
-//      ~550 G atomics/s chip-wide vs ~27 G/s for global atomics (profiles/r01_alu_ubench.txt).
-//   4. bucket accumulation: ONE THREAD PER BUCKET walks its sorted index list, gathers the 64 B
-//      affine point and does an XYZZ mixed add entirely in registers -- >95 % of all time;
-//      integer-ALU bound (v_mad_u64_u32), see DESIGN.md.
-//   5. bucket reduction: per-segment running sums (complete projective adds), wave-level tree,
-//      Horner over windows.
+//   1. k_bases_to_mont   bases -> packed Montgomery copy in HBM (one pass, 2 field muls per point)
+//   2. k_digits          scalars -> signed c-bit digits, one u32 per (window, scalar), coalesced
+//   3. two-level counting sort of point indices by bucket, every scatter staged through an LDS
+//      tile-sort so that HBM sees runs, not 4-byte random writes:
+//        pass A  k_a_count / k_scan_a / k_a_scatter     partition by the high hb bits of the key
+//        pass B  k_b_plan / k_b_count / k_scan_buckets / k_b_scatter   sort by the low lb bits
+//      (c <= 11: pass A alone sorts by the whole key, k_a_scatter<true> + k_tables_from_a)
+//   4. k_accumulate      ONE THREAD PER BUCKET walks its sorted index list, gathers the 64 B affine
+//      point and does an XYZZ mixed add entirely in registers -- ~77 % of the time at 2^26,
+//      integer-ALU bound (v_mad_u64_u32), see DESIGN.md. Buckets longer than `seg` points are
+//      split (k_plan_overflow) and their partial sums folded back in parallel (k_fold_overflow).
+//   5. bucket reduction: k_reduce_segments (running sums per segment) -> k_reduce_window (256
+//      lanes per window) -> k_final (128 lanes per MSM, Horner over windows).
+// A batch of MSMs is folded into the window dimension: all of the above is launched once for up
+// to BB MSMs x wpf windows.
 //
-// Everything is enqueued on config.stream with stream-ordered temporaries; the host only blocks
-// when the API contract requires it (is_async == false or results on host).
+// Everything is enqueued on config.stream with arena-leased temporaries (common.h TempBuf); the
+// host only blocks when the API contract requires it (is_async == false or results on host).
 #include "common.h"
 #include "ec.cuh"
 #include <algorithm>
@@ -94,14 +99,16 @@ namespace icicle_hip {
   //
   // A single-level scatter into 2^(c-1) bucket lists writes 4 bytes to a random one of 32768 open
   // cache lines per element -- measured 29 ms of the first version's 144 ms (profiles/
-  // r01_v1_kernel_stats.txt), almost all write amplification. Two levels keep the number of open
-  // destinations per block small enough for L2 to assemble full lines:
-  //   pass A: scalars -> digits on the fly (no digit array in HBM) -> partition by the HIGH hb bits
-  //           of the bucket key; block b owns scalars [b*chunk, (b+1)*chunk); LDS holds the
-  //           wpf * 2^hb counters / cursors. Element = sign | low key bits | j | index within chunk.
-  //   pass B: one block per (window, partition): counting sort by the LOW lb key bits in LDS; the
-  //           source block of an element (needed to rebuild its global scalar index) is found by a
-  //           binary search in the partition's per-block offset row, staged in LDS.
+  // r01_v1_kernel_stats.txt), almost all write amplification (8.6x, profiles/r01_notes.md). Here
+  // every block first sorts its tile in LDS and then writes each bin's run contiguously:
+  //   k_digits: one pass over the scalars, digit array dig[window][scalar] in HBM (4 B each).
+  //   pass A:   block (b, window) owns digits [b*chunk, (b+1)*chunk) of that window and partitions
+  //             them by the HIGH hb bits of the bucket key. Element = sign | low key bits | j |
+  //             index within chunk.
+  //   pass B:   blocks own sub-chunks (<= 2^17 elements) of one (window, partition) and sort them
+  //             by the LOW lb key bits; each (tile, bin) run reserves its slot in the bucket with
+  //             one global atomic. The source block of an element (needed to rebuild its global
+  //             scalar index) is found by a binary search in the partition's per-block offset row.
   // Output is what bucket accumulation consumes: count[], offs[], sorted[] (point index | sign<<31).
   struct SortPlan {
     int hb, lb;       // high / low bucket-key bits, hb + lb = c - 1
@@ -699,7 +706,7 @@ namespace icicle_hip {
   //     sum by c*w doublings (the same critical path as a serial Horner, but the doublings of
   //     different windows overlap), then a tree through LDS. <1 % of the work.
   //     (A <<<1,1>>> serial Horner is provably wave-uniform, so hipcc compiles ALL of its field
-  //     arithmetic to SALU code; that variant returned wrong results on gfx950 for some shapes.)
+  //     arithmetic to SALU code, which is several times slower per multiply than the VALU path.)
   template <class C>
   __global__ __launch_bounds__(128) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c)
   {

@@ -158,50 +158,6 @@ namespace icicle_hip {
     }
   }
 
-  // ---- leased auxiliary streams ----------------------------------------------------------------
-  static std::mutex g_aux_mtx;
-  static std::vector<AuxRes*>& aux_pool()
-  {
-    static std::vector<AuxRes*> v;
-    return v;
-  }
-  AuxRes* aux_acquire(int nevents)
-  {
-    const int dev = current_device_id();
-    std::lock_guard<std::mutex> g(g_aux_mtx);
-    AuxRes* r = nullptr;
-    for (AuxRes* a : aux_pool())
-      if (!a->busy && a->device == dev) {
-        r = a;
-        break;
-      }
-    if (!r) {
-      r = new AuxRes();
-      r->device = dev;
-      if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->start, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        delete r;
-        return nullptr;
-      }
-      aux_pool().push_back(r);
-    }
-    while ((int)r->ev.size() < nevents) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-      }
-      r->ev.push_back(e);
-    }
-    r->busy = true;
-    return r;
-  }
-  void aux_release(AuxRes* r)
-  {
-    std::lock_guard<std::mutex> g(g_aux_mtx);
-    r->busy = false;
-  }
-
   // ---- kernel timing ---------------------------------------------------------------------------
   static std::atomic<bool> g_timing{false};
   struct TimedSpan {

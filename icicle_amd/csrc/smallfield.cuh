@@ -42,16 +42,6 @@ namespace icicle_hip {
       return umin(r, r + P);
     }
     static SF_HD uint32_t mul(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }
-    // Multiplication by a precomputed constant (twiddle) w given with wt = w * p^-1 mod 2^32:
-    // m = lo(a*w) * p^-1 = lo(a * wt), so the low product disappears: mul_hi, mul_lo, mul_hi, sub, fix.
-    static SF_HD uint32_t twiddle_aux(uint32_t w) { return w * PR::PINV; }
-    static SF_HD uint32_t mul_tw(uint32_t a, uint32_t w, uint32_t wt)
-    {
-      uint32_t m = a * wt;
-      uint32_t u = (uint32_t)(((uint64_t)m * P) >> 32);
-      uint32_t r = (uint32_t)(((uint64_t)a * w) >> 32) - u;
-      return umin(r, r + P);
-    }
     static SF_HD uint32_t to_mont(uint32_t x) { return mul(x, PR::R2); }
     static SF_HD uint32_t from_mont(uint32_t x) { return mont_reduce((uint64_t)x); }
     static SF_HD uint32_t one() { return PR::ONE; }
