@@ -83,6 +83,30 @@ class NTTConfigU32(ctypes.Structure):
         return cls(None, 1, 1, False, 0, False, False, False, None)
 
 
+class NTTConfigU256(ctypes.Structure):
+    """icicle::NTTConfig<S> for the curves' 32-byte scalar_t (include/icicle/ntt.h:53-64), 64 bytes."""
+    _fields_ = [
+        ("stream", ctypes.c_void_p),
+        ("coset_gen", ctypes.c_uint32 * 8),
+        ("batch_size", ctypes.c_int),
+        ("columns_batch", ctypes.c_bool),
+        ("ordering", ctypes.c_int),
+        ("are_inputs_on_device", ctypes.c_bool),
+        ("are_outputs_on_device", ctypes.c_bool),
+        ("is_async", ctypes.c_bool),
+        ("ext", ctypes.c_void_p),
+    ]
+
+    @classmethod
+    def default(cls):
+        one = (ctypes.c_uint32 * 8)(1, 0, 0, 0, 0, 0, 0, 0)
+        return cls(None, one, 1, False, 0, False, False, False, None)
+
+    def set_coset_gen(self, g: int):
+        for i in range(8):
+            self.coset_gen[i] = (g >> (32 * i)) & 0xFFFFFFFF
+
+
 class VecOpsConfig(ctypes.Structure):
     """icicle::VecOpsConfig (include/icicle/vec_ops.h:19-37), 32 bytes."""
     _fields_ = [
@@ -113,6 +137,8 @@ assert ctypes.sizeof(Device) == 68 and Device.id.offset == 64
 assert ctypes.sizeof(MSMConfig) == 40 and MSMConfig.ext.offset == 32
 assert ctypes.sizeof(NTTConfigU32) == 40 and NTTConfigU32.ordering.offset == 20
 assert ctypes.sizeof(NTTInitDomainConfig) == 24
+assert ctypes.sizeof(NTTConfigU256) == 64 and NTTConfigU256.batch_size.offset == 40 and NTTConfigU256.ordering.offset == 48
+assert NTTConfigU256.ext.offset == 56
 assert ctypes.sizeof(VecOpsConfig) == 32 and VecOpsConfig.batch_size.offset == 12 and VecOpsConfig.ext.offset == 24
 
 # every symbol include/icicle_hip.h declares (tests/test_abi.py checks the header against this)
@@ -132,10 +158,15 @@ RUNTIME_SYMBOLS = [
 ]
 CURVES = ["bn254", "bls12_381"]
 NTT_FIELDS = ["babybear", "koalabear"]
+SCALAR_NTT_FIELDS = ["bn254", "bls12_381"]  # NTT over the curve's scalar field, 8-word elements
 API_SYMBOLS = (
     [f"{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
     + [f"{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
                                                "get_root_of_unity_from_domain", "extension_ntt", "hip_twiddle_rows")]
+    + [f"{f}_{s}" for f in SCALAR_NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
+                                                      "get_root_of_unity_from_domain")]
+    + [f"icicle_hip_{f}_{s}" for f in SCALAR_NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain",
+                                                                 "get_root_of_unity_from_domain")]
     + ["icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device"]
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
@@ -193,6 +224,11 @@ for _f in NTT_FIELDS:
     getattr(lib, f"{_f}_hip_twiddle_rows").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_bool, ctypes.c_void_p]
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
+for _f in SCALAR_NTT_FIELDS:
+    getattr(lib, f"{_f}_ntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU256), ctypes.c_void_p]
+    getattr(lib, f"{_f}_ntt_init_domain").argtypes = [ctypes.c_void_p, ctypes.POINTER(NTTInitDomainConfig)]
+    getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+    getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
 for _n in API_SYMBOLS:
     if _n.endswith("convert_montgomery"):
         getattr(lib, _n).argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_bool, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]

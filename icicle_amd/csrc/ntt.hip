@@ -14,6 +14,7 @@
 // twiddles are stored in Montgomery form, and montmul(canonical, w*R) = canonical.
 #include "common.h"
 #include "smallfield.cuh"
+#include "ntt_plan.h"
 #include <algorithm>
 #include <cmath>
 
@@ -45,47 +46,6 @@ namespace icicle_hip {
     using S = SmallField<PR>;
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) tw[i] = S::pow(root_mont, (uint64_t)i);
-  }
-
-  // ---- pass descriptor -------------------------------------------------------------------------
-  struct PassDesc {
-    int s;            // log2 of the sub-transform length L
-    int T;            // tile width (columns per block)
-    uint32_t ntiles;  // tiles per row-transform
-    // tile -> (a, c0): tile index = a * tiles_per_a + ct ;
-    uint32_t tiles_per_a;
-    // load/store addressing inside one logical row: addr = base + k*sk + t*st
-    uint64_t in_base_a, in_base_ct, in_sk, in_st;     // base = a*in_base_a + ct*in_base_ct
-    uint64_t out_sk, out_st;                          // out base computed in-kernel (needs digit reversal)
-    int is_last;      // last pass: natural-order scatter + optional 1/N scaling
-    int pidx;         // pass index
-    // twiddle after this pass (not last): exponent = jnext * K, table stride tstride
-    uint64_t tw_stride;  // max / M
-    uint32_t cprime;     // C' = C / N_{p+1}; jnext = (c0 + t) / C'
-    uint32_t n0, n1;     // N_0, N_1 (for K and digit reversal)
-  };
-
-  struct NttLaunch {
-    uint32_t logn;
-    uint64_t n;
-    uint32_t nbatch;   // number of independent lane-transforms (batch * lanes)
-    uint32_t lanes;    // 1 (scalar) or 4 (quartic extension)
-    uint64_t bs;       // offset(b') = (b'/lanes)*bs + (b'%lanes)
-    uint64_t es;       // element stride
-    int in_rev, out_rev; // bit-reversed logical->memory maps
-    int inverse;
-    uint32_t log_max;
-    uint32_t ninv_mont;  // N^-1 (Montgomery) for inverse
-    int coset;           // multiply by powers table (forward: on first load; inverse: on last store)
-    // row-group execution (fast path): this launch covers rows [row0, row0 + nrows_launch); a buffer
-    // flagged "relative" holds only the current group (its row r lives at offset of row r - row0)
-    uint32_t row0 = 0, nrows_launch = 0;
-    int src_rel = 0, dst_rel = 0;
-  };
-
-  __device__ __forceinline__ uint64_t bitrev64(uint64_t x, uint32_t bits)
-  {
-    return bits == 0 ? 0 : (__brevll(x) >> (64 - bits));
   }
 
   // ---- generic pass (any ordering / coset): one radix-2 stage per LDS round trip ---------------
@@ -553,16 +513,6 @@ namespace icicle_hip {
     return ICICLE_SUCCESS;
   }
 
-  static void split_logn(int logn, int* parts, int* np)
-  {
-    // <= 3 passes; 2^8-point sub-transforms (2 register rounds) up to 2^24, larger ones above
-    const int SMAX = std::max(8, (logn + 2) / 3);
-    const int P = std::max(1, (logn + SMAX - 1) / SMAX);
-    for (int i = 0; i < P; i++)
-      parts[i] = logn / P + (i < logn % P ? 1 : 0);
-    *np = P;
-  }
-
   template <class PR>
   using pass_fn_t = void (*)(const uint32_t*, uint32_t*, const uint32_t*, PassDesc, NttLaunch, uint32_t);
 
@@ -681,7 +631,7 @@ namespace icicle_hip {
       return ICICLE_SUCCESS;
     }
     int parts[3], P;
-    split_logn(logn, parts, &P);
+    split_logn(logn, 8, parts, &P);
     // P >= 2: passes 0..P-2 run in a work buffer (the last pass permutes across tiles, so it can
     // never be in place; this also makes input == output legal, test_mod_arithmetic_api.h:627,679)
     TempBuf d_work;
@@ -716,51 +666,13 @@ namespace icicle_hip {
       uint32_t* dst = (p == P - 1) ? d_out : W;
       nl.src_rel = (grouped && p != 0) ? 1 : 0;
       nl.dst_rel = (grouped && p != P - 1) ? 1 : 0;
-      PassDesc pd{};
-      pd.s = parts[p];
-      pd.pidx = p;
-      pd.is_last = (p == P - 1);
-      const uint64_t L = (uint64_t)1 << pd.s;
-      uint64_t A = 1, C = 1;
-      for (int q = 0; q < p; q++)
-        A <<= parts[q];
-      for (int q = p + 1; q < P; q++)
-        C <<= parts[q];
-      pd.n0 = 1u << parts[0];
-      pd.n1 = P > 1 ? (1u << parts[1]) : 1;
+      const uint64_t L = (uint64_t)1 << parts[p];
       // fast path: block = T * L/16 threads (<= 512), LDS = 2 buffers of L*(T+1) words (<= 160 KiB)
       const uint64_t epb = L >= 16 ? 16 : L;
       uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, 512 * epb / L));
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
         tmax >>= 1;
-      if (!pd.is_last) {
-        pd.T = (int)std::min<uint64_t>(tmax, C);
-        pd.tiles_per_a = (uint32_t)(C / pd.T);
-        pd.ntiles = (uint32_t)(A * pd.tiles_per_a);
-        pd.in_base_a = L * C;
-        pd.in_base_ct = pd.T;
-        pd.in_sk = C;
-        pd.in_st = 1;
-        int lm = 0; // M = N_0..N_{p+1}
-        for (int q = 0; q <= p + 1; q++)
-          lm += parts[q];
-        pd.tw_stride = (uint64_t)1 << (dom.log_max - lm);
-        pd.cprime = (uint32_t)(C >> parts[p + 1]);
-      } else {
-        // tile over k0 (the slowest digit of a); for P==3 `a` in the kernel carries k1
-        const uint64_t n0 = P >= 2 ? ((uint64_t)1 << parts[0]) : 1;
-        const uint64_t n1 = P == 3 ? ((uint64_t)1 << parts[1]) : 1;
-        pd.T = (int)std::min<uint64_t>(tmax, n0);
-        pd.tiles_per_a = (uint32_t)(n0 / pd.T);
-        pd.ntiles = (uint32_t)(n1 * pd.tiles_per_a);
-        // row index = k0*n1 + k1 ; row start = row*L
-        pd.in_base_a = L;               // a = k1
-        pd.in_base_ct = (uint64_t)pd.T * n1 * L;
-        pd.in_sk = 1;
-        pd.in_st = n1 * L;
-        pd.out_sk = n >> pd.s;
-        pd.out_st = 1;
-      }
+      const PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
       if (fast) {
         const unsigned threads = (unsigned)(pd.T * (L / epb));
         const size_t lds_bytes = (size_t)2 * L * (pd.T + 1) * 4;

@@ -1,0 +1,521 @@
+// NTT for gfx950 over the 256-bit scalar fields of the curves (BN254 Fr, BLS12-381 Fr).
+//
+// Reference semantics are those of ntt.hip (icicle/backend/cpu/include/ntt_cpu.h:70-364,
+// cpu_ntt_domain.h:65-110,614-654, src/ntt.cpp:11-84); only the element type differs: scalar_t is
+// 8 little-endian u32 words, NTTConfig<scalar_t> is 64 bytes (coset_gen is a whole element).
+//
+// Same pass decomposition as the 31-bit NTT (ntt_plan.h): <= 3 passes of 2^s-point sub-transforms
+// on [L x T] tiles held in LDS, inter-pass twiddle on the way out, natural-order scatter in the
+// last pass. What changes with 32-byte elements:
+//   * a run of T = 4 elements is already a 128 B HBM transaction, so tiles are narrow and tall;
+//   * the tile lives in LDS as 9 x 29-bit limbs per element (36 B, odd word stride) so the
+//     butterflies use bigfield.cuh's lazy arithmetic without re-packing between stages;
+//   * a butterfly is one 9-limb Montgomery product (~230 VALU ops): the pass is ALU-bound, not
+//     HBM-bound (2^24 elements: ~1.5 GB of traffic per direction vs ~6e10 lane-ops).
+// Data stays in the caller's (canonical or Montgomery) form: twiddles are kept in Montgomery form
+// and montmul(x, w*R) = x*w. Lazy bounds (units of p): loads 1.2, 3.2 and 7.2 after the two
+// product-free stages, +2 per later stage, <= 23.2 after ten stages (limit 64, reduce() accepts
+// < 32), back to canonical on every store.
+#include "common.h"
+#include "bigfield.cuh"
+#include "ntt_plan.h"
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+namespace icicle_hip {
+
+  template <class PR>
+  struct BigNtt {
+    using F = FieldOps<PR>;
+    using fe = typename F::fe;
+    static constexpr int W = F::N32; // words per element in memory
+
+    static HD fe load_words(const uint32_t* w) { return F::unpack(w); }
+    static HD fe pow_u64(fe base, uint64_t e)
+    { // base Montgomery, result Montgomery (canonical limbs not required)
+      fe r = F::one();
+      bool started = false;
+      for (int bit = 63; bit >= 0; bit--) {
+        if (started) r = F::sqr(r);
+        if ((e >> bit) & 1) {
+          r = started ? F::mul(r, base) : base;
+          started = true;
+        }
+      }
+      return r;
+    }
+    static HD fe pow_words(fe base, const uint32_t* e, int nwords)
+    {
+      fe r = F::one();
+      bool started = false;
+      for (int bit = nwords * 32 - 1; bit >= 0; bit--) {
+        if (started) r = F::sqr(r);
+        if ((e[bit >> 5] >> (bit & 31)) & 1) {
+          r = started ? F::mul(r, base) : base;
+          started = true;
+        }
+      }
+      return r;
+    }
+    static HD void store_packed(uint32_t* w, const fe& a) { F::pack(w, F::reduce(a)); }
+  };
+
+  struct BigDomain {
+    uint32_t* tw = nullptr; // tw[i*8 .. i*8+7] = packed Montgomery w_max^i, i < max_size
+    int log_max = -1;
+    uint32_t root[8] = {0}; // canonical w_max
+  };
+  template <class PR>
+  struct BigDomainStore {
+    static std::mutex& mtx()
+    {
+      static std::mutex m;
+      return m;
+    }
+    static std::map<int, BigDomain>& map()
+    {
+      static std::map<int, BigDomain> m;
+      return m;
+    }
+  };
+
+  struct BigWords {
+    uint32_t w[8];
+  };
+
+  // tw[i] = root^i. Thread t fills 64 consecutive entries from one pow().
+  template <class PR>
+  __global__ __launch_bounds__(256) void k_big_gen_twiddles(uint32_t* __restrict__ tw, BigWords root_mont, size_t n)
+  {
+    using B = BigNtt<PR>;
+    using F = typename B::F;
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t i0 = t * 64;
+    if (i0 >= n) return;
+    const typename B::fe r = F::unpack(root_mont.w);
+    typename B::fe x = B::pow_u64(r, (uint64_t)i0);
+    for (size_t i = i0; i < i0 + 64 && i < n; i++) {
+      B::store_packed(tw + i * 8, x);
+      x = F::mul(x, r);
+    }
+  }
+
+  // pw[i] = g^i (packed Montgomery), i < n
+  template <class PR>
+  __global__ __launch_bounds__(256) void k_big_coset_powers(uint32_t* __restrict__ pw, BigWords g_mont, uint64_t n)
+  {
+    using B = BigNtt<PR>;
+    using F = typename B::F;
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t i0 = t * 16;
+    if (i0 >= n) return;
+    const typename B::fe g = F::unpack(g_mont.w);
+    typename B::fe x = B::pow_u64(g, i0);
+    for (uint64_t i = i0; i < i0 + 16 && i < n; i++) {
+      B::store_packed(pw + i * 8, x);
+      x = F::mul(x, g);
+    }
+  }
+
+  __device__ __forceinline__ void load8(uint32_t* dst, const uint32_t* __restrict__ src)
+  {
+    const uint4 a = ((const uint4*)src)[0], b = ((const uint4*)src)[1];
+    dst[0] = a.x, dst[1] = a.y, dst[2] = a.z, dst[3] = a.w;
+    dst[4] = b.x, dst[5] = b.y, dst[6] = b.z, dst[7] = b.w;
+  }
+  __device__ __forceinline__ void store8(uint32_t* __restrict__ dst, const uint32_t* src)
+  {
+    ((uint4*)dst)[0] = make_uint4(src[0], src[1], src[2], src[3]);
+    ((uint4*)dst)[1] = make_uint4(src[4], src[5], src[6], src[7]);
+  }
+
+  // One pass: grid = (ntiles, batch). Dynamic LDS: L*T elements of 9 limbs.
+  // Handles every ordering, cosets, both directions and both batch layouts.
+  template <class PR>
+  __global__ __launch_bounds__(512) void k_big_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ coset_pow, PassDesc pd, NttLaunch nl, BigWords ninv_mont)
+  {
+    using B = BigNtt<PR>;
+    using F = typename B::F;
+    using fe = typename B::fe;
+    extern __shared__ uint32_t lds_raw[];
+    fe* tile = reinterpret_cast<fe*>(lds_raw);
+    const uint32_t L = 1u << pd.s, T = pd.T;
+    const uint64_t boff = (uint64_t)blockIdx.y * nl.bs;
+    const uint32_t a = blockIdx.x / pd.tiles_per_a, ct = blockIdx.x % pd.tiles_per_a;
+    const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
+    const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
+    const uint32_t tot = L * T;
+    uint32_t wbuf[8];
+
+    auto tw_load = [&](uint64_t idx) -> fe {
+      idx &= max_mask;
+      if (nl.inverse) idx = (((uint64_t)1 << nl.log_max) - idx) & max_mask;
+      uint32_t w[8];
+      load8(w, tw + idx * 8);
+      return F::unpack(w);
+    };
+
+    // ---- load: logical (k,t) -> LDS row bitrev_s(k)
+    for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+      const uint32_t t = e % T, k = e / T;
+      const uint64_t addr = in_base + (uint64_t)k * pd.in_sk + (uint64_t)t * pd.in_st;
+      const uint64_t maddr = (nl.in_rev && pd.pidx == 0) ? bitrev64(addr, nl.logn) : addr;
+      load8(wbuf, in + (boff + maddr * nl.es) * 8);
+      fe v = F::unpack(wbuf);
+      if (nl.coset && !nl.inverse && pd.pidx == 0) {
+        uint32_t cw[8];
+        load8(cw, coset_pow + addr * 8);
+        v = F::mul(v, F::unpack(cw));
+      }
+      tile[(pd.s == 0 ? 0u : (__brev(k) >> (32 - pd.s))) * T + t] = v;
+    }
+    __syncthreads();
+
+    // ---- s radix-2 DIT stages in LDS; w_L^e = tw[e * (max/L)]
+    const uint32_t lstride_log = nl.log_max - pd.s;
+    for (int q = 0; q < pd.s; q++) {
+      const uint32_t half = 1u << q;
+      for (uint32_t id = threadIdx.x; id < tot / 2; id += blockDim.x) {
+        const uint32_t t = id % T, bf = id / T;
+        const uint32_t pos = bf & (half - 1);
+        const uint32_t i = ((bf >> q) << (q + 1)) + pos;
+        const fe u = tile[i * T + t];
+        fe v = tile[(i + half) * T + t];
+        // stage 0 has only the trivial twiddle, stage 1 has it on half of the butterflies: skip those
+        // products while the operands are still small (bounds 1.2 -> 3.2 -> 7.2, then +2 per stage)
+        if (q >= 2 || (q == 1 && pos != 0)) v = F::mul(v, tw_load(((uint64_t)pos << (pd.s - 1 - q)) << lstride_log));
+        tile[i * T + t] = F::add(u, v);
+        tile[(i + half) * T + t] = (q == 1) ? F::template sub<4>(u, v) : F::template sub<2>(u, v);
+      }
+      __syncthreads();
+    }
+
+    // ---- store
+    for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
+      const uint32_t t = e % T, k = e / T;
+      fe v = tile[k * T + t];
+      uint64_t oaddr;
+      if (!pd.is_last) {
+        oaddr = in_base + (uint64_t)k * pd.in_sk + (uint64_t)t * pd.in_st;
+        const uint64_t c = (uint64_t)ct * T + t;
+        const uint64_t jnext = c / pd.cprime;
+        const uint64_t K = (pd.pidx == 0) ? (uint64_t)k : ((uint64_t)a + (uint64_t)pd.n0 * k);
+        v = F::mul(v, tw_load(jnext * K * pd.tw_stride));
+      } else {
+        uint64_t K0;
+        if (pd.pidx <= 1) {
+          K0 = (uint64_t)ct * T + t;
+        } else {
+          const uint64_t k0 = (uint64_t)ct * T + t, k1 = a;
+          K0 = k0 + (uint64_t)pd.n0 * k1;
+        }
+        oaddr = K0 + (uint64_t)k * pd.out_sk;
+        if (nl.inverse) {
+          v = F::mul(v, F::unpack(ninv_mont.w));
+          if (nl.coset) {
+            uint32_t cw[8];
+            load8(cw, coset_pow + oaddr * 8);
+            v = F::mul(v, F::unpack(cw));
+          }
+        }
+        if (nl.out_rev) oaddr = bitrev64(oaddr, nl.logn);
+      }
+      B::store_packed(wbuf, v);
+      store8(out + (boff + oaddr * nl.es) * 8, wbuf);
+    }
+  }
+
+  // ---- host ------------------------------------------------------------------------------------
+  template <class PR>
+  static bool words_lt_p(const uint32_t* w)
+  {
+    for (int i = 7; i >= 0; i--) {
+      if (w[i] < PR::P32[i]) return true;
+      if (w[i] > PR::P32[i]) return false;
+    }
+    return false;
+  }
+  static bool words_is_zero(const uint32_t* w)
+  {
+    uint32_t o = 0;
+    for (int i = 0; i < 8; i++)
+      o |= w[i];
+    return o == 0;
+  }
+  static bool words_is_one(const uint32_t* w)
+  {
+    uint32_t o = w[0] ^ 1u;
+    for (int i = 1; i < 8; i++)
+      o |= w[i];
+    return o == 0;
+  }
+  template <class PR>
+  static BigWords mont_words(const typename FieldOps<PR>::fe& x)
+  {
+    BigWords r;
+    BigNtt<PR>::store_packed(r.w, x);
+    return r;
+  }
+  template <class PR>
+  static typename FieldOps<PR>::fe host_inverse(const typename FieldOps<PR>::fe& x)
+  { // x^(p-2)
+    uint32_t e[8];
+    uint64_t borrow = 2;
+    for (int i = 0; i < 8; i++) {
+      const uint64_t v = (uint64_t)PR::P32[i];
+      const uint64_t d = v - borrow;
+      e[i] = (uint32_t)d;
+      borrow = (v < borrow) ? 1 : 0;
+    }
+    return BigNtt<PR>::pow_words(x, e, 8);
+  }
+
+  template <class PR>
+  static icicle_error_t big_init_domain_run(const uint32_t* root, const icicle_ntt_init_domain_config_t* cfg)
+  {
+    using F = FieldOps<PR>;
+    if (!root || !cfg) return ICICLE_INVALID_POINTER;
+    ICICLE_TRY(bind_current_device());
+    const int dev = current_device_id();
+    std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
+    auto& dom = BigDomainStore<PR>::map()[dev];
+    if (dom.tw) return ICICLE_SUCCESS; // already initialised: silent success (cpu_ntt_domain.h:69)
+    if (words_is_zero(root) || !words_lt_p<PR>(root)) return ICICLE_INVALID_ARGUMENT;
+    // order of the root by repeated squaring (cpu_ntt_domain.h:78-94)
+    const typename F::fe r = F::from_canonical(root);
+    typename F::fe x = r;
+    int log_max = 0;
+    while (!F::eq(x, F::one()) && log_max <= PR::TWO_ADICITY) {
+      x = F::sqr(x);
+      log_max++;
+    }
+    if (!F::eq(x, F::one())) return ICICLE_INVALID_ARGUMENT; // not a 2^k-th root of unity
+    hipStream_t st = (hipStream_t)cfg->stream;
+    const size_t n = (size_t)1 << log_max;
+    uint32_t* tw = nullptr;
+    HIP_TRY(hipMalloc(&tw, n * 32), ICICLE_ALLOCATION_FAILED);
+    k_big_gen_twiddles<PR><<<(unsigned)((n / 64 + 256) / 256), 256, 0, st>>>(tw, mont_words<PR>(r), n);
+    LAUNCH_CHECK("k_big_gen_twiddles", st);
+    HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
+    if (!cfg->is_async) HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    dom.tw = tw;
+    dom.log_max = log_max;
+    memcpy(dom.root, root, 32);
+    return ICICLE_SUCCESS;
+  }
+
+  template <class PR>
+  static icicle_error_t big_release_domain_run()
+  {
+    ICICLE_TRY(bind_current_device());
+    const int dev = current_device_id();
+    std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
+    auto it = BigDomainStore<PR>::map().find(dev);
+    if (it != BigDomainStore<PR>::map().end()) {
+      if (it->second.tw) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(it->second.tw);
+      }
+      BigDomainStore<PR>::map().erase(it);
+    }
+    return ICICLE_SUCCESS;
+  }
+
+  template <class PR>
+  static icicle_error_t big_rou_from_domain_run(uint64_t logn, uint32_t* rou)
+  {
+    using F = FieldOps<PR>;
+    if (!rou) return ICICLE_INVALID_POINTER;
+    const int dev = current_device_id();
+    std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
+    auto it = BigDomainStore<PR>::map().find(dev);
+    if (it == BigDomainStore<PR>::map().end() || !it->second.tw) return ICICLE_INVALID_ARGUMENT;
+    if ((int64_t)logn > it->second.log_max) return ICICLE_INVALID_ARGUMENT;
+    typename F::fe x = F::from_canonical(it->second.root); // twiddles[max >> logn] (cpu_ntt_domain.h:644-654)
+    for (int i = 0; i < it->second.log_max - (int)logn; i++)
+      x = F::sqr(x);
+    F::to_canonical(rou, x);
+    return ICICLE_SUCCESS;
+  }
+
+  template <class PR>
+  static icicle_error_t big_get_root_of_unity_run(uint64_t max_size, uint32_t* rou)
+  {
+    using F = FieldOps<PR>;
+    if (!rou || max_size == 0) return ICICLE_INVALID_ARGUMENT;
+    uint32_t logn = 0;
+    while (((uint64_t)1 << logn) < max_size)
+      logn++; // ceil(log2(max_size)), src/ntt.cpp:57
+    if ((int)logn > PR::TWO_ADICITY) return ICICLE_INVALID_ARGUMENT;
+    typename F::fe x = F::from_canonical(PR::ROU32);
+    for (int i = 0; i < PR::TWO_ADICITY - (int)logn; i++)
+      x = F::sqr(x);
+    if (logn == 0) x = F::one();
+    F::to_canonical(rou, x);
+    return ICICLE_SUCCESS;
+  }
+
+  template <class PR>
+  static icicle_error_t big_ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output)
+  {
+    using F = FieldOps<PR>;
+    using fe = typename F::fe;
+    if (!cfg) return ICICLE_INVALID_POINTER;
+    if (size <= 0 || (size & (size - 1)) != 0) return ICICLE_INVALID_ARGUMENT; // cpu_ntt_main.h:38-41
+    if (!input || !output) return ICICLE_INVALID_POINTER;
+    if (dir != ICICLE_NTT_FORWARD && dir != ICICLE_NTT_INVERSE) return ICICLE_INVALID_ARGUMENT;
+    if (cfg->ordering < 0 || cfg->ordering > ICICLE_kMN) return ICICLE_INVALID_ARGUMENT;
+    const int batch = std::max(1, cfg->batch_size);
+    ICICLE_TRY(bind_current_device());
+    const int dev = current_device_id();
+    BigDomain dom;
+    {
+      std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
+      auto it = BigDomainStore<PR>::map().find(dev);
+      if (it == BigDomainStore<PR>::map().end() || !it->second.tw) return ICICLE_INVALID_ARGUMENT; // domain not initialised
+      dom = it->second;
+    }
+    int logn = 0;
+    while ((1 << logn) < size)
+      logn++;
+    if (logn > dom.log_max) return ICICLE_INVALID_ARGUMENT;
+    if (words_is_zero(cfg->coset_gen) || !words_lt_p<PR>(cfg->coset_gen)) return ICICLE_INVALID_ARGUMENT;
+
+    hipStream_t st = (hipStream_t)cfg->stream;
+    const uint64_t n = (uint64_t)size;
+    const size_t bytes = (size_t)n * batch * 32;
+
+    TempBuf d_in_tmp, d_out_tmp, d_pw, d_work;
+    const uint32_t* d_in = input;
+    uint32_t* d_out = output;
+    if (!cfg->are_inputs_on_device) {
+      HIP_TRY(d_in_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(hipMemcpyAsync(d_in_tmp.ptr(), input, bytes, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
+      d_in = d_in_tmp.as<uint32_t>();
+    }
+    if (!cfg->are_outputs_on_device) {
+      if (!cfg->are_inputs_on_device) {
+        d_out = d_in_tmp.as<uint32_t>(); // staged input doubles as the output buffer
+      } else {
+        HIP_TRY(d_out_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+        d_out = d_out_tmp.as<uint32_t>();
+      }
+    }
+    auto finish = [&]() -> icicle_error_t {
+      if (!cfg->are_outputs_on_device) {
+        HIP_TRY(hipMemcpyAsync(output, d_out, bytes, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
+        HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+      } else if (!cfg->is_async) {
+        HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+      }
+      return ICICLE_SUCCESS;
+    };
+    if (logn == 0) { // size-1 transforms are the identity in every mode
+      if (d_out != d_in) HIP_TRY(hipMemcpyAsync(d_out, d_in, bytes, hipMemcpyDeviceToDevice, st), ICICLE_COPY_FAILED);
+      return finish();
+    }
+
+    NttLaunch nl;
+    nl.logn = logn;
+    nl.n = n;
+    nl.nbatch = (uint32_t)batch;
+    nl.lanes = 1;
+    if (cfg->columns_batch) { // element j of transform b at j*batch + b (ntt_cpu.h:250,274-275)
+      nl.bs = 1;
+      nl.es = (uint64_t)batch;
+    } else {
+      nl.bs = n;
+      nl.es = 1;
+    }
+    const int ord = cfg->ordering;
+    nl.in_rev = (ord == ICICLE_kRN || ord == ICICLE_kRR);
+    nl.out_rev = (ord == ICICLE_kNR || ord == ICICLE_kRR);
+    nl.inverse = (dir == ICICLE_NTT_INVERSE);
+    nl.log_max = dom.log_max;
+    nl.ninv_mont = 0;
+    BigWords ninv{};
+    if (nl.inverse) { // (1/2)^logn; 1/2 = (p+1)/2
+      uint32_t h[8];
+      uint64_t c = 1;
+      for (int i = 0; i < 8; i++) {
+        const uint64_t v = (uint64_t)PR::P32[i] + c;
+        h[i] = (uint32_t)v;
+        c = v >> 32;
+      }
+      for (int i = 0; i < 8; i++)
+        h[i] = (h[i] >> 1) | (i < 7 ? (h[i + 1] << 31) : ((uint32_t)c << 31));
+      ninv = mont_words<PR>(BigNtt<PR>::pow_u64(F::from_canonical(h), (uint64_t)logn));
+    }
+    nl.coset = !words_is_one(cfg->coset_gen);
+    if (nl.coset) {
+      HIP_TRY(d_pw.alloc(n * 32, st), ICICLE_ALLOCATION_FAILED);
+      fe gm = F::from_canonical(cfg->coset_gen);
+      if (nl.inverse) gm = host_inverse<PR>(gm);
+      k_big_coset_powers<PR><<<(unsigned)((n / 16 + 256) / 256), 256, 0, st>>>(d_pw.as<uint32_t>(), mont_words<PR>(gm), n);
+      LAUNCH_CHECK("k_big_coset_powers", st);
+    }
+
+    int parts[3], P;
+    split_logn(logn, 8, parts, &P);
+    uint32_t* Wk = nullptr;
+    if (P >= 2) { // see ntt.hip: the last pass permutes across tiles, earlier passes run in a work buffer
+      HIP_TRY(d_work.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+      Wk = d_work.as<uint32_t>();
+    }
+    HIP_TRY(hipFuncSetAttribute((const void*)k_big_ntt_pass<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
+    for (int p = 0; p < P; p++) {
+      const uint32_t* src = (p == 0) ? d_in : Wk;
+      uint32_t* dst = (p == P - 1) ? d_out : Wk;
+      const uint64_t L = (uint64_t)1 << parts[p];
+      // tile of L x T elements, 36 B each, <= 72 KiB so that two blocks share a CU; T = 4 gives 128 B runs
+      uint32_t tmax = 4;
+      while (tmax > 1 && L * tmax * sizeof(fe) > 72 * 1024)
+        tmax >>= 1;
+      const PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
+      const uint32_t tot = (uint32_t)(L * pd.T);
+      const unsigned threads = std::max(64u, std::min(512u, tot / 2));
+      k_big_ntt_pass<PR><<<dim3(pd.ntiles, nl.nbatch), threads, (size_t)tot * sizeof(fe), st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, nl, ninv);
+      LAUNCH_CHECK("k_big_ntt_pass", st);
+    }
+    HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
+    return finish();
+  }
+
+} // namespace icicle_hip
+
+using namespace icicle_hip;
+
+#define GUARDED(expr)                                                                                                  \
+  try {                                                                                                                \
+    return (expr);                                                                                                     \
+  } catch (...) {                                                                                                      \
+    return ICICLE_INVALID_ARGUMENT;                                                                                    \
+  }
+
+#define DEFINE_NTT_U256(F, PRM)                                                                                        \
+  extern "C" icicle_error_t F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* config, uint32_t* output) \
+  {                                                                                                                    \
+    GUARDED(big_ntt_run<PRM>(input, size, dir, config, output));                                                       \
+  }                                                                                                                    \
+  extern "C" icicle_error_t F##_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config) \
+  {                                                                                                                    \
+    GUARDED(big_init_domain_run<PRM>(primitive_root, config));                                                         \
+  }                                                                                                                    \
+  extern "C" icicle_error_t F##_ntt_release_domain(void) { GUARDED(big_release_domain_run<PRM>()); }                   \
+  extern "C" icicle_error_t F##_get_root_of_unity(uint64_t max_size, uint32_t* rou)                                    \
+  {                                                                                                                    \
+    GUARDED(big_get_root_of_unity_run<PRM>(max_size, rou));                                                            \
+  }                                                                                                                    \
+  extern "C" icicle_error_t F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou)                            \
+  {                                                                                                                    \
+    GUARDED(big_rou_from_domain_run<PRM>(logn, rou));                                                                  \
+  }                                                                                                                    \
+  extern "C" icicle_error_t icicle_hip_##F##_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u256_t* c, uint32_t* o) { GUARDED(big_ntt_run<PRM>(i, n, d, c, o)); } \
+  extern "C" icicle_error_t icicle_hip_##F##_ntt_init_domain(const uint32_t* r, const icicle_ntt_init_domain_config_t* c) { GUARDED(big_init_domain_run<PRM>(r, c)); } \
+  extern "C" icicle_error_t icicle_hip_##F##_ntt_release_domain(void) { GUARDED(big_release_domain_run<PRM>()); }      \
+  extern "C" icicle_error_t icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t l, uint32_t* r) { GUARDED(big_rou_from_domain_run<PRM>(l, r)); }
+
+DEFINE_NTT_U256(bn254, bn254_fr_params)
+DEFINE_NTT_U256(bls12_381, bls12_381_fr_params)

@@ -1,0 +1,111 @@
+// Pass decomposition shared by the 31-bit NTT (ntt.hip) and the 256-bit scalar-field NTT (ntt_big.hip).
+//
+// N = N0*N1[*N2] is split into at most three passes; pass p computes 2^s-point sub-transforms on
+// [L x T] tiles (T adjacent columns => every HBM access is a run of T contiguous elements), applies
+// the inter-pass twiddle on the way out, and the LAST pass scatters straight into natural order.
+// Addresses are in ELEMENTS of one logical row; the kernels scale by the element stride / width.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+
+namespace icicle_hip {
+
+  // ---- pass descriptor -------------------------------------------------------------------------
+  struct PassDesc {
+    int s;            // log2 of the sub-transform length L
+    int T;            // tile width (columns per block)
+    uint32_t ntiles;  // tiles per row-transform
+    // tile -> (a, c0): tile index = a * tiles_per_a + ct ;
+    uint32_t tiles_per_a;
+    // load/store addressing inside one logical row: addr = base + k*sk + t*st
+    uint64_t in_base_a, in_base_ct, in_sk, in_st;     // base = a*in_base_a + ct*in_base_ct
+    uint64_t out_sk, out_st;                          // out base computed in-kernel (needs digit reversal)
+    int is_last;      // last pass: natural-order scatter + optional 1/N scaling
+    int pidx;         // pass index
+    // twiddle after this pass (not last): exponent = jnext * K, table stride tstride
+    uint64_t tw_stride;  // max / M
+    uint32_t cprime;     // C' = C / N_{p+1}; jnext = (c0 + t) / C'
+    uint32_t n0, n1;     // N_0, N_1 (for K and digit reversal)
+  };
+
+  struct NttLaunch {
+    uint32_t logn;
+    uint64_t n;
+    uint32_t nbatch;   // number of independent lane-transforms (batch * lanes)
+    uint32_t lanes;    // 1 (scalar) or 4 (quartic extension)
+    uint64_t bs;       // offset(b') = (b'/lanes)*bs + (b'%lanes)
+    uint64_t es;       // element stride
+    int in_rev, out_rev; // bit-reversed logical->memory maps
+    int inverse;
+    uint32_t log_max;
+    uint32_t ninv_mont;  // N^-1 (Montgomery) for inverse
+    int coset;           // multiply by powers table (forward: on first load; inverse: on last store)
+    // row-group execution (fast path): this launch covers rows [row0, row0 + nrows_launch); a buffer
+    // flagged "relative" holds only the current group (its row r lives at offset of row r - row0)
+    uint32_t row0 = 0, nrows_launch = 0;
+    int src_rel = 0, dst_rel = 0;
+  };
+
+  __device__ __forceinline__ uint64_t bitrev64(uint64_t x, uint32_t bits)
+  {
+    return bits == 0 ? 0 : (__brevll(x) >> (64 - bits));
+  }
+
+
+  // <= 3 passes; sub-transforms of at most 2^smax points while that covers logn, larger above
+  static inline void split_logn(int logn, int smax, int* parts, int* np)
+  {
+    const int SMAX = std::max(smax, (logn + 2) / 3);
+    const int P = std::max(1, (logn + SMAX - 1) / SMAX);
+    for (int i = 0; i < P; i++)
+      parts[i] = logn / P + (i < logn % P ? 1 : 0);
+    *np = P;
+  }
+
+  // descriptor of pass p of P; tmax = widest tile the kernel's LDS / block budget allows for 2^parts[p] rows
+  static inline PassDesc make_pass(const int* parts, int P, int p, uint64_t n, int log_max, uint32_t tmax)
+  {
+    PassDesc pd{};
+    pd.s = parts[p];
+    pd.pidx = p;
+    pd.is_last = (p == P - 1);
+    const uint64_t L = (uint64_t)1 << pd.s;
+    uint64_t A = 1, C = 1;
+    for (int q = 0; q < p; q++)
+      A <<= parts[q];
+    for (int q = p + 1; q < P; q++)
+      C <<= parts[q];
+    pd.n0 = 1u << parts[0];
+    pd.n1 = P > 1 ? (1u << parts[1]) : 1;
+    if (!pd.is_last) {
+      pd.T = (int)std::min<uint64_t>(tmax, C);
+      pd.tiles_per_a = (uint32_t)(C / pd.T);
+      pd.ntiles = (uint32_t)(A * pd.tiles_per_a);
+      pd.in_base_a = L * C;
+      pd.in_base_ct = pd.T;
+      pd.in_sk = C;
+      pd.in_st = 1;
+      int lm = 0; // M = N_0..N_{p+1}
+      for (int q = 0; q <= p + 1; q++)
+        lm += parts[q];
+      pd.tw_stride = (uint64_t)1 << (log_max - lm);
+      pd.cprime = (uint32_t)(C >> parts[p + 1]);
+    } else {
+      // tile over k0 (the slowest digit of a); for P==3 `a` in the kernel carries k1
+      const uint64_t n0 = P >= 2 ? ((uint64_t)1 << parts[0]) : 1;
+      const uint64_t n1 = P == 3 ? ((uint64_t)1 << parts[1]) : 1;
+      pd.T = (int)std::min<uint64_t>(tmax, n0);
+      pd.tiles_per_a = (uint32_t)(n0 / pd.T);
+      pd.ntiles = (uint32_t)(n1 * pd.tiles_per_a);
+      // row index = k0*n1 + k1 ; row start = row*L
+      pd.in_base_a = L; // a = k1
+      pd.in_base_ct = (uint64_t)pd.T * n1 * L;
+      pd.in_sk = 1;
+      pd.in_st = n1 * L;
+      pd.out_sk = n >> pd.s;
+      pd.out_st = 1;
+    }
+    return pd;
+  }
+
+} // namespace icicle_hip

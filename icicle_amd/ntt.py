@@ -1,7 +1,7 @@
 """ntt() / domain management: mirror of wrappers/rust/icicle-core/src/ntt/mod.rs:113-119,285-355."""
 import ctypes
 import numpy as np
-from ._lib import lib, check, NTTConfigU32, NTTInitDomainConfig
+from ._lib import lib, check, NTTConfigU32, NTTConfigU256, NTTInitDomainConfig, SCALAR_NTT_FIELDS
 from .runtime import DeviceVec
 
 FORWARD, INVERSE = 0, 1
@@ -17,13 +17,33 @@ def _ptr(x):
     return x.ctypes.data, False
 
 
+def _is_big(field: str) -> bool:
+    return field in SCALAR_NTT_FIELDS
+
+
+def _words(x: int):
+    return (ctypes.c_uint32 * 8)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+
+
+def _int(w) -> int:
+    return sum(int(w[i]) << (32 * i) for i in range(8))
+
+
 def get_root_of_unity(field: str, max_size: int) -> int:
+    if _is_big(field):
+        w = (ctypes.c_uint32 * 8)()
+        check(getattr(lib, f"{field}_get_root_of_unity")(max_size, w), "get_root_of_unity")
+        return _int(w)
     r = ctypes.c_uint32()
     check(getattr(lib, f"{field}_get_root_of_unity")(max_size, ctypes.byref(r)), "get_root_of_unity")
     return r.value
 
 
 def get_root_of_unity_from_domain(field: str, logn: int) -> int:
+    if _is_big(field):
+        w = (ctypes.c_uint32 * 8)()
+        check(getattr(lib, f"{field}_get_root_of_unity_from_domain")(logn, w), "get_root_of_unity_from_domain")
+        return _int(w)
     r = ctypes.c_uint32()
     check(getattr(lib, f"{field}_get_root_of_unity_from_domain")(logn, ctypes.byref(r)), "get_root_of_unity_from_domain")
     return r.value
@@ -31,6 +51,9 @@ def get_root_of_unity_from_domain(field: str, logn: int) -> int:
 
 def init_domain(field: str, primitive_root: int, cfg: NTTInitDomainConfig = None):
     cfg = cfg or NTTInitDomainConfig.default()
+    if _is_big(field):
+        check(getattr(lib, f"{field}_ntt_init_domain")(_words(primitive_root), ctypes.byref(cfg)), "ntt_init_domain")
+        return
     r = ctypes.c_uint32(primitive_root)
     check(getattr(lib, f"{field}_ntt_init_domain")(ctypes.byref(r), ctypes.byref(cfg)), "ntt_init_domain")
 
@@ -39,9 +62,15 @@ def release_domain(field: str):
     check(getattr(lib, f"{field}_ntt_release_domain")(), "ntt_release_domain")
 
 
-def ntt(field: str, inp, direction: int, cfg: NTTConfigU32 = None, out=None, size: int = None, extension: bool = False):
-    cfg = cfg or NTTConfigU32.default()
-    lanes = 4 if extension else 1
+def ntt(field: str, inp, direction: int, cfg=None, out=None, size: int = None, extension: bool = False):
+    """Scalar-field NTT of a curve (field in SCALAR_NTT_FIELDS): elements are 8 u32 words, cfg is NTTConfigU256."""
+    if _is_big(field):
+        assert not extension
+        cfg = cfg or NTTConfigU256.default()
+        lanes = 8
+    else:
+        cfg = cfg or NTTConfigU32.default()
+        lanes = 4 if extension else 1
     ip, i_dev = _ptr(inp)
     cfg.are_inputs_on_device = i_dev
     if size is None:

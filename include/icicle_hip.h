@@ -163,6 +163,31 @@ typedef struct {
 ICICLE_HIP_DECLARE_NTT_U32(babybear)
 ICICLE_HIP_DECLARE_NTT_U32(koalabear)
 
+/* NTT over the curves' 256-bit scalar fields: scalar_t = 8 little-endian u32 words, so NTTConfig<scalar_t>
+ * is 64 bytes (include/icicle/ntt.h:53-64 with S = bn254::scalar_t; storage<8> is 8-byte aligned on the host,
+ * include/icicle/math/storage.h:36-49). Symbols: src/ntt.cpp:11-84 built with FIELD = the curve's scalar field. */
+typedef struct {
+  icicleStreamHandle stream;
+  uint32_t coset_gen[8]; /* canonical, {1,0,..} = no coset */
+  int32_t batch_size;
+  bool columns_batch;
+  int32_t ordering; /* icicle_ntt_ordering_t */
+  bool are_inputs_on_device;
+  bool are_outputs_on_device;
+  bool is_async;
+  icicle_config_extension_t* ext;
+} icicle_ntt_config_u256_t;
+
+#define ICICLE_HIP_DECLARE_NTT_U256(F)                                                                                 \
+  icicle_error_t F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* config, uint32_t* output); /* src/ntt.cpp:11 */ \
+  icicle_error_t F##_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config);  /* src/ntt.cpp:26 */ \
+  icicle_error_t F##_ntt_release_domain(void);                                                                          /* src/ntt.cpp:41 */ \
+  icicle_error_t F##_get_root_of_unity(uint64_t max_size, uint32_t* rou);                                               /* src/ntt.cpp:55 */ \
+  icicle_error_t F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);                                       /* src/ntt.cpp:75 */
+
+ICICLE_HIP_DECLARE_NTT_U256(bn254)
+ICICLE_HIP_DECLARE_NTT_U256(bls12_381)
+
 /* ======================================================================================
  * Montgomery-form conversion (vec-ops): include/icicle/vec_ops.h:19-37 (VecOpsConfig, 32 bytes),
  * src/vec_ops.cpp:404-408,421-425 (<prefix>_scalar_convert_montgomery, _extension_scalar_convert_montgomery),
@@ -229,6 +254,13 @@ icicle_error_t icicle_hip_bls12_381_msm_precompute_bases(const void* input_bases
   icicle_error_t icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);
 ICICLE_HIP_DECLARE_NTT_ALIASES(babybear)
 ICICLE_HIP_DECLARE_NTT_ALIASES(koalabear)
+#define ICICLE_HIP_DECLARE_NTT_U256_ALIASES(F)                                                                         \
+  icicle_error_t icicle_hip_##F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* config, uint32_t* output); \
+  icicle_error_t icicle_hip_##F##_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config); \
+  icicle_error_t icicle_hip_##F##_ntt_release_domain(void);                                                            \
+  icicle_error_t icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);
+ICICLE_HIP_DECLARE_NTT_U256_ALIASES(bn254)
+ICICLE_HIP_DECLARE_NTT_U256_ALIASES(bls12_381)
 ICICLE_HIP_DECLARE_CONVERT(icicle_hip_bn254)
 ICICLE_HIP_DECLARE_CONVERT(icicle_hip_bls12_381)
 ICICLE_HIP_DECLARE_CONVERT(icicle_hip_babybear)

@@ -129,7 +129,10 @@ KOALABEAR = NttField("koalabear", 0x7F000001, 0x6AC49F88, 24)
 BN254_FR = NttField(
     "bn254", BN254.r, 0x2A3C09F0A58A7E8500E0A7EB8EF62ABC402D111E41112ED49BD61B6E725B19F0, 28
 )
-NTT_FIELDS = {"babybear": BABYBEAR, "koalabear": KOALABEAR, "bn254": BN254_FR}
+BLS12_381_FR = NttField(
+    "bls12_381", BLS12_381.r, 0x0212D79E5B416B6F0FD56DC8D168D6C0C4024FF270B3E0941B788F500B912F1F, 32
+)
+NTT_FIELDS = {"babybear": BABYBEAR, "koalabear": KOALABEAR, "bn254": BN254_FR, "bls12_381": BLS12_381_FR}
 
 
 def omega(f: NttField, logn: int) -> int:

@@ -57,6 +57,14 @@ class NTTConfigU32(ctypes.Structure):  # icicle/include/icicle/ntt.h:53-64 for a
     ]
 
 
+class NTTConfigU256(ctypes.Structure):  # the same struct for the curves' 32-byte scalar_t (storage<8>, 8-byte aligned)
+    _fields_ = [
+        ("stream", ctypes.c_void_p), ("coset_gen", ctypes.c_uint32 * 8), ("batch_size", ctypes.c_int),
+        ("columns_batch", ctypes.c_bool), ("ordering", ctypes.c_int), ("are_inputs_on_device", ctypes.c_bool),
+        ("are_outputs_on_device", ctypes.c_bool), ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p),
+    ]
+
+
 class NTTInitDomainConfig(ctypes.Structure):
     _fields_ = [("stream", ctypes.c_void_p), ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p)]
 
@@ -283,3 +291,54 @@ class RefNttField:
         fn = getattr(self.lib, f"{self.name}_ntt")
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         return fn(d_in, size, direction, ctypes.byref(cfg), d_out)
+
+
+def _w8(x: int):
+    return (ctypes.c_uint32 * 8)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+
+
+def _i8(w) -> int:
+    return sum(int(w[i]) << (32 * i) for i in range(8))
+
+
+class RefScalarNttField:
+    """NTT over a curve's 256-bit scalar field (bn254 / bls12_381) through the reference's C ABI on "CPU"
+    (src/ntt.cpp:11-84 compiled with FIELD = the curve's scalar field). Elements: 8 u32 words."""
+
+    def __init__(self, name: str):
+        _load("device")
+        self.name = name
+        self.lib = _load(name)
+
+    def get_root_of_unity(self, max_size: int) -> int:
+        w = (ctypes.c_uint32 * 8)()
+        fn = getattr(self.lib, f"{self.name}_get_root_of_unity")
+        fn.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+        assert fn(max_size, w) == 0
+        return _i8(w)
+
+    def init_domain(self, root: int):
+        cfg = NTTInitDomainConfig(None, False, None)
+        fn = getattr(self.lib, f"{self.name}_ntt_init_domain")
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        assert fn(_w8(root), ctypes.byref(cfg)) == 0
+
+    def release_domain(self):
+        assert getattr(self.lib, f"{self.name}_ntt_release_domain")() == 0
+
+    def get_root_of_unity_from_domain(self, logn: int) -> int:
+        w = (ctypes.c_uint32 * 8)()
+        fn = getattr(self.lib, f"{self.name}_get_root_of_unity_from_domain")
+        fn.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+        assert fn(logn, w) == 0
+        return _i8(w)
+
+    def ntt(self, inp: np.ndarray, size: int, direction: int, batch=1, columns_batch=False, ordering=0,
+            coset_gen=1) -> np.ndarray:
+        cfg = NTTConfigU256(None, _w8(coset_gen), batch, columns_batch, ordering, False, False, False, None)
+        out = np.zeros_like(inp)
+        fn = getattr(self.lib, f"{self.name}_ntt")
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        rc = fn(_p(inp), size, direction, ctypes.byref(cfg), _p(out))
+        assert rc == 0, f"reference ntt failed rc={rc}"
+        return out

@@ -28,10 +28,10 @@ for spec in bn254:1 bls12_381:2; do
   $CXX $FLAGS -DCURVE_ID=$id -DFIELD_ID=$id -DCURVE=$c -DFIELD=$c -DICICLE_FFI_PREFIX=$c -DMSM=ON "$HERE/hip_backend_curve.cpp" \
     -L"$REF" -licicle_curve_$c -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_curve_$c.so"
 done
-for spec in bn254:1 bls12_381:2; do   # the curves' scalar fields: Montgomery conversion only
+for spec in bn254:1 bls12_381:2; do   # the curves' scalar fields: Montgomery conversion + NTT over 32-byte elements
   f=${spec%%:*}; id=${spec##*:}
   echo "[plugin] field $f (scalar field of the curve)"
-  $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$f -DICICLE_FFI_PREFIX=$f -DNTT=ON -DHIP_PLUGIN_NO_NTT "$HERE/hip_backend_field.cpp" \
+  $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$f -DICICLE_FFI_PREFIX=$f -DNTT=ON -DHIP_PLUGIN_SCALAR_FIELD_256 "$HERE/hip_backend_field.cpp" \
     -L"$REF" -licicle_field_$f -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_field_$f.so"
 done
 for spec in babybear:1001 koalabear:1004; do

@@ -1,7 +1,7 @@
-// Reference-runtime plugin, part 3/3: per-field APIs. Every field (incl. the curves' scalar fields,
-// compile with -DHIP_PLUGIN_NO_NTT) gets scalar_convert_montgomery; the 31-bit fields also get NTT.
-// NTT for one 31-bit field (compile once per field with
-// -DFIELD_ID=<n> -DICICLE_FFI_PREFIX=<field> -DNTT=ON -DEXT_FIELD=ON, icicle/cmake/field.cmake:42-79).
+// Reference-runtime plugin, part 3/3: per-field APIs: scalar_convert_montgomery and the NTT family.
+// Compile once per field with -DFIELD_ID=<n> -DICICLE_FFI_PREFIX=<field> -DNTT=ON (icicle/cmake/field.cmake:42-79):
+//   31-bit fields (babybear, koalabear): add -DEXT_FIELD=ON, the extension-field NTT is registered too;
+//   the curves' 256-bit scalar fields (bn254, bls12_381): add -DHIP_PLUGIN_SCALAR_FIELD_256.
 // Registers all four members of the NTT API family (a missing member makes the reference dispatcher
 // THROW through its extern "C" shim) plus the extension-field NTT, with the
 // signatures of icicle/include/icicle/backend/ntt_backend.h:13-93.
@@ -29,14 +29,19 @@ static eIcicleError hip_scalar_convert(const Device& device, const scalar_t* inp
 }
 REGISTER_CONVERT_MONTGOMERY_BACKEND("HIP", hip_scalar_convert);
 
-#ifndef HIP_PLUGIN_NO_NTT
-static_assert(sizeof(scalar_t) == 4, "the NTT part of this plugin covers the 31-bit fields");
-static_assert(sizeof(NTTConfig<scalar_t>) == sizeof(hip_ntt_config_u32_t), "NTTConfig layout drifted");
+#ifdef HIP_PLUGIN_SCALAR_FIELD_256
+typedef hip_ntt_config_u256_t hip_ntt_config_t;
+static_assert(sizeof(scalar_t) == 32, "HIP_PLUGIN_SCALAR_FIELD_256 is for the curves' scalar fields");
+#else
+typedef hip_ntt_config_u32_t hip_ntt_config_t;
+static_assert(sizeof(scalar_t) == 4, "31-bit field expected");
+#endif
+static_assert(sizeof(NTTConfig<scalar_t>) == sizeof(hip_ntt_config_t), "NTTConfig layout drifted");
 static_assert(sizeof(NTTInitDomainConfig) == sizeof(hip_ntt_init_domain_config_t), "NTTInitDomainConfig layout drifted");
 
-static hip_ntt_config_u32_t translate(const NTTConfig<scalar_t>& c)
+static hip_ntt_config_t translate(const NTTConfig<scalar_t>& c)
 {
-  hip_ntt_config_u32_t o;
+  hip_ntt_config_t o;
   std::memcpy(&o, &c, sizeof(o));
   o.ext = nullptr;
   return o;
@@ -45,16 +50,18 @@ static hip_ntt_config_u32_t translate(const NTTConfig<scalar_t>& c)
 static eIcicleError hip_ntt(const Device& device, const scalar_t* input, int size, NTTDir dir, const NTTConfig<scalar_t>& config, scalar_t* output)
 {
   if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
-  const hip_ntt_config_u32_t c = translate(config);
+  const hip_ntt_config_t c = translate(config);
   return (eIcicleError)HIP_FN(ntt)((const uint32_t*)input, size, (int)dir, &c, (uint32_t*)output);
 }
 
+#ifndef HIP_PLUGIN_SCALAR_FIELD_256
 static eIcicleError hip_ext_ntt(const Device& device, const extension_t* input, int size, NTTDir dir, const NTTConfig<scalar_t>& config, extension_t* output)
 {
   if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
-  const hip_ntt_config_u32_t c = translate(config);
+  const hip_ntt_config_t c = translate(config);
   return (eIcicleError)HIP_FN(extension_ntt)((const uint32_t*)input, size, (int)dir, &c, (uint32_t*)output);
 }
+#endif
 
 static eIcicleError hip_ntt_init_domain(const Device& device, const scalar_t& primitive_root, const NTTInitDomainConfig& config)
 {
@@ -81,6 +88,7 @@ REGISTER_NTT_INIT_DOMAIN_BACKEND("HIP", hip_ntt_init_domain);
 REGISTER_NTT_RELEASE_DOMAIN_BACKEND("HIP", hip_ntt_release_domain);
 REGISTER_NTT_GET_ROU_FROM_DOMAIN_BACKEND("HIP", hip_get_rou_from_domain);
 REGISTER_NTT_BACKEND("HIP", hip_ntt);
+#ifndef HIP_PLUGIN_SCALAR_FIELD_256
 REGISTER_NTT_EXT_FIELD_BACKEND("HIP", hip_ext_ntt);
 
 static eIcicleError hip_ext_scalar_convert(const Device& device, const extension_t* input, uint64_t size, bool is_to_montgomery, const VecOpsConfig& config, extension_t* output)
@@ -92,4 +100,4 @@ static eIcicleError hip_ext_scalar_convert(const Device& device, const extension
   return (eIcicleError)HIP_FN(extension_scalar_convert_montgomery)(input, size, is_to_montgomery, &c, output);
 }
 REGISTER_CONVERT_MONTGOMERY_EXT_FIELD_BACKEND("HIP", hip_ext_scalar_convert);
-#endif // HIP_PLUGIN_NO_NTT
+#endif // !HIP_PLUGIN_SCALAR_FIELD_256

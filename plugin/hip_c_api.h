@@ -25,6 +25,16 @@ typedef struct {
 
 typedef struct {
   void* stream;
+  uint32_t coset_gen[8];
+  int batch_size;
+  bool columns_batch;
+  int ordering;
+  bool are_inputs_on_device, are_outputs_on_device, is_async;
+  void* ext;
+} hip_ntt_config_u256_t; // == icicle_ntt_config_u256_t == icicle::NTTConfig<32-byte scalar_t> (64 bytes)
+
+typedef struct {
+  void* stream;
   bool is_async;
   void* ext;
 } hip_ntt_init_domain_config_t;
@@ -64,4 +74,11 @@ HIP_DECLARE_CURVE(bls12_381)
   int icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t, uint32_t*);
 HIP_DECLARE_FIELD(babybear)
 HIP_DECLARE_FIELD(koalabear)
+#define HIP_DECLARE_SCALAR_FIELD(F)                                                                                    \
+  int icicle_hip_##F##_ntt(const uint32_t*, int, int, const hip_ntt_config_u256_t*, uint32_t*);                        \
+  int icicle_hip_##F##_ntt_init_domain(const uint32_t*, const hip_ntt_init_domain_config_t*);                          \
+  int icicle_hip_##F##_ntt_release_domain(void);                                                                       \
+  int icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t, uint32_t*);
+HIP_DECLARE_SCALAR_FIELD(bn254)
+HIP_DECLARE_SCALAR_FIELD(bls12_381)
 }

@@ -113,6 +113,27 @@ def main():
         fobj.release_domain()
         assert rt.set_device("CPU", 0) == 0
         fobj.release_domain()
+
+    # ---- NTT over the curves' 256-bit scalar fields: "HIP" vs "CPU" through the reference frontend ----
+    for name in ("bn254", "bls12_381"):
+        F = pyref.NTT_FIELDS[name]
+        sf = ref.RefScalarNttField(name)
+        logn, batch = 12, 2
+        n = 1 << logn
+        root = sf.get_root_of_unity(1 << (logn + 1))
+        x = to_words(rand_scalars(rng, n * batch, F.p), 8).reshape(-1)
+        assert rt.set_device("CPU", 0) == 0
+        sf.init_domain(root)
+        exp_f = sf.ntt(x, n, 0, batch=batch)
+        exp_i = sf.ntt(x, n, 1, batch=batch, ordering=3, coset_gen=7, columns_batch=True)
+        assert rt.set_device("HIP", 0) == 0
+        sf.init_domain(root)
+        assert sf.get_root_of_unity_from_domain(logn) == pyref.omega(F, logn)
+        assert np.array_equal(sf.ntt(x, n, 0, batch=batch), exp_f)
+        assert np.array_equal(sf.ntt(x, n, 1, batch=batch, ordering=3, coset_gen=7, columns_batch=True), exp_i)
+        sf.release_domain()
+        assert rt.set_device("CPU", 0) == 0
+        sf.release_domain()
     print("PLUGIN OK")
 
 

@@ -18,6 +18,12 @@ BIG = {
     ),
     "bls12_381_fr": (0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, 8),
 }
+# scalar fields with an NTT: root of unity of order 2^two_adicity (reference fp_config::rou,
+# fields/snark_fields/bn254_scalar.h:68-69, bls12_381_scalar.h:46-47)
+BIG_ROU = {
+    "bn254_fr": 0x2A3C09F0A58A7E8500E0A7EB8EF62ABC402D111E41112ED49BD61B6E725B19F0,
+    "bls12_381_fr": 0x0212D79E5B416B6F0FD56DC8D168D6C0C4024FF270B3E0941B788F500B912F1F,
+}
 RB = 29
 
 
@@ -65,6 +71,12 @@ def gen_big(name, p, l32):
     s.append(f"  static constexpr uint32_t CANON_TO_REFMONT[{nl}] = {arr(limbs(c4, nl))}; // 2^{32*l32} * R mod p")
     c3 = r32 % p  # our-Montgomery x*R -> reference-Montgomery: montmul(xR, C) = x*C => C = 2^(32 l32)
     s.append(f"  static constexpr uint32_t MONT_TO_REFMONT[{nl}] = {arr(limbs(c3, nl))}; // 2^{32*l32} mod p")
+    if name in BIG_ROU:
+        rou = BIG_ROU[name]
+        ta = ((p - 1) & -(p - 1)).bit_length() - 1
+        assert pow(rou, 1 << ta, p) == 1 and pow(rou, 1 << (ta - 1), p) != 1
+        s.append(f"  static constexpr int TWO_ADICITY = {ta};")
+        s.append(f"  static constexpr uint32_t ROU32[{l32}] = {arr(limbs(rou, l32, 32))}; // canonical, order 2^TWO_ADICITY")
     s.append("};")
     return "\n".join(s)
 

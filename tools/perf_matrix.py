@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import icicle_amd  # noqa: E402
 from icicle_amd import msm as M, ntt as N, runtime  # noqa: E402
-from icicle_amd._lib import MSMConfig, NTTConfigU32, lib, check  # noqa: E402
+from icicle_amd._lib import MSMConfig, NTTConfigU32, NTTConfigU256, lib, check  # noqa: E402
 
 runtime.set_device(0)
 dev = torch.device("cuda", 0)
@@ -62,7 +62,30 @@ def ntt_case(field, logn, batch):
     N.release_domain(field)
 
 
+def ntt_scalar_case(field, logn, batch):
+    """NTT over the curve's 256-bit scalar field; inputs are any words < 2^253 (valid canonical elements)"""
+    n = 1 << logn
+    N.init_domain(field, N.get_root_of_unity(field, n))
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    x = torch.randint(-(2 ** 31), 2 ** 31, (batch, n, 8), dtype=torch.int32, device=dev, generator=g)
+    x[:, :, 7] &= 0x0FFFFFFF
+    y = torch.empty_like(x)
+    cfg = NTTConfigU256.default()
+    cfg.batch_size = batch
+    cfg.is_async = True
+    ms = time_it(lambda: N.ntt(field, x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n))
+    gbs = 2 * batch * n * 32 / ms / 1e6
+    print(f"ntt {field + '_fr':12s} 2^{logn:<2d} batch {batch:<5d} {ms:9.3f} ms  {batch * n / ms / 1e6:8.2f} Gelem/s  {gbs:7.0f} GB/s algorithmic", flush=True)
+    N.release_domain(field)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "scalar-ntt":
+        for logn, batch in ((12, 256), (16, 16), (20, 1), (22, 1), (24, 1)):
+            ntt_scalar_case("bn254", logn, batch)
+        ntt_scalar_case("bls12_381", 22, 1)
+        sys.exit(0)
     for logn in (12, 16, 20, 22, 24, 26):
         msm_case("bn254", logn)
     msm_case("bn254", 12, batch=1024)
