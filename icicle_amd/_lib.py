@@ -161,6 +161,8 @@ NTT_FIELDS = ["babybear", "koalabear"]
 SCALAR_NTT_FIELDS = ["bn254", "bls12_381"]  # NTT over the curve's scalar field, 8-word elements
 API_SYMBOLS = (
     [f"{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
+    + [f"{c}_g2_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
+    + [f"icicle_hip_{c}_g2_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
                                                "get_root_of_unity_from_domain", "extension_ntt", "hip_twiddle_rows")]
     + [f"{f}_{s}" for f in SCALAR_NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
@@ -217,6 +219,10 @@ for _c in CURVES:
     getattr(lib, f"{_c}_msm_precompute_bases").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.c_void_p]
     getattr(lib, f"{_c}_hip_projective_sum").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     getattr(lib, f"{_c}_hip_generate_affine_points").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_bool, ctypes.c_void_p]
+    getattr(lib, f"{_c}_g2_msm").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.c_void_p]
+    getattr(lib, f"{_c}_g2_msm_precompute_bases").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.c_void_p]
+    getattr(lib, f"{_c}_g2_hip_projective_sum").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    getattr(lib, f"{_c}_g2_hip_generate_affine_points").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_bool, ctypes.c_void_p]
 for _f in NTT_FIELDS:
     getattr(lib, f"{_f}_ntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU32), ctypes.c_void_p]
     getattr(lib, f"{_f}_extension_ntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU32), ctypes.c_void_p]

@@ -58,6 +58,7 @@ namespace icicle_hip {
     static constexpr int N = PR::NL;
     static constexpr int N32 = PR::NL32;
     static constexpr uint32_t MASK = RB_MASK;
+    static constexpr bool TIGHT = false; // see fq2.cuh
     using fe = Fe<PR>;
     // R/p (lower bound) used only by the debug bound tracker
     static constexpr double r_over_p() { return (double)(1ull << (RB * N - PR::NBITS)); }
@@ -79,6 +80,17 @@ namespace icicle_hip {
 #pragma unroll
       for (int i = 0; i < N; i++)
         r.l[i] = PR::ONE[i];
+      BF_SET_BOUND(r, 1);
+      return r;
+    }
+    // constant given as [N] Montgomery limbs (< p)
+    template <class ARR>
+    static HD fe from_const(const ARR& c)
+    {
+      fe r;
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        r.l[i] = c[i];
       BF_SET_BOUND(r, 1);
       return r;
     }
@@ -284,6 +296,18 @@ namespace icicle_hip {
       for (int i = 0; i < N - 1; i++)
         a.l[i] = ge ? t[i] : a.l[i];
       a.l[N - 1] = ge ? (uint32_t)top : a.l[N - 1];
+#ifdef BIGFIELD_BOUNDS
+      a.bnd = (a.bnd - (double)K > (double)K) ? a.bnd - (double)K : (a.bnd < (double)K ? a.bnd : (double)K);
+#endif
+    }
+    // value < 16p -> < 4p (two conditional subtractions); used by ec.cuh in Fq2Ops' TIGHT mode only
+    static HD fe below4(const fe& a)
+    {
+      BF_ASSERT(a.bnd <= 16.0, "below4 input bound");
+      fe r = a;
+      cond_sub<8>(r);
+      cond_sub<4>(r);
+      return r;
     }
     static HD fe reduce(const fe& a)
     { // value < 32p  ->  [0,p)
@@ -323,6 +347,20 @@ namespace icicle_hip {
       for (int i = 0; i < N; i++)
         o |= ra.l[i] ^ rb.l[i];
       return o == 0;
+    }
+
+    // a^(p-2) (Montgomery in, Montgomery out); a = 0 gives 0. Cold paths only (affine conversion).
+    static HD fe inv(const fe& a)
+    {
+      fe r = one(), base = a;
+      for (int wi = 0; wi < N32; wi++) {
+        const uint32_t e = PR::P32[wi] - (wi == 0 ? 2u : 0u);
+        for (int b = 0; b < 32; b++) {
+          if ((e >> b) & 1) r = mul(r, base);
+          base = sqr(base);
+        }
+      }
+      return r;
     }
 
     // ---- packed 32-bit <-> 29-bit limbs ----

@@ -12,16 +12,27 @@
 // Bounds (units of p, see bigfield.cuh; machine-checked under -DBIGFIELD_BOUNDS):
 //   affine (Montgomery)  x <= 1.2, y <= 2.2         XYZZ  X <= 8, Y <= 4, ZZ,ZZZ <= 2
 //   projective           X,Y,Z <= 4
+//
+// The same code serves G1 (coordinates in Fq, FieldOps) and G2 (coordinates in Fq2, fq2.cuh):
+// C::EXT_DEGREE selects the field-ops class, everything below only uses their common interface.
 #pragma once
 #include "bigfield.cuh"
+#include "fq2.cuh"
+#include <type_traits>
+
+#if defined(__HIPCC__)
+  #define EC_NOINLINE __host__ __device__ __noinline__
+#else
+  #define EC_NOINLINE __attribute__((noinline))
+#endif
 
 namespace icicle_hip {
 
   template <class C>
   struct EC {
-    using F = FieldOps<typename C::fq>;
+    using F = std::conditional_t<C::EXT_DEGREE == 2, Fq2Ops<typename C::fq>, FieldOps<typename C::fq>>;
     using fe = typename F::fe;
-    static constexpr int N32 = F::N32;
+    static constexpr int N32 = F::N32; // packed words per coordinate
 
     struct Aff { // Montgomery coordinates; never the identity
       fe x, y;
@@ -33,25 +44,12 @@ namespace icicle_hip {
       fe x, y, z;
     };
 
-    static HD fe b3()
-    {
-      fe r;
-#pragma unroll
-      for (int i = 0; i < F::N; i++)
-        r.l[i] = C::B3[i];
-      BF_SET_BOUND(r, 1);
-      return r;
-    }
+    static HD fe b3() { return F::from_const(C::B3); }
     static HD Aff generator()
     {
       Aff g;
-#pragma unroll
-      for (int i = 0; i < F::N; i++) {
-        g.x.l[i] = C::GX[i];
-        g.y.l[i] = C::GY[i];
-      }
-      BF_SET_BOUND(g.x, 1);
-      BF_SET_BOUND(g.y, 1);
+      g.x = F::from_const(C::GX);
+      g.y = F::from_const(C::GY);
       return g;
     }
 
@@ -101,6 +99,7 @@ namespace icicle_hip {
       fe M = F::add(F::dbl(X2), X2);     // 3x^2 <= 3.3
       fe S2 = F::dbl(S);                 // <= 2.2
       r.x = F::template sub<4>(F::sqr(M), S2);             // <= 5.1
+      if constexpr (F::TIGHT) r.x = F::below4(r.x);        // Fq2 over BN254: stored X stays < 4p
       fe t = F::template sub<8>(S, r.x);                   // <= 9.1
       r.y = F::template sub<2>(F::mul(M, t), F::mul(W, p.y)); // <= 3.3
       r.zz = V;
@@ -122,8 +121,9 @@ namespace icicle_hip {
       }
       fe U2 = F::mul(b.x, acc.zz);
       fe S2 = F::mul(b.y, acc.zzz);
-      fe P = F::template sub<8>(U2, acc.x); // <= 9.1
-      fe R = F::template sub<4>(S2, acc.y); // <= 5.1
+      // TIGHT (Fq2 over BN254, products < 2p rather than ~1.2p): X is kept < 4p, so 4p suffices here
+      fe P = F::template sub<(F::TIGHT ? 4 : 8)>(U2, acc.x); // <= 9.1
+      fe R = F::template sub<4>(S2, acc.y);                  // <= 5.1
       fe PP = F::sqr(P);                    // <= 1.7
       if (F::maybe_zero_mulout(PP)) {
         if (F::is_zero(P)) { // same x: either b == acc (double) or b == -acc (cancel)
@@ -138,8 +138,9 @@ namespace icicle_hip {
       fe PPP = F::mul(P, PP);               // ~1.2
       fe Q = F::mul(acc.x, PP);             // ~1.2
       fe t = F::add(PPP, F::dbl(Q));        // <= 3.6
-      fe X3 = F::template sub<4>(F::sqr(R), t); // <= 5.3
-      fe d = F::template sub<8>(Q, X3);     // <= 9.2
+      fe X3 = F::template sub<(F::TIGHT ? 8 : 4)>(F::sqr(R), t); // <= 5.3
+      if constexpr (F::TIGHT) X3 = F::below4(X3);
+      fe d = F::template sub<(F::TIGHT ? 4 : 8)>(Q, X3);         // <= 9.2
       // Y3 = R*d - Y1*PPP = R*d + (4p - Y1)*PPP with one shared reduction (lazy, mul_add)
       fe Y3 = F::mul_add(R, d, F::template neg<4>(acc.y), PPP); // <= 1.5
       acc.zz = F::mul(acc.zz, PP);
@@ -176,7 +177,17 @@ namespace icicle_hip {
     }
     // Renes-Costello-Batina 2016, Algorithm 7 (a = 0), the formula the reference uses
     // (projective.h:101-143): 12M + 2 mul-by-3b, valid for ALL inputs.
+    // Over Fq2 the body is ~5000 (BN254) to ~12000 (BLS12-381) instructions; the cold kernels that use
+    // it call it as a function there (one copy per kernel) instead of inlining it at every site.
     static HD Proj add(const Proj& p, const Proj& q)
+    {
+      if constexpr (C::EXT_DEGREE == 2)
+        return add_call(p, q);
+      else
+        return add_body(p, q);
+    }
+    static EC_NOINLINE Proj add_call(const Proj& p, const Proj& q) { return add_body(p, q); }
+    static HD Proj add_body(const Proj& p, const Proj& q)
     {
       fe t0 = F::mul(p.x, q.x);
       fe t1 = F::mul(p.y, q.y);
@@ -201,6 +212,14 @@ namespace icicle_hip {
     // Renes-Costello-Batina 2016, Algorithm 9 (a = 0), the reference's dbl (projective.h:73-99):
     // 6M + 2S + 1 mul-by-3b instead of the 14 of add(p, p).
     static HD Proj dbl(const Proj& p)
+    {
+      if constexpr (C::EXT_DEGREE == 2)
+        return dbl_call(p);
+      else
+        return dbl_body(p);
+    }
+    static EC_NOINLINE Proj dbl_call(const Proj& p) { return dbl_body(p); }
+    static HD Proj dbl_body(const Proj& p)
     {
       fe t0 = F::sqr(p.y);                 // Y^2
       fe z8 = F::dbl(F::dbl(F::dbl(t0)));  // 8Y^2            <= 8*1.2

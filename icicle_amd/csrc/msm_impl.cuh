@@ -1,0 +1,1158 @@
+// MSM for gfx950: sort-based Pippenger bucket method.
+//
+// Reference semantics: icicle/backend/cpu/src/curve/cpu_msm.hpp:431-443 (batch / shared-bases /
+// precompute layout), :259-314 (signed digits, skip zero bases), :455-480 (precompute contract).
+// The CPU backend gives each worker private buckets and random-access RMWs into them; on MI355X
+// the same sum is reorganised so that the only random access left is a read-only gather:
+//
+//   1. k_bases_to_mont   bases -> packed Montgomery copy in HBM (one pass, 2 field muls per point)
+//   2. k_digits          scalars -> signed c-bit digits, one u32 per (window, scalar), coalesced
+//   3. two-level counting sort of point indices by bucket, every scatter staged through an LDS
+//      tile-sort so that HBM sees runs, not 4-byte random writes:
+//        pass A  k_a_count / k_scan_a / k_a_scatter     partition by the high hb bits of the key
+//        pass B  k_b_plan / k_b_count / k_scan_buckets / k_b_scatter   sort by the low lb bits
+//      (c <= 11: pass A alone sorts by the whole key, k_a_scatter<true> + k_tables_from_a)
+//   4. k_accumulate      ONE THREAD PER BUCKET walks its sorted index list, gathers the 64 B affine
+//      point and does an XYZZ mixed add entirely in registers -- ~77 % of the time at 2^26,
+//      integer-ALU bound (v_mad_u64_u32), see DESIGN.md. Buckets longer than `seg` points are
+//      split (k_plan_overflow) and their partial sums folded back in parallel (k_fold_overflow).
+//   5. bucket reduction: k_reduce_segments (running sums per segment) -> k_reduce_window (256
+//      lanes per window) -> k_final (128 lanes per MSM, Horner over windows).
+// A batch of MSMs is folded into the window dimension: all of the above is launched once for up
+// to BB MSMs x wpf windows.
+//
+// Everything is enqueued on config.stream with arena-leased temporaries (common.h TempBuf); the
+// host only blocks when the API contract requires it (is_async == false or results on host).
+#pragma once
+#include "common.h"
+#include "ec.cuh"
+#include <algorithm>
+
+namespace icicle_hip {
+
+  struct MsmPlan {
+    int bits;    // scalar bits considered
+    int c;       // window bits
+    int nwin;    // total windows W = ceil((bits+1)/c)
+    int pf;      // precompute factor
+    int wpf;     // windows per precomputed base = target windows actually accumulated
+    uint32_t nb; // buckets per window = 2^(c-1)
+    uint32_t seg; // bucket-accumulation segment size: a bucket with more points is split across threads
+  };
+
+  static MsmPlan make_plan(int n, int scalar_bits, const icicle_msm_config_t& cfg)
+  {
+    MsmPlan p;
+    p.bits = (cfg.bitsize > 0 && cfg.bitsize < scalar_bits) ? cfg.bitsize : scalar_bits;
+    p.pf = std::max(1, cfg.precompute_factor);
+    int c = cfg.c;
+    if (c <= 0) {
+      // minimise  (#mixed adds) + (bucket-reduction adds, weighted for their poor parallelism)
+      double best = 1e300;
+      for (int cc = 2; cc <= 21; cc++) {
+        const int w = (p.bits + 1 + cc - 1) / cc;
+        const int wpf = (w + p.pf - 1) / p.pf;
+        // per bucket: ~2 complete adds (14 muls each) in the reduction vs 10 muls per mixed add, plus
+        // the traffic of writing/reading the bucket; weight 8 also penalises its poorer parallelism
+        const double cost = (double)w * n + 8.0 * wpf * (double)(1u << (cc - 1));
+        if (cost < best) {
+          best = cost;
+          c = cc;
+        }
+      }
+    }
+    c = std::min(21, std::max(2, c)); // two-level sort: 2^hb partitions (pass A) x 2^lb bins (pass B), hb, lb <= 10
+    p.c = c;
+    p.nwin = (p.bits + 1 + c - 1) / c;
+    p.wpf = (p.nwin + p.pf - 1) / p.pf;
+    p.nb = 1u << (c - 1);
+    {
+      const double avg = (double)n * p.pf * ((double)p.nwin / p.wpf) / (double)p.nb; // points per bucket
+      uint32_t sgm = 64;
+      while ((double)sgm < 2.0 * avg)
+        sgm <<= 1;
+      p.seg = sgm;
+    }
+    return p;
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // 1. bases -> packed Montgomery (thread per coordinate)
+  template <class C>
+  __global__ __launch_bounds__(256) void k_bases_to_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t ncoord, bool in_refmont)
+  {
+    using F = typename EC<C>::F;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= ncoord) return;
+    uint32_t w[F::N32];
+#pragma unroll
+    for (int i = 0; i < F::N32; i++)
+      w[i] = in[t * F::N32 + i];
+    typename F::fe v = in_refmont ? F::from_refmont(w) : F::from_canonical(w);
+    F::pack(w, F::reduce(v));
+#pragma unroll
+    for (int i = 0; i < F::N32; i++)
+      out[t * F::N32 + i] = w[i];
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // 2+3. signed digits and a two-level counting sort of point indices by bucket.
+  //
+  // A single-level scatter into 2^(c-1) bucket lists writes 4 bytes to a random one of 32768 open
+  // cache lines per element -- measured 29 ms of the first version's 144 ms (profiles/
+  // r01_v1_kernel_stats.txt), almost all write amplification (8.6x, profiles/r01_notes.md). Here
+  // every block first sorts its tile in LDS and then writes each bin's run contiguously:
+  //   k_digits: one pass over the scalars, digit array dig[window][scalar] in HBM (4 B each).
+  //   pass A:   block (b, window) owns digits [b*chunk, (b+1)*chunk) of that window and partitions
+  //             them by the HIGH hb bits of the bucket key. Element = sign | low key bits | j |
+  //             index within chunk.
+  //   pass B:   blocks own sub-chunks (<= 2^17 elements) of one (window, partition) and sort them
+  //             by the LOW lb key bits; each (tile, bin) run reserves its slot in the bucket with
+  //             one global atomic. The source block of an element (needed to rebuild its global
+  //             scalar index) is found by a binary search in the partition's per-block offset row.
+  // Output is what bucket accumulation consumes: count[], offs[], sorted[] (point index | sign<<31).
+  struct SortPlan {
+    int hb, lb;       // high / low bucket-key bits, hb + lb = c - 1
+    int jb;           // bits for the precompute index j
+    int chunk_log;    // scalars per pass-A block = 2^chunk_log
+    int nblk;         // pass-A blocks
+  };
+
+  // digit word: |d| | (d<0)<<31, |d| in [0, 2^(c-1)], 0 = skip. Signed recoding as cpu_msm.hpp:289-295.
+  struct DigitIter {
+    uint32_t w[9];
+    uint32_t carry = 0;
+    __device__ __forceinline__ uint32_t next(int wi, int c)
+    {
+      const int bit = wi * c;
+      const int word = bit >> 5, sh = bit & 31;
+      uint32_t v = 0;
+      if (word < 8) {
+        const uint64_t two = ((uint64_t)w[word + 1] << 32) | w[word];
+        v = (uint32_t)(two >> sh) & ((1u << c) - 1);
+      }
+      v += carry;
+      const uint32_t half = 1u << (c - 1);
+      if (v > half) {
+        carry = 1;
+        const uint32_t d = (1u << c) - v;
+        return d ? (d | 0x80000000u) : 0u;
+      }
+      carry = 0;
+      return v;
+    }
+  };
+
+  template <class C>
+  __device__ __forceinline__ void load_scalar(DigitIter& it, const uint32_t* __restrict__ scalars, size_t i, bool scalars_refmont)
+  {
+    using FR = FieldOps<typename C::fr>;
+    static_assert(FR::N32 == 8, "scalar fields here are 8 x u32");
+    const uint4* p = reinterpret_cast<const uint4*>(scalars + i * 8);
+    const uint4 lo = p[0], hi = p[1];
+    it.w[0] = lo.x, it.w[1] = lo.y, it.w[2] = lo.z, it.w[3] = lo.w;
+    it.w[4] = hi.x, it.w[5] = hi.y, it.w[6] = hi.z, it.w[7] = hi.w;
+    if (scalars_refmont) { // x*2^256 -> x  (cpu_msm.hpp:274-275 from_montgomery)
+      typename FR::fe cst;
+#pragma unroll
+      for (int k = 0; k < FR::N; k++)
+        cst.l[k] = C::fr::REFMONT_TO_CANON[k];
+      BF_SET_BOUND(cst, 1);
+      FR::pack(it.w, FR::reduce(FR::mul(FR::unpack(it.w), cst)));
+    }
+    it.w[8] = 0;
+    it.carry = 0;
+  }
+
+  // digits of all windows, dig[wi*n + i] (coalesced 4-byte writes; read back window by window)
+  template <class C>
+  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, size_t nscal, int c, int nwin, bool scalars_refmont)
+  {
+    // nscal = (MSMs in this launch) * n scalars; row (b*nwin + wi) of `dig` holds window wi of MSM b
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nscal) return;
+    const size_t b = t / n, i = t - b * n;
+    DigitIter it;
+    load_scalar<C>(it, scalars, t, scalars_refmont);
+    for (int wi = 0; wi < nwin; wi++)
+      dig[(b * nwin + wi) * n + i] = it.next(wi, c);
+  }
+
+  // exclusive prefix of one value per thread over the block (blockDim.x a multiple of 64, <= 1024);
+  // wsum: >= 17 words of LDS scratch
+  __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wsum)
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+      const uint32_t t = lane < nwv ? wsum[lane] : 0;
+      uint32_t sft = t;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t y = __shfl_up(sft, d);
+        if (lane >= d) sft += y;
+      }
+      if (lane < nwv) wsum[lane] = sft - t;
+    }
+    __syncthreads();
+    const uint32_t r = x - v + wsum[wave];
+    __syncthreads();
+    return r;
+  }
+
+  // Tile sort in LDS: a block ranks TS = 16 * blockDim elements by destination, stages them sorted,
+  // and writes each destination's run contiguously -- HBM sees >= 64-byte runs instead of 4-byte
+  // scatters (the unstaged scatter wrote 30 GB to place 3.5 GB, profiles/r01_notes.md).
+  constexpr int SORT_EPT = 16;                 // elements per thread per tile
+  constexpr uint32_t SORT_TS = 1024 * SORT_EPT; // tile size with 1024 threads
+  struct TileLds {
+    uint32_t* cnt;   // [D] per-destination count of this tile -> reused as tile-local offset
+    uint32_t* gbase; // [D] global position of this tile's run per destination
+    uint32_t* stage; // [SORT_TS]
+    uint16_t* sdest; // [SORT_TS]
+    uint32_t* wsum;  // [32]
+  };
+  __device__ __forceinline__ TileLds tile_lds(uint32_t* lds, uint32_t D)
+  {
+    TileLds t;
+    t.cnt = lds;
+    t.gbase = lds + D;
+    t.stage = lds + 2 * D;
+    t.sdest = reinterpret_cast<uint16_t*>(lds + 2 * D + SORT_TS);
+    t.wsum = lds + 2 * D + SORT_TS + SORT_TS / 2;
+    return t;
+  }
+  __host__ __device__ static inline size_t tile_lds_bytes(uint32_t D) { return ((size_t)2 * D + SORT_TS + SORT_TS / 2 + 32) * 4; }
+
+  // pass A count: block (b, wl) histograms the high key bits of scalar chunk b for target window w0+wl
+  static __global__ __launch_bounds__(1024) void k_a_count(const uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int nwin, int wpf, int pf, SortPlan sp)
+  {
+    // wl = (MSM index in this launch) * wpf + target window
+    extern __shared__ uint32_t lds[];
+    const int b = blockIdx.x, wl = blockIdx.y, wp = wl % wpf;
+    const size_t rowbase = (size_t)(wl / wpf) * nwin;
+    const uint32_t D = 1u << sp.hb;
+    for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
+      lds[k] = 0;
+    __syncthreads();
+    const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
+    for (int j = 0; j < pf; j++) {
+      const int wi = j * wpf + wp;
+      if (wi >= nwin) break;
+      const uint32_t* d = dig + (rowbase + wi) * n;
+      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t key = d[i] & 0x7fffffffu;
+        if (key) atomicAdd(&lds[(key - 1) >> sp.lb], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
+      cntA[(((size_t)wl << sp.hb) + k) * sp.nblk + b] = lds[k];
+  }
+
+  // pass A scatter: element = sign | low key bits | j | index within chunk, into partition runs
+  // FINAL: single-level sort (lb == 0): the element is already the bucket-list entry (point index | sign)
+  template <bool FINAL>
+  __global__ __launch_bounds__(1024) void k_a_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int nwin, int wpf, int pf, SortPlan sp, size_t cap)
+  {
+    extern __shared__ uint32_t lds[];
+    const int b = blockIdx.x, wl = blockIdx.y, wp = wl % wpf;
+    const size_t rowbase = (size_t)(wl / wpf) * nwin;
+    const uint32_t D = 1u << sp.hb;
+    TileLds t = tile_lds(lds, D);
+    uint32_t* cursor = lds + tile_lds_bytes(D) / 4; // [D] running write position per destination
+    for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
+      cursor[k] = offA[(((size_t)wl << sp.hb) + k) * sp.nblk + b];
+    __syncthreads();
+    const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
+    const uint32_t lmask = (1u << sp.lb) - 1;
+    uint32_t* dst = outA + (size_t)wl * cap;
+    for (int j = 0; j < pf; j++) {
+      const int wi = j * wpf + wp;
+      if (wi >= nwin) break;
+      const uint32_t* d = dig + (rowbase + wi) * n;
+      for (int tile0 = lo; tile0 < hi; tile0 += SORT_TS) {
+        if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t el[SORT_EPT], dr[SORT_EPT]; // element, (dest << 16 | rank)
+#pragma unroll
+        for (int it = 0; it < SORT_EPT; it++) {
+          const int i = tile0 + it * 1024 + threadIdx.x;
+          dr[it] = 0xffffffffu;
+          if (i < hi) {
+            const uint32_t dv = d[i];
+            const uint32_t key = dv & 0x7fffffffu;
+            if (key) {
+              const uint32_t km = key - 1, h = km >> sp.lb;
+              el[it] = FINAL ? (((uint32_t)i * (uint32_t)pf + (uint32_t)j) | (dv & 0x80000000u))
+                             : ((dv & 0x80000000u) | ((km & lmask) << (31 - sp.lb)) | ((uint32_t)j << (31 - sp.lb - sp.jb)) | (uint32_t)(i - lo));
+              dr[it] = (h << 16) | atomicAdd(&t.cnt[h], 1u);
+            }
+          }
+        }
+        __syncthreads();
+        const uint32_t mycnt = threadIdx.x < D ? t.cnt[threadIdx.x] : 0;
+        const uint32_t toff = block_exscan(mycnt, t.wsum);
+        if (threadIdx.x < D) {
+          t.cnt[threadIdx.x] = toff; // now the tile-local offset
+          t.gbase[threadIdx.x] = cursor[threadIdx.x];
+          cursor[threadIdx.x] += mycnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SORT_EPT; it++)
+          if (dr[it] != 0xffffffffu) {
+            const uint32_t h = dr[it] >> 16, pos = t.cnt[h] + (dr[it] & 0xffffu);
+            t.stage[pos] = el[it];
+            t.sdest[pos] = (uint16_t)h;
+          }
+        __syncthreads();
+        const uint32_t ntile = t.cnt[D - 1] + (cursor[D - 1] - t.gbase[D - 1]);
+        for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += blockDim.x) {
+          const uint32_t h = t.sdest[sidx];
+          dst[t.gbase[h] + (sidx - t.cnt[h])] = t.stage[sidx];
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  // exclusive scan of one window's [2^hb][nblk] counters (partition-major, block-minor), in place
+  // into offA (positions relative to the window's region); one 1024-thread block per window.
+  static __global__ __launch_bounds__(1024) void k_scan_a(const uint32_t* __restrict__ cntA, uint32_t* __restrict__ offA, uint32_t m)
+  {
+    __shared__ uint32_t part[1024];
+    const size_t base = (size_t)blockIdx.x * m;
+    const uint32_t per = (m + 1023) / 1024;
+    const uint32_t lo = min(m, threadIdx.x * per), hi = min(m, lo + per);
+    uint32_t s = 0;
+    for (uint32_t k = lo; k < hi; k++)
+      s += cntA[base + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t k = lo; k < hi; k++) {
+      const uint32_t x = cntA[base + k];
+      offA[base + k] = run;
+      run += x;
+    }
+    if (threadIdx.x == 1023) offA[(size_t)gridDim.x * m + blockIdx.x] = part[1023]; // window total
+  }
+
+  // single-level sort (lb == 0): bucket k of window wl IS partition k; count/offs come from pass A's table
+  static __global__ __launch_bounds__(256) void k_tables_from_a(const uint32_t* __restrict__ offA, uint32_t* __restrict__ count, uint32_t* __restrict__ offs, size_t nbk, uint32_t nb, int nblk, size_t totals_base)
+  {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nbk) return;
+    const size_t wl = t / nb;
+    const uint32_t k = (uint32_t)(t - wl * nb);
+    const uint32_t ps = offA[t * nblk];
+    const uint32_t pe = (k + 1 < nb) ? offA[(t + 1) * nblk] : offA[totals_base + wl];
+    offs[t] = ps;
+    count[t] = pe - ps;
+  }
+
+  // pass B. A partition (window wp, high key bits h) is cut into sub-chunks of CHUNKB elements, one
+  // block each, so neither a sparse top window nor skewed scalars can serialise it on one block.
+  // k_b_plan turns partition sizes into a block -> (partition, sub-chunk) table; k_b_count adds LDS
+  // histograms of the low lb key bits into count[]; k_scan_buckets makes offs[]/cursor[];
+  // k_b_scatter reserves a range per (block, bin) with ONE global atomic and ranks inside it in LDS.
+  constexpr uint32_t CHUNKB_LOG = 17;
+
+  static __global__ __launch_bounds__(1024) void k_b_plan(const uint32_t* __restrict__ offA, uint32_t* __restrict__ bstart, uint32_t nparts, int wpf, int hb, int nblk)
+  {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nparts + 1023) / 1024;
+    const uint32_t lo = min(nparts, threadIdx.x * per), hi = min(nparts, lo + per);
+    const uint32_t nparts_w = 1u << hb;
+    auto psize = [&](uint32_t p) -> uint32_t {
+      const uint32_t wp = p >> hb, h = p & (nparts_w - 1);
+      const size_t row = (size_t)p * nblk;
+      const uint32_t ps = offA[row];
+      const uint32_t pe = (h + 1 < nparts_w) ? offA[row + nblk] : offA[(size_t)wpf * nparts_w * nblk + wp];
+      return pe - ps;
+    };
+    uint32_t s = 0;
+    for (uint32_t p = lo; p < hi; p++)
+      s += (psize(p) + (1u << CHUNKB_LOG) - 1) >> CHUNKB_LOG;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t p = lo; p < hi; p++) {
+      bstart[p] = run;
+      run += (psize(p) + (1u << CHUNKB_LOG) - 1) >> CHUNKB_LOG;
+    }
+    if (threadIdx.x == 1023) bstart[nparts] = part[1023];
+  }
+
+  // block -> (partition p, element range [r0,r1) in the window's pass-A array); false if idle
+  __device__ __forceinline__ bool b_locate(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ offA, uint32_t nparts, int wpf, int hb, int nblk, uint32_t& p, uint32_t& r0, uint32_t& r1)
+  {
+    const uint32_t blk = blockIdx.x;
+    if (blk >= bstart[nparts]) return false;
+    uint32_t lo = 0, hi = nparts; // last p with bstart[p] <= blk
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (bstart[mid] <= blk) {
+        lo = mid;
+      } else {
+        hi = mid;
+      }
+    }
+    p = lo;
+    const uint32_t nparts_w = 1u << hb;
+    const uint32_t wp = p >> hb, h = p & (nparts_w - 1);
+    const size_t row = (size_t)p * nblk;
+    const uint32_t ps = offA[row];
+    const uint32_t pe = (h + 1 < nparts_w) ? offA[row + nblk] : offA[(size_t)wpf * nparts_w * nblk + wp];
+    r0 = ps + ((blk - bstart[p]) << CHUNKB_LOG);
+    r1 = min(pe, r0 + (1u << CHUNKB_LOG));
+    return r0 < r1;
+  }
+
+  static __global__ __launch_bounds__(1024) void k_b_count(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ count, uint32_t nparts, int wpf, SortPlan sp, size_t cap, uint32_t nb)
+  {
+    extern __shared__ uint32_t lds[];
+    uint32_t p, r0, r1;
+    if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p, r0, r1)) return;
+    const uint32_t nbins = 1u << sp.lb;
+    for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x)
+      lds[k] = 0;
+    __syncthreads();
+    const uint32_t wp = p >> sp.hb, h = p & ((1u << sp.hb) - 1);
+    const uint32_t* src = inA + (size_t)wp * cap;
+    const int lshift = 31 - sp.lb;
+    const uint32_t lmask = nbins - 1;
+    for (uint32_t pos = r0 + threadIdx.x; pos < r1; pos += blockDim.x)
+      atomicAdd(&lds[(src[pos] >> lshift) & lmask], 1u);
+    __syncthreads();
+    uint32_t* cw = count + (size_t)wp * nb + ((size_t)h << sp.lb);
+    for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x)
+      if (lds[k]) atomicAdd(&cw[k], lds[k]);
+  }
+
+  // exclusive scan over the buckets of one window: one 1024-thread block per window
+  static __global__ __launch_bounds__(1024) void k_scan_buckets(const uint32_t* __restrict__ count, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor, uint32_t nb)
+  {
+    __shared__ uint32_t part[1024];
+    const int wp = blockIdx.x;
+    const uint32_t per = (nb + 1023) / 1024;
+    const uint32_t lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
+    uint32_t s = 0;
+    for (uint32_t k = lo; k < hi; k++)
+      s += count[(size_t)wp * nb + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t k = lo; k < hi; k++) {
+      offs[(size_t)wp * nb + k] = run;
+      cursor[(size_t)wp * nb + k] = run;
+      run += count[(size_t)wp * nb + k];
+    }
+  }
+
+  static __global__ __launch_bounds__(1024) void k_b_scatter(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted, uint32_t nparts, int wpf, int pf, SortPlan sp, size_t cap, uint32_t nb)
+  {
+    extern __shared__ uint32_t lds[]; // tile-sort arrays | [nblk+1] piece offsets of this partition
+    uint32_t p, r0, r1;
+    if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p, r0, r1)) return;
+    const uint32_t D = 1u << sp.lb;
+    TileLds t = tile_lds(lds, D);
+    uint32_t* boffs = lds + tile_lds_bytes(D) / 4;
+    const uint32_t wp = p >> sp.hb, h = p & ((1u << sp.hb) - 1);
+    const uint32_t nparts_w = 1u << sp.hb;
+    const size_t row = (size_t)p * sp.nblk;
+    for (uint32_t k = threadIdx.x; k <= (uint32_t)sp.nblk; k += blockDim.x)
+      boffs[k] = (k < (uint32_t)sp.nblk) ? offA[row + k] : ((h + 1 < nparts_w) ? offA[row + sp.nblk] : offA[(size_t)wpf * nparts_w * sp.nblk + wp]);
+    __syncthreads();
+    const uint32_t* src = inA + (size_t)wp * cap;
+    uint32_t* dst = sorted + (size_t)wp * cap;
+    uint32_t* cw = cursor + (size_t)wp * nb + ((size_t)h << sp.lb);
+    const int lshift = 31 - sp.lb;
+    const uint32_t lmask = D - 1;
+    const uint32_t imask = (1u << (31 - sp.lb - sp.jb)) - 1;
+    const uint32_t jmask = (1u << sp.jb) - 1;
+    for (uint32_t tile0 = r0; tile0 < r1; tile0 += SORT_TS) {
+      if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
+      __syncthreads();
+      uint32_t el[SORT_EPT], dr[SORT_EPT];
+#pragma unroll
+      for (int it = 0; it < SORT_EPT; it++) {
+        const uint32_t pos = tile0 + it * 1024 + threadIdx.x;
+        dr[it] = 0xffffffffu;
+        if (pos < r1) {
+          const uint32_t e = src[pos];
+          // source block (scalar chunk) of this element: last bsrc with boffs[bsrc] <= pos
+          uint32_t blo = 0, bhi = sp.nblk;
+          while (bhi - blo > 1) {
+            const uint32_t mid = (blo + bhi) >> 1;
+            if (boffs[mid] <= pos) {
+              blo = mid;
+            } else {
+              bhi = mid;
+            }
+          }
+          const uint32_t i = (blo << sp.chunk_log) + (e & imask);
+          const uint32_t j = (e >> (31 - sp.lb - sp.jb)) & jmask;
+          const uint32_t bin = (e >> lshift) & lmask;
+          el[it] = (i * (uint32_t)pf + j) | (e & 0x80000000u);
+          dr[it] = (bin << 16) | atomicAdd(&t.cnt[bin], 1u);
+        }
+      }
+      __syncthreads();
+      const uint32_t mycnt = threadIdx.x < D ? t.cnt[threadIdx.x] : 0;
+      const uint32_t toff = block_exscan(mycnt, t.wsum);
+      if (threadIdx.x < D) {
+        t.cnt[threadIdx.x] = toff;
+        t.gbase[threadIdx.x] = mycnt ? atomicAdd(&cw[threadIdx.x], mycnt) : 0u; // reserve the run in the bucket list
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < SORT_EPT; it++)
+        if (dr[it] != 0xffffffffu) {
+          const uint32_t bin = dr[it] >> 16, pos = t.cnt[bin] + (dr[it] & 0xffffu);
+          t.stage[pos] = el[it];
+          t.sdest[pos] = (uint16_t)bin;
+        }
+      __syncthreads();
+      const uint32_t ntile = min(r1 - tile0, SORT_TS);
+      for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += blockDim.x) {
+        const uint32_t bin = t.sdest[sidx];
+        dst[t.gbase[bin] + (sidx - t.cnt[bin])] = t.stage[sidx];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // 4. bucket accumulation. Thread t < nbk owns bucket t and accumulates its first `seg` points
+  //    (XYZZ accumulator in registers); a bucket with more points (sparse top window, skewed scalars:
+  //    wrappers/rust/icicle-core/src/msm/tests.rs:256-304) gets overflow segments of `seg` points each,
+  //    planned by k_plan_overflow, accumulated by threads t >= nbk and folded in by k_fold_overflow.
+  struct OvfSeg {
+    uint32_t bucket; // global bucket id
+    uint32_t start;  // first point of this segment inside the bucket
+    uint32_t first;  // 1 if this is the first overflow segment of its bucket
+    uint32_t nextra; // number of overflow segments of the bucket (valid when first)
+  };
+
+  static __global__ __launch_bounds__(256) void k_plan_overflow(const uint32_t* __restrict__ count, size_t nbk, uint32_t seg, uint32_t* __restrict__ ovf_count, OvfSeg* __restrict__ ovf, uint32_t ovf_cap)
+  {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= nbk) return;
+    const uint32_t cnt = count[t];
+    if (cnt <= seg) return;
+    const uint32_t extra = (cnt + seg - 1) / seg - 1;
+    const uint32_t slot = atomicAdd(ovf_count, extra);
+    for (uint32_t sgi = 0; sgi < extra && slot + sgi < ovf_cap; sgi++) {
+      OvfSeg o;
+      o.bucket = (uint32_t)t;
+      o.start = (sgi + 1) * seg;
+      o.first = (sgi == 0);
+      o.nextra = extra;
+      ovf[slot + sgi] = o;
+    }
+  }
+
+  template <class C, int MINW>
+  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
+  {
+    // bases_stride: words between the base arrays of consecutive MSMs of a batch (0 = shared bases)
+    using E = EC<C>;
+    constexpr int PW = 2 * E::N32; // words per affine point
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t bucket;
+    uint32_t start;
+    typename E::Proj* dst;
+    if (t < nbk) {
+      bucket = t;
+      start = 0;
+      dst = buckets + t;
+    } else {
+      const size_t o = t - nbk;
+      if (o >= *ovf_count) return;
+      bucket = ovf[o].bucket;
+      start = ovf[o].start;
+      dst = ovf_part + o;
+    }
+    const size_t wp = bucket / nb; // window index within the launch = (MSM index) * wpf + target window
+    bases_mont += (wp / wpf) * bases_stride;
+    const uint32_t total = count[bucket];
+    const uint32_t cnt = min(total - min(total, start), seg);
+    const uint32_t* src = sorted + wp * cap + offs[bucket] + start;
+    typename E::XYZZ acc;
+    bool empty = true;
+    for (uint32_t j = 0; j < cnt; j++) {
+      const uint32_t e = src[j];
+      const uint4* p = reinterpret_cast<const uint4*>(bases_mont + (size_t)(e & 0x7fffffffu) * PW);
+      uint32_t w[PW];
+#pragma unroll
+      for (int q = 0; q < PW / 4; q++) {
+        const uint4 v = p[q];
+        w[4 * q] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
+      }
+      if (E::words_are_zero(w)) continue; // identity base: contributes nothing (cpu_msm.hpp:282)
+      typename E::Aff a = E::cneg(E::load_mont(w), (e >> 31) != 0);
+      E::madd(acc, empty, a);
+    }
+    *dst = E::to_proj(acc, empty);
+  }
+
+  // buckets[b] += its overflow partials: one 64-lane block per overflowing bucket at a time (lanes fold
+  // strided partials, then a tree through LDS), so a bucket with thousands of segments -- a 1-bit top
+  // window, all-equal scalars -- costs log-depth, not a serial chain.
+  template <class C>
+  __global__ __launch_bounds__(64) void k_fold_overflow(typename EC<C>::Proj* __restrict__ buckets, const typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t ovf_cap)
+  {
+    using E = EC<C>;
+    __shared__ typename E::Proj sh[64];
+    const uint32_t n = min(*ovf_count, ovf_cap);
+    const int lane = threadIdx.x;
+    for (uint32_t o = blockIdx.x; o < n; o += gridDim.x) {
+      if (!ovf[o].first) continue; // block-uniform
+      const uint32_t ne = min(ovf[o].nextra, n - o);
+      typename E::Proj v = E::proj_identity();
+      for (uint32_t k = lane; k < ne; k += 64)
+        v = E::add(v, ovf_part[o + k]);
+      sh[lane] = v;
+      __syncthreads();
+      for (int s = 32; s >= 1; s >>= 1) {
+        if (lane < s) {
+          v = E::add(v, sh[lane + s]);
+          sh[lane] = v;
+        }
+        __syncthreads();
+      }
+      if (lane == 0) buckets[ovf[o].bucket] = E::add(buckets[ovf[o].bucket], v);
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // 5a. per-segment running sums. Segment = m consecutive buckets [k0, k0+m) of one window;
+  //     val = sum_{k} (k+1) * B_k  =  tri + k0 * line   (bucket index k carries weight k+1).
+  template <class C>
+  __global__ __launch_bounds__(64) void k_reduce_segments(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ segval, uint32_t nb, uint32_t m, int wpf)
+  {
+    using E = EC<C>;
+    const uint32_t nseg = nb / m;
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= (size_t)wpf * nseg) return;
+    const size_t wp = t / nseg;
+    const uint32_t seg = t % nseg;
+    const uint32_t k0 = seg * m;
+    const typename E::Proj* b = buckets + wp * nb + k0;
+    typename E::Proj line = E::proj_identity(), tri = E::proj_identity();
+    for (int k = (int)m - 1; k >= 0; k--) {
+      line = E::add(line, b[k]);
+      tri = E::add(tri, line);
+    }
+    if (k0) tri = E::add(tri, E::mul_small(line, k0));
+    segval[t] = tri;
+  }
+
+  // 5b. one 256-thread block per window (128 where 256 projective points would not fit the 64 KiB
+  //     of static LDS, i.e. G2 over BLS12-381): each thread folds nseg/RWL segment values, then a tree
+  //     through LDS (4 waves keep the serial part short: it is latency-, not throughput-bound)
+  template <class C>
+  struct ReduceWindowLanes {
+    static constexpr int value = (sizeof(typename EC<C>::Proj) * 256 <= 60 * 1024) ? 256 : 128;
+  };
+  template <class C>
+  __global__ __launch_bounds__(ReduceWindowLanes<C>::value) void k_reduce_window(const typename EC<C>::Proj* __restrict__ segval, typename EC<C>::Proj* __restrict__ winsum, uint32_t nseg)
+  {
+    using E = EC<C>;
+    constexpr int RWL = ReduceWindowLanes<C>::value;
+    __shared__ typename E::Proj sh[RWL];
+    const int wp = blockIdx.x, lane = threadIdx.x;
+    typename E::Proj v = E::proj_identity();
+    for (uint32_t s = lane; s < nseg; s += RWL)
+      v = E::add(v, segval[(size_t)wp * nseg + s]);
+    sh[lane] = v;
+    __syncthreads();
+    for (int s = RWL / 2; s >= 1; s >>= 1) {
+      if (lane < s) {
+        v = E::add(v, sh[lane + s]);
+        sh[lane] = v;
+      }
+      __syncthreads();
+    }
+    if (lane == 0) winsum[wp] = v;
+  }
+
+  // 5c. window combine: result = sum_w 2^(c*w) * winsum[w], written in the reference's
+  //     projective_t layout (canonical words). One 128-lane block: lane w scales its own window
+  //     sum by c*w doublings (the same critical path as a serial Horner, but the doublings of
+  //     different windows overlap), then a tree through LDS. <1 % of the work.
+  //     (A <<<1,1>>> serial Horner is provably wave-uniform, so hipcc compiles ALL of its field
+  //     arithmetic to SALU code, which is several times slower per multiply than the VALU path.)
+  template <class C>
+  __global__ __launch_bounds__(128) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c)
+  {
+    using E = EC<C>;
+    __shared__ typename E::Proj sh[128];
+    const int lane = threadIdx.x;
+    winsum += (size_t)blockIdx.x * wpf;
+    result += (size_t)blockIdx.x * 3 * E::N32;
+    typename E::Proj v = E::proj_identity();
+    if (lane < wpf) {
+      v = winsum[lane];
+      for (int i = 0; i < lane * c; i++)
+        v = E::dbl(v);
+    }
+    sh[lane] = v;
+    __syncthreads();
+    for (int s = 64; s >= 1; s >>= 1) {
+      if (lane < s) {
+        v = E::add(v, sh[lane + s]);
+        sh[lane] = v;
+      }
+      __syncthreads();
+    }
+    if (lane == 0) E::store_proj_canonical(result, v);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // projective (Montgomery) -> affine words; identity -> (0,0)
+  template <class C>
+  __device__ void store_affine(uint32_t* w, const typename EC<C>::Proj& p, bool refmont)
+  {
+    using E = EC<C>;
+    using F = typename E::F;
+    if (F::is_zero(p.z)) {
+      for (int i = 0; i < 2 * E::N32; i++)
+        w[i] = 0;
+      return;
+    }
+    typename F::fe zi = F::inv(p.z); // cold path (precompute / generator)
+    typename F::fe x = F::mul(p.x, zi), y = F::mul(p.y, zi);
+    if (refmont) {
+      F::to_refmont(w, x);
+      F::to_refmont(w + E::N32, y);
+    } else {
+      F::to_canonical(w, x);
+      F::to_canonical(w + E::N32, y);
+    }
+  }
+
+  // msm_precompute_bases: out[pf*i + j] = 2^(j*shift) * P_i  (cpu_msm.hpp:455-480), shift = c*wpf
+  template <class C>
+  __global__ __launch_bounds__(64) void k_precompute(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, int pf, int shift, bool refmont)
+  {
+    using E = EC<C>;
+    using F = typename E::F;
+    constexpr int PW = 2 * E::N32;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[PW];
+    for (int k = 0; k < PW; k++) {
+      w[k] = in[(size_t)i * PW + k];
+      out[(size_t)i * pf * PW + k] = w[k];
+    }
+    typename E::Proj p;
+    if (E::words_are_zero(w)) {
+      p = E::proj_identity();
+    } else {
+      typename E::Aff a;
+      a.x = refmont ? F::from_refmont(w) : F::from_canonical(w);
+      a.y = refmont ? F::from_refmont(w + E::N32) : F::from_canonical(w + E::N32);
+      p = E::to_proj(a);
+    }
+    for (int j = 1; j < pf; j++) {
+      for (int s = 0; s < shift; s++)
+        p = E::dbl(p);
+      uint32_t o[PW];
+      store_affine<C>(o, p, refmont);
+      for (int k = 0; k < PW; k++)
+        out[((size_t)i * pf + j) * PW + k] = o[k];
+    }
+  }
+
+  // synthetic distinct points (k0 + i) * G, i < n; each thread produces L consecutive points
+  template <class C>
+  __global__ __launch_bounds__(64) void k_generate(uint32_t* __restrict__ out, int n, uint64_t k0, int L)
+  {
+    using E = EC<C>;
+    constexpr int PW = 2 * E::N32;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long first = (long long)t * L;
+    if (first >= n) return;
+    const typename E::Proj g = E::to_proj(E::generator());
+    uint64_t k = k0 + (uint64_t)first;
+    typename E::Proj p = E::proj_identity();
+    for (int b = 63; b >= 0; b--) {
+      p = E::dbl(p);
+      if ((k >> b) & 1) p = E::add(p, g);
+    }
+    for (int j = 0; j < L && first + j < n; j++) {
+      uint32_t o[PW];
+      store_affine<C>(o, p, false);
+      for (int q = 0; q < PW; q++)
+        out[((size_t)first + j) * PW + q] = o[q];
+      p = E::add(p, g);
+    }
+  }
+
+  // sum of n projective points in the reference's canonical layout (multi-GPU partial-result combine)
+  template <class C>
+  __global__ __launch_bounds__(64) void k_proj_sum(const uint32_t* __restrict__ pts, int n, uint32_t* __restrict__ out)
+  {
+    using E = EC<C>;
+    using F = typename E::F;
+    __shared__ typename E::Proj sh[64];
+    const int lane = threadIdx.x;
+    typename E::Proj v = E::proj_identity();
+    for (int i = lane; i < n; i += 64) {
+      const uint32_t* w = pts + (size_t)i * 3 * E::N32;
+      typename E::Proj p;
+      p.x = F::from_canonical(w);
+      p.y = F::from_canonical(w + E::N32);
+      p.z = F::from_canonical(w + 2 * E::N32);
+      v = E::add(v, p);
+    }
+    sh[lane] = v;
+    __syncthreads();
+    for (int s = 32; s >= 1; s >>= 1) {
+      if (lane < s) {
+        v = E::add(v, sh[lane + s]);
+        sh[lane] = v;
+      }
+      __syncthreads();
+    }
+    if (lane == 0) E::store_proj_canonical(out, v);
+  }
+
+  template <class C>
+  static icicle_error_t proj_sum_run(const void* pts, int n, void* out, hipStream_t st)
+  {
+    if (n < 0 || !out || (n > 0 && !pts)) return ICICLE_INVALID_ARGUMENT;
+    ICICLE_TRY(bind_current_device());
+    k_proj_sum<C><<<1, 64, 0, st>>>((const uint32_t*)pts, n, (uint32_t*)out);
+    LAUNCH_CHECK("k_proj_sum", st);
+    return ICICLE_SUCCESS;
+  }
+
+  // ------------------------------------------------------------------------------------------
+  template <class C>
+  static icicle_error_t msm_run(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v)
+  {
+    using E = EC<C>;
+    using FR = FieldOps<typename C::fr>;
+    constexpr int PW = 2 * E::N32, RW = 3 * E::N32;
+    if (!cfg || !results_v || n < 0) return ICICLE_INVALID_ARGUMENT;
+    const int batch = std::max(1, cfg->batch_size);
+    if (n > 0 && (!scalars_v || !bases_v)) return ICICLE_INVALID_POINTER;
+    ICICLE_TRY(bind_current_device());
+    hipStream_t st = (hipStream_t)cfg->stream;
+    const MsmPlan pl = make_plan(std::max(n, 1), C::fr::NBITS, *cfg);
+    const int pf = pl.pf;
+    if ((long long)n * pf >= (1ll << 31)) return ICICLE_INVALID_ARGUMENT;
+    const bool shared = cfg->are_points_shared_in_batch || batch == 1;
+    const size_t npts_one = (size_t)n * pf;
+    const size_t npts_all = shared ? npts_one : npts_one * batch;
+
+    // ---- result buffer
+    TempBuf d_res_tmp;
+    uint32_t* d_res = (uint32_t*)results_v;
+    if (!cfg->are_results_on_device) {
+      HIP_TRY(d_res_tmp.alloc((size_t)batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
+      d_res = d_res_tmp.as<uint32_t>();
+    }
+
+    if (n == 0) { // empty sum = identity for every batch element
+      std::vector<uint32_t> id((size_t)batch * RW, 0);
+      for (int b = 0; b < batch; b++)
+        id[(size_t)b * RW + E::N32] = 1; // (0:1:0)
+      HIP_TRY(hipMemcpyAsync(d_res, id.data(), id.size() * 4, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
+      HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+      if (!cfg->are_results_on_device) HIP_TRY(hipMemcpy(results_v, d_res, id.size() * 4, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
+      return ICICLE_SUCCESS;
+    }
+
+    // ---- stage inputs
+    TempBuf d_sc_tmp, d_b_tmp;
+    const uint32_t* d_scalars = (const uint32_t*)scalars_v;
+    if (!cfg->are_scalars_on_device) {
+      const size_t bytes = (size_t)batch * n * FR::N32 * 4;
+      HIP_TRY(d_sc_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(hipMemcpyAsync(d_sc_tmp.ptr(), scalars_v, bytes, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
+      d_scalars = d_sc_tmp.as<uint32_t>();
+    }
+    const uint32_t* d_bases = (const uint32_t*)bases_v;
+    if (!cfg->are_points_on_device) {
+      const size_t bytes = npts_all * PW * 4;
+      HIP_TRY(d_b_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(hipMemcpyAsync(d_b_tmp.ptr(), bases_v, bytes, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
+      d_bases = d_b_tmp.as<uint32_t>();
+    }
+
+    // ---- geometry
+    const uint32_t nb = pl.nb;
+    const int wpf = pl.wpf;
+    const size_t cap = npts_one; // bucket-list capacity per target window
+    SortPlan sp;
+    {
+      const int kb = pl.c - 1;
+      // each tile-sorted pass ranks into <= 1024 destinations (one per thread of the block); small
+      // windows (kb <= 10) need a single level: pass A already produces the bucket lists
+      int hb = kb <= 10 ? kb : (kb + 1) / 2;
+      if (const char* e = getenv("ICICLE_HIP_MSM_HB")) hb = atoi(e);
+      hb = std::max(kb - 10, std::min(std::min(kb, 10), hb));
+      if (hb < 0 || hb > 10 || kb - hb > 10) return ICICLE_INVALID_ARGUMENT;
+      sp.hb = hb;
+      sp.lb = kb - hb;
+      sp.jb = 0;
+      while ((1 << sp.jb) < pf)
+        sp.jb++;
+      int logn = 0;
+      while (((size_t)1 << logn) < (size_t)n)
+        logn++;
+      const int max_chunk = 31 - sp.lb - sp.jb;
+      if (max_chunk < 10) return ICICLE_INVALID_ARGUMENT;
+      sp.chunk_log = std::max(10, std::min(max_chunk, std::max(17, logn - 9)));
+      if (sp.chunk_log < logn - 9) return ICICLE_INVALID_ARGUMENT; // would need more than 512 pass-A blocks per window
+      sp.nblk = (int)(((size_t)n + ((size_t)1 << sp.chunk_log) - 1) >> sp.chunk_log);
+    }
+    const bool single_level = (sp.lb == 0);
+    const size_t nparts_w = (size_t)1 << sp.hb;
+    const uint32_t m = std::min<uint32_t>(nb, 32);
+    const uint32_t nseg = nb / m;
+
+    // ---- batch folding: BB MSMs of the batch run as ONE launch sequence with BB*wpf windows
+    // (wrappers/rust/icicle-core/src/msm/tests.rs:92-254 batches; small MSMs would otherwise leave the
+    // GPU idle). BB is bounded by a memory budget and by the grid.y limit.
+    const size_t per_msm_bytes = (size_t)pl.nwin * n * 4 + (single_level ? 1 : 2) * (size_t)wpf * cap * 4 + (size_t)wpf * nb * (sizeof(typename E::Proj) + 12) +
+                                 (size_t)wpf * nparts_w * sp.nblk * 8 + (shared ? 0 : npts_one * PW * 4);
+    size_t budget = (size_t)48 << 30;
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 2);
+    }
+    int BB = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / std::max<size_t>(per_msm_bytes, 1)));
+    BB = std::min(BB, std::max(1, 60000 / wpf));
+    const size_t TW = (size_t)BB * wpf; // windows per launch
+    const size_t nbk = TW * nb;
+    const size_t nparts = TW << sp.hb;
+    const size_t tabA = nparts * sp.nblk + TW; // [wl][h][b] counters + per-window totals
+    const size_t elems_max = (size_t)BB * n * pl.nwin + 1;
+    const uint32_t maxblkB = (uint32_t)std::min<size_t>(nparts + (elems_max >> CHUNKB_LOG) + 2, 0x7fffffffu);
+    const uint32_t ovf_cap = (uint32_t)std::min<size_t>(elems_max / pl.seg + 16, 0x7fffffffu);
+
+    TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt;
+    HIP_TRY(d_mont.alloc((shared ? 1 : (size_t)BB) * npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_dig.alloc((size_t)BB * pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
+    if (!single_level) HIP_TRY(d_partA.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_sorted.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_cntA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_offA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_bstart.alloc((nparts + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_count.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_offs.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_cursor.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_buckets.alloc(nbk * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_seg.alloc(TW * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_win.alloc(TW * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovfcnt.alloc(16, st), ICICLE_ALLOCATION_FAILED);
+
+    const size_t ldsA = tile_lds_bytes(1u << sp.hb) + ((size_t)4 << sp.hb);
+    const size_t ldsB = tile_lds_bytes(1u << sp.lb) + ((size_t)sp.nblk + 1) * 4;
+    if (ldsA > 156 * 1024 || ldsB > 156 * 1024) return ICICLE_INVALID_ARGUMENT;
+    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_b_count, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_b_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+
+    uint32_t* dig = d_dig.as<uint32_t>();
+    uint32_t* cntA = d_cntA.as<uint32_t>();
+    uint32_t* offA = d_offA.as<uint32_t>();
+    uint32_t* sorted = d_sorted.as<uint32_t>();
+    uint32_t* count = d_count.as<uint32_t>();
+    uint32_t* offs = d_offs.as<uint32_t>();
+    typename E::Proj* buckets = d_buckets.as<typename E::Proj>();
+
+    for (int b0 = 0; b0 < batch; b0 += BB) {
+      const int bb = std::min(BB, batch - b0); // MSMs in this launch sequence
+      const size_t tw = (size_t)bb * wpf;
+      const size_t gbk = tw * nb;
+      const size_t gparts = tw << sp.hb;
+      if (b0 == 0 || !shared) {
+        const uint32_t* src = d_bases + (shared ? 0 : (size_t)b0 * npts_one * PW);
+        const size_t ncoord = (shared ? 1 : (size_t)bb) * npts_one * 2;
+        k_bases_to_mont<C><<<dim3((unsigned)((ncoord + 255) / 256)), 256, 0, st>>>(src, d_mont.as<uint32_t>(), ncoord, cfg->are_points_montgomery_form);
+        LAUNCH_CHECK("k_bases_to_mont", st);
+      }
+      const uint32_t* sc = d_scalars + (size_t)b0 * n * FR::N32;
+      const size_t nscal = (size_t)bb * n;
+      k_digits<C><<<(unsigned)((nscal + 255) / 256), 256, 0, st>>>(sc, dig, n, nscal, pl.c, pl.nwin, cfg->are_scalars_montgomery_form);
+      LAUNCH_CHECK("k_digits", st);
+      // the per-window totals live right after the [tw][2^hb][nblk] table of THIS launch
+      k_a_count<<<dim3(sp.nblk, (unsigned)tw), 1024, ((size_t)4 << sp.hb), st>>>(dig, cntA, n, pl.nwin, wpf, pf, sp);
+      LAUNCH_CHECK("k_a_count", st);
+      k_scan_a<<<(unsigned)tw, 1024, 0, st>>>(cntA, offA, (uint32_t)(nparts_w * sp.nblk));
+      LAUNCH_CHECK("k_scan_a", st);
+      if (single_level) {
+        k_a_scatter<true><<<dim3(sp.nblk, (unsigned)tw), 1024, ldsA, st>>>(dig, offA, sorted, n, pl.nwin, wpf, pf, sp, cap);
+        LAUNCH_CHECK("k_a_scatter<final>", st);
+        k_tables_from_a<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(offA, count, offs, gbk, nb, sp.nblk, gparts * sp.nblk);
+        LAUNCH_CHECK("k_tables_from_a", st);
+      } else {
+        uint32_t* partA = d_partA.as<uint32_t>();
+        const size_t elems = (size_t)bb * n * pl.nwin + 1;
+        const uint32_t nblkB = (uint32_t)std::min<size_t>(gparts + (elems >> CHUNKB_LOG) + 2, maxblkB);
+        k_a_scatter<false><<<dim3(sp.nblk, (unsigned)tw), 1024, ldsA, st>>>(dig, offA, partA, n, pl.nwin, wpf, pf, sp, cap);
+        LAUNCH_CHECK("k_a_scatter", st);
+        k_b_plan<<<1, 1024, 0, st>>>(offA, d_bstart.as<uint32_t>(), (uint32_t)gparts, (int)tw, sp.hb, sp.nblk);
+        LAUNCH_CHECK("k_b_plan", st);
+        HIP_TRY(hipMemsetAsync(count, 0, gbk * 4, st), ICICLE_COPY_FAILED);
+        k_b_count<<<nblkB, 1024, ((size_t)1 << sp.lb) * 4, st>>>(partA, offA, d_bstart.as<uint32_t>(), count, (uint32_t)gparts, (int)tw, sp, cap, nb);
+        LAUNCH_CHECK("k_b_count", st);
+        k_scan_buckets<<<(unsigned)tw, 1024, 0, st>>>(count, offs, d_cursor.as<uint32_t>(), nb);
+        LAUNCH_CHECK("k_scan_buckets", st);
+        k_b_scatter<<<nblkB, 1024, ldsB, st>>>(partA, offA, d_bstart.as<uint32_t>(), d_cursor.as<uint32_t>(), sorted, (uint32_t)gparts, (int)tw, pf, sp, cap, nb);
+        LAUNCH_CHECK("k_b_scatter", st);
+      }
+      HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16, st), ICICLE_COPY_FAILED);
+      k_plan_overflow<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(count, gbk, pl.seg, d_ovfcnt.as<uint32_t>(), d_ovf.as<OvfSeg>(), ovf_cap);
+      LAUNCH_CHECK("k_plan_overflow", st);
+      KernelTimer::begin(0, st);
+      {
+        // waves per SIMD the register allocator must leave room for: 3 fits BN254 G1 (157 VGPRs) without
+        // spilling, 2 fits BLS12-381 G1 (14-limb elements) and BN254 G2, 1 for BLS12-381 G2
+        constexpr bool BIGPT = sizeof(typename E::XYZZ) > 256; // G2
+        static const int minw = getenv("ICICLE_HIP_MSM_ACC_WAVES") ? atoi(getenv("ICICLE_HIP_MSM_ACC_WAVES"))
+                                                                   : (BIGPT ? (sizeof(typename E::XYZZ) <= 288 ? 2 : 1) : (E::F::N <= 9 ? 3 : 2));
+        const size_t nthreads_acc = gbk + ovf_cap;
+        const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
+        const size_t bstride = shared ? 0 : npts_one * PW;
+#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), nb, gbk, cap, pl.seg, wpf, bstride
+        if constexpr (BIGPT) {
+          if constexpr (sizeof(typename E::XYZZ) <= 288) {
+            if (minw >= 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
+            else k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
+          } else {
+            k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
+          }
+        } else {
+          if (minw == 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
+          else if (minw == 4) k_accumulate<C, 4><<<gridn, 128, 0, st>>>(ACC_ARGS);
+          else if (minw == 1) k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
+          else k_accumulate<C, 3><<<gridn, 128, 0, st>>>(ACC_ARGS);
+        }
+#undef ACC_ARGS
+      }
+      LAUNCH_CHECK("k_accumulate", st);
+      KernelTimer::end(0, st);
+      k_fold_overflow<C><<<std::min<uint32_t>(ovf_cap, 4096), 64, 0, st>>>(buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
+      LAUNCH_CHECK("k_fold_overflow", st);
+      const size_t nsg = tw * nseg;
+      k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(buckets, d_seg.as<typename E::Proj>(), nb, m, (int)tw);
+      LAUNCH_CHECK("k_reduce_segments", st);
+      k_reduce_window<C><<<(unsigned)tw, ReduceWindowLanes<C>::value, 0, st>>>(d_seg.as<typename E::Proj>(), d_win.as<typename E::Proj>(), nseg);
+      LAUNCH_CHECK("k_reduce_window", st);
+      k_final<C><<<bb, 128, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c);
+      LAUNCH_CHECK("k_final", st);
+    }
+    HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
+
+    if (!cfg->are_results_on_device) {
+      HIP_TRY(hipMemcpyAsync(results_v, d_res, (size_t)batch * RW * 4, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
+      HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    } else if (!cfg->is_async) {
+      HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    }
+    return ICICLE_SUCCESS;
+  }
+
+  template <class C>
+  static icicle_error_t msm_precompute_run(const void* in_v, int n, const icicle_msm_config_t* cfg, void* out_v)
+  {
+    using E = EC<C>;
+    constexpr int PW = 2 * E::N32;
+    if (!cfg || n < 0) return ICICLE_INVALID_ARGUMENT;
+    if (n == 0) return ICICLE_SUCCESS;
+    if (!in_v || !out_v) return ICICLE_INVALID_POINTER;
+    ICICLE_TRY(bind_current_device());
+    hipStream_t st = (hipStream_t)cfg->stream;
+    const MsmPlan pl = make_plan(n, C::fr::NBITS, *cfg);
+    const int pf = pl.pf;
+    TempBuf d_in_tmp, d_out_tmp;
+    const uint32_t* d_in = (const uint32_t*)in_v;
+    uint32_t* d_out = (uint32_t*)out_v;
+    // input location: are_points_on_device ; output location: are_results_on_device (msm.h:39-47)
+    if (!cfg->are_points_on_device) {
+      HIP_TRY(d_in_tmp.alloc((size_t)n * PW * 4, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(hipMemcpyAsync(d_in_tmp.ptr(), in_v, (size_t)n * PW * 4, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
+      d_in = d_in_tmp.as<uint32_t>();
+    }
+    if (!cfg->are_results_on_device) {
+      HIP_TRY(d_out_tmp.alloc((size_t)n * pf * PW * 4, st), ICICLE_ALLOCATION_FAILED);
+      d_out = d_out_tmp.as<uint32_t>();
+    }
+    k_precompute<C><<<(n + 63) / 64, 64, 0, st>>>(d_in, d_out, n, pf, pl.c * pl.wpf, cfg->are_points_montgomery_form);
+    LAUNCH_CHECK("k_precompute", st);
+    HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
+    if (!cfg->are_results_on_device) {
+      HIP_TRY(hipMemcpyAsync(out_v, d_out, (size_t)n * pf * PW * 4, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
+      HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    } else if (!cfg->is_async) {
+      HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    }
+    return ICICLE_SUCCESS;
+  }
+
+  template <class C>
+  static icicle_error_t generate_run(void* out_v, int n, uint64_t k0, bool on_device, hipStream_t st)
+  {
+    using E = EC<C>;
+    constexpr int PW = 2 * E::N32;
+    if (n < 0 || (n > 0 && !out_v)) return ICICLE_INVALID_ARGUMENT;
+    if (n == 0) return ICICLE_SUCCESS;
+    ICICLE_TRY(bind_current_device());
+    TempBuf tmp;
+    uint32_t* d_out = (uint32_t*)out_v;
+    if (!on_device) {
+      HIP_TRY(tmp.alloc((size_t)n * PW * 4, st), ICICLE_ALLOCATION_FAILED);
+      d_out = tmp.as<uint32_t>();
+    }
+    const int L = 16;
+    const int nthreads = (n + L - 1) / L;
+    k_generate<C><<<(nthreads + 63) / 64, 64, 0, st>>>(d_out, n, k0, L);
+    LAUNCH_CHECK("k_generate", st);
+    HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
+    if (!on_device) HIP_TRY(hipMemcpyAsync(out_v, d_out, (size_t)n * PW * 4, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
+    HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    return ICICLE_SUCCESS;
+  }
+
+} // namespace icicle_hip
+

@@ -2,6 +2,7 @@
 
 Arrays are numpy uint32 in the reference's memory layout: scalars [batch*N, 8]; affine bases
 [M, 2*L] (x then y, identity = all zeros); projective results [batch, 3*L] (L = 8 bn254, 12 bls12_381).
+With g2=True the group is G2: coordinates are Fq2 elements {c0, c1}, so L doubles (16 / 24).
 Device-resident operands are passed as runtime.DeviceVec or raw integer device pointers.
 """
 import ctypes
@@ -22,9 +23,14 @@ def _ptr(x):
     return x.ctypes.data, False
 
 
-def msm(curve: str, scalars, bases, cfg: MSMConfig = None, results=None, msm_size: int = None):
+def _group(curve: str, g2: bool):
+    """(coordinate words, symbol prefix)"""
+    return (2 * LIMBS[curve], f"{curve}_g2") if g2 else (LIMBS[curve], curve)
+
+
+def msm(curve: str, scalars, bases, cfg: MSMConfig = None, results=None, msm_size: int = None, g2: bool = False):
     """results[b] = sum_i scalars[b*N+i] * bases[...]. Returns `results` (host ndarray unless a DeviceVec was given)."""
-    L = LIMBS[curve]
+    L, sym = _group(curve, g2)
     cfg = cfg or MSMConfig.default()
     sp, s_dev = _ptr(scalars)
     bp, b_dev = _ptr(bases)
@@ -39,12 +45,12 @@ def msm(curve: str, scalars, bases, cfg: MSMConfig = None, results=None, msm_siz
         results = np.zeros((max(1, cfg.batch_size), 3 * L), dtype=np.uint32)
     rp, r_dev = _ptr(results)
     cfg.are_results_on_device = r_dev
-    check(getattr(lib, f"{curve}_msm")(sp, bp, msm_size, ctypes.byref(cfg), rp), f"{curve}_msm")
+    check(getattr(lib, f"{sym}_msm")(sp, bp, msm_size, ctypes.byref(cfg), rp), f"{sym}_msm")
     return results
 
 
-def precompute_bases(curve: str, bases, cfg: MSMConfig, output=None, nof_bases: int = None):
-    L = LIMBS[curve]
+def precompute_bases(curve: str, bases, cfg: MSMConfig, output=None, nof_bases: int = None, g2: bool = False):
+    L, sym = _group(curve, g2)
     bp, b_dev = _ptr(bases)
     cfg.are_points_on_device = b_dev
     if nof_bases is None:
@@ -53,15 +59,15 @@ def precompute_bases(curve: str, bases, cfg: MSMConfig, output=None, nof_bases: 
         output = np.zeros((nof_bases * cfg.precompute_factor, 2 * L), dtype=np.uint32)
     op, o_dev = _ptr(output)
     cfg.are_results_on_device = o_dev
-    check(getattr(lib, f"{curve}_msm_precompute_bases")(bp, nof_bases, ctypes.byref(cfg), op), f"{curve}_msm_precompute_bases")
+    check(getattr(lib, f"{sym}_msm_precompute_bases")(bp, nof_bases, ctypes.byref(cfg), op), f"{sym}_msm_precompute_bases")
     return output
 
 
-def generate_affine_points(curve: str, n: int, k0: int = 1, out=None):
+def generate_affine_points(curve: str, n: int, k0: int = 1, out=None, g2: bool = False):
     """n distinct points (k0+i)*G generated on the GPU (synthetic benchmark inputs)."""
-    L = LIMBS[curve]
+    L, sym = _group(curve, g2)
     if out is None:
         out = np.zeros((n, 2 * L), dtype=np.uint32)
     op, o_dev = _ptr(out)
-    check(getattr(lib, f"{curve}_hip_generate_affine_points")(op, n, k0, o_dev, None), "generate_affine_points")
+    check(getattr(lib, f"{sym}_hip_generate_affine_points")(op, n, k0, o_dev, None), "generate_affine_points")
     return out

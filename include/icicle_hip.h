@@ -126,6 +126,12 @@ icicle_error_t bn254_msm(const void* scalars, const void* bases, int msm_size, c
 icicle_error_t bn254_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases); /* src/msm.cpp:45 */
 icicle_error_t bls12_381_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
 icicle_error_t bls12_381_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
+/* G2 (the reference's G2_ENABLED build): bases are g2_affine_t = {x.c0, x.c1, y.c0, y.c1} over the base field
+ * (curves/params/bn254.h:15-17, fields/complex_extension.h), results g2_projective_t = {x, y, z}. Same MSMConfig. */
+icicle_error_t bn254_g2_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results); /* src/msm.cpp:28 */
+icicle_error_t bn254_g2_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases); /* src/msm.cpp:61 */
+icicle_error_t bls12_381_g2_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
+icicle_error_t bls12_381_g2_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
 
 /* ======================================================================================
  * NTT: include/icicle/ntt.h:23-26 (NTTDir), 37-44 (Ordering), 53-64 (NTTConfig<S>), 92-96
@@ -228,6 +234,10 @@ icicle_error_t bls12_381_hip_generate_affine_points(void* out, int n, uint64_t k
  * base-sharded multi-GPU MSM after the RCCL all-gather of per-GPU partial results. */
 icicle_error_t bn254_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);
 icicle_error_t bls12_381_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);
+icicle_error_t bn254_g2_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream);
+icicle_error_t bls12_381_g2_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream);
+icicle_error_t bn254_g2_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);
+icicle_error_t bls12_381_g2_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);
 /* data[r][c] *= w_N^(+-(row0+r)*c) on device (N = 2^logn_total, w_N from the initialised domain): the inter-step
  * twiddle of a 4-step NTT whose two steps run on different GPUs (icicle_amd/dist.py, all-to-all over RCCL). */
 icicle_error_t babybear_hip_twiddle_rows(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t logn_total, bool inverse, icicleStreamHandle stream);
@@ -246,6 +256,10 @@ icicle_error_t icicle_hip_bn254_msm(const void* scalars, const void* bases, int 
 icicle_error_t icicle_hip_bn254_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
 icicle_error_t icicle_hip_bls12_381_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
 icicle_error_t icicle_hip_bls12_381_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
+icicle_error_t icicle_hip_bn254_g2_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
+icicle_error_t icicle_hip_bn254_g2_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
+icicle_error_t icicle_hip_bls12_381_g2_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
+icicle_error_t icicle_hip_bls12_381_g2_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
 #define ICICLE_HIP_DECLARE_NTT_ALIASES(F)                                                                              \
   icicle_error_t icicle_hip_##F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* config, uint32_t* output); \
   icicle_error_t icicle_hip_##F##_extension_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* config, uint32_t* output); \

@@ -115,6 +115,130 @@ def gen_points(c: Curve, n: int, k0: int = 1):
 
 
 # ----------------------------------------------------------------------------------------------
+# G2: the sextic twists over Fq2 = Fq[u]/(u^2+1) (reference: ComplexExtensionField, c0 = real, c1 = imaginary;
+# curves/params/bn254.h:32-53, bls12_381.h G2 block). Elements are (c0, c1) tuples; points ((x0,x1),(y0,y1)).
+def f2_add(q, a, b):
+    return ((a[0] + b[0]) % q, (a[1] + b[1]) % q)
+
+
+def f2_sub(q, a, b):
+    return ((a[0] - b[0]) % q, (a[1] - b[1]) % q)
+
+
+def f2_mul(q, a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+
+
+def f2_inv(q, a):
+    ni = pow((a[0] * a[0] + a[1] * a[1]) % q, -1, q)
+    return (a[0] * ni % q, (-a[1]) * ni % q)
+
+
+@dataclass(frozen=True)
+class G2Curve:
+    name: str
+    base: Curve
+    b: tuple
+    gx: tuple
+    gy: tuple
+
+
+BN254_G2 = G2Curve(
+    "bn254",
+    BN254,
+    f2_mul(BN254.q, (3, 0), f2_inv(BN254.q, (9, 1))),
+    (
+        10857046999023057135944570762232829481370756359578518086990519993285655852781,
+        11559732032986387107991004021392285783925812861821192530917403151452391805634,
+    ),
+    (
+        8495653923123431417604973247489272438418190587263600148770280649306958101930,
+        4082367875863433681332203403145435568316851327593401208105741076214120093531,
+    ),
+)
+BLS12_381_G2 = G2Curve(
+    "bls12_381",
+    BLS12_381,
+    (4, 4),
+    (
+        0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+        0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E,
+    ),
+    (
+        0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+        0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE,
+    ),
+)
+G2_CURVES = {"bn254": BN254_G2, "bls12_381": BLS12_381_G2}
+INF2 = ((0, 0), (0, 0))
+
+
+def g2_add(c: G2Curve, p, r):
+    q = c.base.q
+    if p == INF2:
+        return r
+    if r == INF2:
+        return p
+    (x1, y1), (x2, y2) = p, r
+    if x1 == x2:
+        if f2_add(q, y1, y2) == (0, 0):
+            return INF2
+        lam = f2_mul(q, f2_mul(q, (3, 0), f2_mul(q, x1, x1)), f2_inv(q, f2_add(q, y1, y1)))
+    else:
+        lam = f2_mul(q, f2_sub(q, y2, y1), f2_inv(q, f2_sub(q, x2, x1)))
+    x3 = f2_sub(q, f2_sub(q, f2_mul(q, lam, lam), x1), x2)
+    return (x3, f2_sub(q, f2_mul(q, lam, f2_sub(q, x1, x3)), y1))
+
+
+def g2_neg(c: G2Curve, p):
+    return INF2 if p == INF2 else (p[0], f2_sub(c.base.q, (0, 0), p[1]))
+
+
+def g2_mul(c: G2Curve, k: int, p):
+    k %= c.base.r
+    acc = INF2
+    while k:
+        if k & 1:
+            acc = g2_add(c, acc, p)
+        p = g2_add(c, p, p)
+        k >>= 1
+    return acc
+
+
+def g2_on_curve(c: G2Curve, p):
+    q = c.base.q
+    if p == INF2:
+        return True
+    x, y = p
+    return f2_sub(q, f2_mul(q, y, y), f2_add(q, f2_mul(q, f2_mul(q, x, x), x), c.b)) == (0, 0)
+
+
+def g2_msm_naive(c: G2Curve, scalars, points):
+    acc = INF2
+    for s, p in zip(scalars, points):
+        acc = g2_add(c, acc, g2_mul(c, s, p))
+    return acc
+
+
+def g2_proj_to_affine(c: G2Curve, x, y, z):
+    q = c.base.q
+    if z == (0, 0):
+        return INF2
+    zi = f2_inv(q, z)
+    return (f2_mul(q, x, zi), f2_mul(q, y, zi))
+
+
+def g2_gen_points(c: G2Curve, n: int, k0: int = 1):
+    g = (c.gx, c.gy)
+    p = g2_mul(c, k0, g)
+    out = []
+    for _ in range(n):
+        out.append(p)
+        p = g2_add(c, p, g)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # small NTT fields
 @dataclass(frozen=True)
 class NttField:

@@ -154,14 +154,17 @@ def ref_convert_montgomery(libname: str, symbol: str, arr: np.ndarray, count: in
 
 
 class RefCurve:
-    """bn254 / bls12_381 through the reference's own C ABI, on its "CPU" device."""
+    """bn254 / bls12_381 through the reference's own C ABI, on its "CPU" device.
+    g2=True selects the <curve>_g2_* entry points (G2_ENABLED build): coordinates are Fq2 = 2 base-field elements."""
 
-    def __init__(self, name: str):
+    def __init__(self, name: str, g2: bool = False):
         _load("device")
         _load(name)  # field lib (dependency of the curve lib, resolved through RPATH=$ORIGIN)
         self.name = name
+        self.g2 = g2
+        self.sym = f"{name}_g2" if g2 else name
         self.lib = _load(name)
-        self.L = {"bn254": 8, "bls12_381": 12}[name]
+        self.L = {"bn254": 8, "bls12_381": 12}[name] * (2 if g2 else 1)
 
     def msm(self, scalars: np.ndarray, bases: np.ndarray, batch=1, shared=True, precompute_factor=1, c=0, bitsize=0,
             scalars_mont=False, points_mont=False, n_threads=0):
@@ -178,7 +181,7 @@ class RefCurve:
             dev.config_extension_set_int(ext, b"n_threads", n_threads)
             cfg.ext = ext
         out = np.zeros((batch, 3 * self.L), dtype=np.uint32)
-        rc = getattr(self.lib, f"{self.name}_msm")(_p(scalars), _p(bases), n, ctypes.byref(cfg), _p(out))
+        rc = getattr(self.lib, f"{self.sym}_msm")(_p(scalars), _p(bases), n, ctypes.byref(cfg), _p(out))
         if ext:
             dev.destroy_config_extension.argtypes = [ctypes.c_void_p]
             dev.destroy_config_extension(ext)
@@ -189,7 +192,7 @@ class RefCurve:
         n = bases.size // (2 * self.L)
         cfg = MSMConfig(None, precompute_factor, c, 0, 1, True, False, False, False, False, False, False, None)
         out = np.zeros((n * precompute_factor, 2 * self.L), dtype=np.uint32)
-        rc = getattr(self.lib, f"{self.name}_msm_precompute_bases")(_p(bases), n, ctypes.byref(cfg), _p(out))
+        rc = getattr(self.lib, f"{self.sym}_msm_precompute_bases")(_p(bases), n, ctypes.byref(cfg), _p(out))
         assert rc == 0
         return out
 
@@ -197,20 +200,20 @@ class RefCurve:
         """projective_t[...] -> affine_t[...] with Projective::to_affine (projective.h:55-59)."""
         proj = np.ascontiguousarray(proj.reshape(-1, 3 * self.L))
         out = np.zeros((proj.shape[0], 2 * self.L), dtype=np.uint32)
-        fn = getattr(self.lib, f"{self.name}_to_affine")
+        fn = getattr(self.lib, f"{self.sym}_to_affine")
         for i in range(proj.shape[0]):
             fn(ctypes.c_void_p(proj[i].ctypes.data), ctypes.c_void_p(out[i].ctypes.data))
         return out
 
     def projective_eq(self, a: np.ndarray, b: np.ndarray) -> bool:
-        fn = getattr(self.lib, f"{self.name}_projective_eq")
+        fn = getattr(self.lib, f"{self.sym}_projective_eq")
         fn.restype = ctypes.c_bool
         a = np.ascontiguousarray(a)
         b = np.ascontiguousarray(b)
         return bool(fn(_p(a), _p(b)))
 
     def is_on_curve(self, a: np.ndarray) -> bool:
-        fn = getattr(self.lib, f"{self.name}_is_on_curve")
+        fn = getattr(self.lib, f"{self.sym}_is_on_curve")
         fn.restype = ctypes.c_bool
         a = np.ascontiguousarray(a)
         return bool(fn(_p(a)))
@@ -218,7 +221,7 @@ class RefCurve:
     def generate_affine_points(self, n: int) -> np.ndarray:
         """projective_t::rand_host_many(affine_t*, n) (projective.h:43-53): period-100 repetition."""
         out = np.zeros((n, 2 * self.L), dtype=np.uint32)
-        getattr(self.lib, f"{self.name}_generate_affine_points")(_p(out), n)
+        getattr(self.lib, f"{self.sym}_generate_affine_points")(_p(out), n)
         return out
 
     def generate_scalars(self, n: int) -> np.ndarray:

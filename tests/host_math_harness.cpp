@@ -125,6 +125,8 @@ extern "C" int host_ec_op(int curve, int op, const uint32_t* pts, int n, const u
   switch (curve) {
   case 0: return ec_op<bn254_g1>(op, pts, n, aux, out);
   case 1: return ec_op<bls12_381_g1>(op, pts, n, aux, out);
+  case 2: return ec_op<bn254_g2>(op, pts, n, aux, out);
+  case 3: return ec_op<bls12_381_g2>(op, pts, n, aux, out);
   }
   return -1;
 }

@@ -105,3 +105,45 @@ def test_c_oracle_vs_reference_random_msm():
     sc = to_words(rand_scalars(rng, 150, C.r), 8)
     got = oc.to_affine("bn254", oc.msm("bn254", sc, bases, c=8))
     assert np.array_equal(got, refc.to_affine(refc.msm(sc, bases))[0])
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_reference_g2_msm_matches_python_definition(cname):
+    """pins pyref's Fq2 / G2 arithmetic (used by the G2 GPU tests) to the reference's G2_ENABLED build"""
+    C = pyref.G2_CURVES[cname]
+    rc = ref.RefCurve(cname, g2=True)
+    L = C.base.limbs_q
+    rng = np.random.default_rng(3)
+    n = 12
+    pts = pyref.g2_gen_points(C, n, k0=424242)
+    pts[4] = pyref.INF2
+    arr = np.concatenate([to_words([p[0][0] for p in pts], L), to_words([p[0][1] for p in pts], L),
+                          to_words([p[1][0] for p in pts], L), to_words([p[1][1] for p in pts], L)], axis=1)
+    sc = rand_scalars(rng, n, C.base.r)
+    sc[0], sc[1] = 0, C.base.r - 1
+    out = rc.msm(to_words(sc, 8), arr)
+    assert rc.is_on_curve(out[0])
+    aff = rc.to_affine(out)[0]
+    got = tuple((from_words(aff[(2 * k) * L:(2 * k + 1) * L]), from_words(aff[(2 * k + 1) * L:(2 * k + 2) * L])) for k in range(2))
+    assert got == pyref.g2_msm_naive(C, sc, pts)
+
+
+@pytest.mark.parametrize("fname", ["bn254", "bls12_381"])
+def test_reference_scalar_field_ntt_matches_definition(fname):
+    """pins pyref.ntt_naive over the 256-bit scalar fields (used by tests/test_gpu_ntt_scalar.py)"""
+    F = pyref.NTT_FIELDS[fname]
+    rf = ref.RefScalarNttField(fname)
+    root = rf.get_root_of_unity(1 << 8)
+    assert root == pyref.omega(F, 8)
+    rf.init_domain(root)
+    try:
+        rng = np.random.default_rng(0)
+        n = 16
+        vals = rand_scalars(rng, n, F.p)
+        x = to_words(vals, 8).reshape(-1)
+        y = rf.ntt(x, n, 0)
+        assert from_words(y.reshape(n, 8)) == pyref.ntt_naive(F, vals, pyref.omega(F, 4))
+        y = rf.ntt(x, n, 1, coset_gen=12345, ordering=3)
+        assert from_words(y.reshape(n, 8)) == pyref.ntt_naive(F, vals, pyref.omega(F, 4), inverse=True, coset_gen=12345, ordering="RR")
+    finally:
+        rf.release_domain()

@@ -94,6 +94,72 @@ CURVES = {
 }
 
 
+# G2: twist curves over Fq2 = Fq[u]/(u^2+1); name: (b' as (c0, c1) or callable, generator x (c0, c1), y (c0, c1))
+# generators: the standard ones (EIP-197 for BN254, the BLS12-381 spec), the same values as the reference's
+# curves/params/{bn254,bls12_381}.h g2_gen_*; checked on-curve below.
+G2 = {
+    "bn254": (
+        "3/(9+u)",
+        (
+            10857046999023057135944570762232829481370756359578518086990519993285655852781,
+            11559732032986387107991004021392285783925812861821192530917403151452391805634,
+        ),
+        (
+            8495653923123431417604973247489272438418190587263600148770280649306958101930,
+            4082367875863433681332203403145435568316851327593401208105741076214120093531,
+        ),
+    ),
+    "bls12_381": (
+        "4(1+u)",
+        (
+            0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+            0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E,
+        ),
+        (
+            0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+            0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE,
+        ),
+    ),
+}
+
+
+def f2mul(a, b, p):
+    return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+
+
+def f2inv(a, p):
+    ni = pow((a[0] * a[0] + a[1] * a[1]) % p, -1, p)
+    return (a[0] * ni % p, (-a[1]) * ni % p)
+
+
+def g2_b(name, p):
+    if name == "bn254":
+        return f2mul((3, 0), f2inv((9, 1), p), p)
+    return (4, 4)
+
+
+def gen_curve_g2(name, fq, fr):
+    p, _ = BIG[fq]
+    nl = (p.bit_length() + 6 + RB - 1) // RB
+    R = 1 << (RB * nl)
+    _, gx, gy = G2[name]
+    b = g2_b(name, p)
+    x3 = f2mul(f2mul(gx, gx, p), gx, p)
+    y2 = f2mul(gy, gy, p)
+    assert ((y2[0] - x3[0] - b[0]) % p, (y2[1] - x3[1] - b[1]) % p) == (0, 0), name
+    pair = lambda v: "{" + ", ".join(arr(limbs(c * R % p, nl)) for c in v) + "}"
+    s = []
+    s.append(f"struct {name}_g2 {{ // twist over Fq2 = Fq[u]/(u^2+1), b' = {G2[name][0]}")
+    s.append(f"  using fq = {fq}_params;")
+    s.append(f"  using fr = {fr}_params;")
+    s.append("  static constexpr int EXT_DEGREE = 2;")
+    s.append(f"  static constexpr uint32_t B3[2][{nl}] = {pair((3 * b[0] % p, 3 * b[1] % p))}; // 3*b', Montgomery")
+    s.append(f"  static constexpr uint32_t GX[2][{nl}] = {pair(gx)}; // generator, Montgomery")
+    s.append(f"  static constexpr uint32_t GY[2][{nl}] = {pair(gy)};")
+    s.append("};")
+    return "\n".join(s)
+
+
 def gen_curve(name, fq, fr, b, gx, gy):
     p, _ = BIG[fq]
     nl = (p.bit_length() + 6 + RB - 1) // RB
@@ -103,6 +169,7 @@ def gen_curve(name, fq, fr, b, gx, gy):
     s.append(f"struct {name}_g1 {{")
     s.append(f"  using fq = {fq}_params;")
     s.append(f"  using fr = {fr}_params;")
+    s.append("  static constexpr int EXT_DEGREE = 1;")
     s.append(f"  static constexpr uint32_t B3[{nl}] = {arr(limbs(3 * b * R % p, nl))}; // 3*b, Montgomery")
     s.append(f"  static constexpr uint32_t GX[{nl}] = {arr(limbs(gx * R % p, nl))}; // generator, Montgomery")
     s.append(f"  static constexpr uint32_t GY[{nl}] = {arr(limbs(gy * R % p, nl))};")
@@ -148,6 +215,7 @@ def main():
         out.append(gen_big(name, p, l32))
     for name, (fq, fr, b, gx, gy) in CURVES.items():
         out.append(gen_curve(name, fq, fr, b, gx, gy))
+        out.append(gen_curve_g2(name, fq, fr))
     for name, (p, rou) in SMALL.items():
         out.append(gen_small(name, p, rou))
     out.append("} // namespace icicle_hip")
