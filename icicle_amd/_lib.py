@@ -176,6 +176,7 @@ API_SYMBOLS = (
     + [f"{pre}{f}_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in CURVES + NTT_FIELDS]
     + [f"{pre}{f}_extension_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in NTT_FIELDS]
     + [f"{pre}{c}_{k}_convert_montgomery" for pre in ("", "icicle_hip_") for c in CURVES for k in ("affine", "projective")]
+    + [f"{pre}{c}_g2_{k}_convert_montgomery" for pre in ("", "icicle_hip_") for c in CURVES for k in ("affine", "projective")]
 )
 
 if not os.path.exists(LIB_PATH):

@@ -124,9 +124,19 @@ using namespace icicle_hip;
   extern "C" icicle_error_t icicle_hip_##NAME##_affine_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_big<PR>(i, 2 * n, to, c, o)); } \
   extern "C" icicle_error_t icicle_hip_##NAME##_projective_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_big<PR>(i, 3 * n, to, c, o)); }
 
+// G2 points: coordinates are Fq2 = two base-field components each, converted component-wise
+// (fields/complex_extension.h:88-96; src/curves/montgomery_conversion.cpp:26-44,60-78)
+#define DEFINE_G2_POINT_CONVERT(NAME, PR)                                                                              \
+  extern "C" icicle_error_t NAME##_g2_affine_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_big<PR>(i, 4 * n, to, c, o)); } \
+  extern "C" icicle_error_t NAME##_g2_projective_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_big<PR>(i, 6 * n, to, c, o)); } \
+  extern "C" icicle_error_t icicle_hip_##NAME##_g2_affine_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_big<PR>(i, 4 * n, to, c, o)); } \
+  extern "C" icicle_error_t icicle_hip_##NAME##_g2_projective_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_big<PR>(i, 6 * n, to, c, o)); }
+
 DEFINE_SCALAR_CONVERT_BIG(bn254, bn254_fr_params)
 DEFINE_SCALAR_CONVERT_BIG(bls12_381, bls12_381_fr_params)
 DEFINE_SCALAR_CONVERT_SMALL(babybear, babybear_params)
 DEFINE_SCALAR_CONVERT_SMALL(koalabear, koalabear_params)
 DEFINE_POINT_CONVERT(bn254, bn254_fq_params)
 DEFINE_POINT_CONVERT(bls12_381, bls12_381_fq_params)
+DEFINE_G2_POINT_CONVERT(bn254, bn254_fq_params)
+DEFINE_G2_POINT_CONVERT(bls12_381, bls12_381_fq_params)

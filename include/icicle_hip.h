@@ -223,6 +223,10 @@ icicle_error_t bn254_affine_convert_montgomery(const void* input, uint64_t n, bo
 icicle_error_t bn254_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 icicle_error_t bls12_381_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 icicle_error_t bls12_381_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t bn254_g2_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output); /* src/curves/montgomery_conversion.cpp:29 */
+icicle_error_t bn254_g2_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output); /* :63 */
+icicle_error_t bls12_381_g2_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t bls12_381_g2_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 
 /* ---- backend-specific helpers (not part of the reference ABI) ---- */
 const char* icicle_hip_version(void);
@@ -285,6 +289,10 @@ icicle_error_t icicle_hip_bn254_affine_convert_montgomery(const void* input, uin
 icicle_error_t icicle_hip_bn254_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 icicle_error_t icicle_hip_bls12_381_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 icicle_error_t icicle_hip_bls12_381_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_bn254_g2_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_bn254_g2_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_bls12_381_g2_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_bls12_381_g2_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 
 #ifdef __cplusplus
 }

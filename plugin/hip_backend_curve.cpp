@@ -66,3 +66,37 @@ REGISTER_PROJECTIVE_CONVERT_MONTGOMERY_BACKEND("HIP", hip_projective_convert);
 
 REGISTER_MSM_BACKEND("HIP", hip_msm);
 REGISTER_MSM_PRE_COMPUTE_BASES_BACKEND("HIP", hip_msm_precompute);
+
+#ifdef G2_ENABLED
+// G2 (icicle/include/icicle/backend/msm_backend.h:46-81, curves/montgomery_conversion.h:53-89)
+#define HIP_G2_FN(name) CONCAT_EXPAND(CONCAT_EXPAND(CONCAT_EXPAND(icicle_hip, ICICLE_FFI_PREFIX), g2), name)
+
+static eIcicleError hip_g2_msm(const Device& device, const scalar_t* scalars, const g2_affine_t* bases, int msm_size, const MSMConfig& config, g2_projective_t* results)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_msm_config_t c = translate(config);
+  return (eIcicleError)HIP_G2_FN(msm)(scalars, bases, msm_size, &c, results);
+}
+static eIcicleError hip_g2_msm_precompute(const Device& device, const g2_affine_t* input_bases, int nof_bases, const MSMConfig& config, g2_affine_t* output_bases)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_msm_config_t c = translate(config);
+  return (eIcicleError)HIP_G2_FN(msm_precompute_bases)(input_bases, nof_bases, &c, output_bases);
+}
+static eIcicleError hip_g2_affine_convert(const Device& device, const g2_affine_t* input, size_t n, bool is_into, const VecOpsConfig& config, g2_affine_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_vec_ops_config_t c = translate(config);
+  return (eIcicleError)HIP_G2_FN(affine_convert_montgomery)(input, n, is_into, &c, output);
+}
+static eIcicleError hip_g2_projective_convert(const Device& device, const g2_projective_t* input, size_t n, bool is_into, const VecOpsConfig& config, g2_projective_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  const hip_vec_ops_config_t c = translate(config);
+  return (eIcicleError)HIP_G2_FN(projective_convert_montgomery)(input, n, is_into, &c, output);
+}
+REGISTER_MSM_G2_BACKEND("HIP", hip_g2_msm);
+REGISTER_MSM_G2_PRE_COMPUTE_BASES_BACKEND("HIP", hip_g2_msm_precompute);
+REGISTER_AFFINE_G2_CONVERT_MONTGOMERY_BACKEND("HIP", hip_g2_affine_convert);
+REGISTER_PROJECTIVE_G2_CONVERT_MONTGOMERY_BACKEND("HIP", hip_g2_projective_convert);
+#endif // G2_ENABLED

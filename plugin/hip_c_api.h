@@ -66,6 +66,10 @@ HIP_DECLARE_POINT_CONVERT(bls12_381)
   int icicle_hip_##C##_msm_precompute_bases(const void*, int, const hip_msm_config_t*, void*);
 HIP_DECLARE_CURVE(bn254)
 HIP_DECLARE_CURVE(bls12_381)
+HIP_DECLARE_CURVE(bn254_g2)
+HIP_DECLARE_CURVE(bls12_381_g2)
+HIP_DECLARE_POINT_CONVERT(bn254_g2)
+HIP_DECLARE_POINT_CONVERT(bls12_381_g2)
 #define HIP_DECLARE_FIELD(F)                                                                                           \
   int icicle_hip_##F##_ntt(const uint32_t*, int, int, const hip_ntt_config_u32_t*, uint32_t*);                         \
   int icicle_hip_##F##_extension_ntt(const uint32_t*, int, int, const hip_ntt_config_u32_t*, uint32_t*);               \

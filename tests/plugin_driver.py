@@ -114,6 +114,25 @@ def main():
         assert rt.set_device("CPU", 0) == 0
         fobj.release_domain()
 
+    # ---- G2 MSM (+ G2 Montgomery conversion) on "HIP" vs "CPU" through the reference frontend ----
+    for name in ("bn254", "bls12_381"):
+        C2 = pyref.G2_CURVES[name]
+        g2 = ref.RefCurve(name, g2=True)
+        n = 1500
+        bases = g2.generate_affine_points(n)
+        sc = to_words(rand_scalars(rng, n * 2, C2.base.r), 8)
+        assert rt.set_device("HIP", 0) == 0
+        got = g2.msm(sc, bases, batch=2)
+        pre = g2.precompute_bases(bases, 3, c=8)
+        am = ref.ref_convert_montgomery(name, f"{name}_g2_affine_convert_montgomery", bases, n, True)
+        assert rt.set_device("CPU", 0) == 0
+        exp = g2.msm(sc, bases, batch=2)
+        assert np.array_equal(g2.to_affine(got), g2.to_affine(exp))
+        assert np.array_equal(pre, g2.precompute_bases(bases, 3, c=8))
+        assert np.array_equal(am, ref.ref_convert_montgomery(name, f"{name}_g2_affine_convert_montgomery", bases, n, True))
+        for bidx in range(2):
+            assert g2.projective_eq(got[bidx], exp[bidx]) and g2.is_on_curve(got[bidx])
+
     # ---- NTT over the curves' 256-bit scalar fields: "HIP" vs "CPU" through the reference frontend ----
     for name in ("bn254", "bls12_381"):
         F = pyref.NTT_FIELDS[name]
