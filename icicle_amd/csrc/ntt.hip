@@ -182,8 +182,12 @@ namespace icicle_hip {
     return r;
   }
 
+  // threads per block: 512, except the 2^12-point variant (NQ0 = 4, NR = 3; <= 124 VGPRs) which runs 1024 so
+  // that a tile is 4 columns wide
+  constexpr int ntt_fast_max_threads(int nq0, int nr) { return (nq0 == 4 && nr == 3) ? 1024 : 512; }
+
   template <class PR, int NQ0, int NR, bool DIF, bool INV>
-  __global__ __launch_bounds__(512) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
+  __global__ __launch_bounds__(ntt_fast_max_threads(NQ0, NR)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
   {
     using S = SmallField<PR>;
     constexpr int SS = NQ0 + 4 * (NR - 1);
@@ -195,7 +199,12 @@ namespace icicle_hip {
     constexpr int KB_BITS = SS - NQ0;
     extern __shared__ uint32_t lds[];
     const uint32_t T = pd.T, TP = T + 1;
-    const uint32_t a = blockIdx.x / pd.tiles_per_a, ct = blockIdx.x % pd.tiles_per_a;
+    // Narrow tiles (T*4 B < one 128 B line): neighbouring tiles share HBM lines. Workgroups are dealt
+    // round-robin to the 8 XCDs, so give each XCD a contiguous range of tiles -- then the tiles that
+    // share a line run back to back on the same XCD and meet in its L2.
+    uint32_t tile = blockIdx.x;
+    if (pd.xcd_remap) tile = (blockIdx.x & 7u) * (pd.ntiles >> 3) + (blockIdx.x >> 3);
+    const uint32_t a = tile / pd.tiles_per_a, ct = tile % pd.tiles_per_a;
     const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
     const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
     const uint32_t lstride_log = nl.log_max - SS;
@@ -631,7 +640,12 @@ namespace icicle_hip {
       return ICICLE_SUCCESS;
     }
     int parts[3], P;
-    split_logn(logn, 8, parts, &P);
+    {
+      // sub-transform size: 2^8 (three passes at 2^24). ICICLE_HIP_NTT_SMAX=12 selects two passes of 2^12.
+      static const int smax_env = getenv("ICICLE_HIP_NTT_SMAX") ? atoi(getenv("ICICLE_HIP_NTT_SMAX")) : 0;
+      const int smax = (smax_env >= 4 && smax_env <= 12) ? smax_env : 8;
+      split_logn(logn, smax, parts, &P);
+    }
     // P >= 2: passes 0..P-2 run in a work buffer (the last pass permutes across tiles, so it can
     // never be in place; this also makes input == output legal, test_mod_arithmetic_api.h:627,679)
     TempBuf d_work;
@@ -669,10 +683,13 @@ namespace icicle_hip {
       const uint64_t L = (uint64_t)1 << parts[p];
       // fast path: block = T * L/16 threads (<= 512), LDS = 2 buffers of L*(T+1) words (<= 160 KiB)
       const uint64_t epb = L >= 16 ? 16 : L;
-      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, 512 * epb / L));
+      const uint64_t maxthr = (parts[p] == 12) ? 1024 : 512; // ntt_fast_max_threads()
+      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, maxthr * epb / L));
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
         tmax >>= 1;
-      const PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
+      PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
+      static const bool xcd_on = !(getenv("ICICLE_HIP_NTT_XCD") && atoi(getenv("ICICLE_HIP_NTT_XCD")) == 0);
+      pd.xcd_remap = (xcd_on && fast && pd.T < 32 && pd.ntiles >= 64 && pd.ntiles % 8 == 0) ? 1 : 0;
       if (fast) {
         const unsigned threads = (unsigned)(pd.T * (L / epb));
         const size_t lds_bytes = (size_t)2 * L * (pd.T + 1) * 4;

@@ -22,6 +22,7 @@ namespace icicle_hip {
     uint64_t out_sk, out_st;                          // out base computed in-kernel (needs digit reversal)
     int is_last;      // last pass: natural-order scatter + optional 1/N scaling
     int pidx;         // pass index
+    int xcd_remap;    // fast path: blockIdx.x -> tile map that keeps neighbouring tiles on one XCD
     // twiddle after this pass (not last): exponent = jnext * K, table stride tstride
     uint64_t tw_stride;  // max / M
     uint32_t cprime;     // C' = C / N_{p+1}; jnext = (c0 + t) / C'

@@ -28,11 +28,12 @@ def time_it(fn, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def msm_case(curve, logn, batch=1, pf=1):
+def msm_case(curve, logn, batch=1, pf=1, g2=False):
     n = 1 << logn
-    L = M.LIMBS[curve]
+    L = M.LIMBS[curve] * (2 if g2 else 1)
+    sym = f"{curve}_g2" if g2 else curve
     bases = torch.empty((n, 2 * L), dtype=torch.int32, device=dev)
-    check(getattr(lib, f"{curve}_hip_generate_affine_points")(bases.data_ptr(), n, 1, True, None))
+    check(getattr(lib, f"{sym}_hip_generate_affine_points")(bases.data_ptr(), n, 1, True, None))
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     sc = torch.randint(-(2 ** 31), 2 ** 31, (n * batch, 8), dtype=torch.int32, device=dev, generator=g)
@@ -41,8 +42,8 @@ def msm_case(curve, logn, batch=1, pf=1):
     cfg = MSMConfig.default()
     cfg.batch_size = batch
     cfg.is_async = True
-    ms = time_it(lambda: M.msm(curve, sc.data_ptr(), bases.data_ptr(), cfg, results=res.data_ptr(), msm_size=n))
-    print(f"msm {curve:10s} 2^{logn:<2d} batch {batch:<4d} {ms:9.3f} ms  {batch * n / ms / 1e6:8.2f} Gpoint/s", flush=True)
+    ms = time_it(lambda: M.msm(curve, sc.data_ptr(), bases.data_ptr(), cfg, results=res.data_ptr(), msm_size=n, g2=g2))
+    print(f"msm {sym:12s} 2^{logn:<2d} batch {batch:<4d} {ms:9.3f} ms  {batch * n / ms / 1e6:8.2f} Gpoint/s", flush=True)
 
 
 def ntt_case(field, logn, batch):
@@ -81,6 +82,16 @@ def ntt_scalar_case(field, logn, batch):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ntt":
+        for logn, batch in ((12, 4096), (16, 1024), (20, 256), (22, 128), (24, 64), (24, 8), (27, 4)):
+            ntt_case("babybear", logn, batch)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g2":
+        for logn in (12, 16, 20, 22, 24):
+            msm_case("bn254", logn, g2=True)
+        for logn in (16, 20, 22):
+            msm_case("bls12_381", logn, g2=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "scalar-ntt":
         for logn, batch in ((12, 256), (16, 16), (20, 1), (22, 1), (24, 1)):
             ntt_scalar_case("bn254", logn, batch)
