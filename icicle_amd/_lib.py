@@ -169,6 +169,7 @@ API_SYMBOLS = (
                                                       "get_root_of_unity_from_domain")]
     + [f"icicle_hip_{f}_{s}" for f in SCALAR_NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain",
                                                                  "get_root_of_unity_from_domain")]
+    + [f"{pre}{c}_ecntt" for pre in ("", "icicle_hip_") for c in CURVES]
     + ["icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device"]
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
@@ -232,6 +233,7 @@ for _f in NTT_FIELDS:
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
 for _f in SCALAR_NTT_FIELDS:
+    getattr(lib, f"{_f}_ecntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU256), ctypes.c_void_p]
     getattr(lib, f"{_f}_ntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU256), ctypes.c_void_p]
     getattr(lib, f"{_f}_ntt_init_domain").argtypes = [ctypes.c_void_p, ctypes.POINTER(NTTInitDomainConfig)]
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.c_void_p]

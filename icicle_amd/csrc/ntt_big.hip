@@ -16,8 +16,7 @@
 // and montmul(x, w*R) = x*w. Lazy bounds (units of p): loads 1.2, 3.2 and 7.2 after the two
 // product-free stages, +2 per later stage, <= 23.2 after ten stages (limit 64, reduce() accepts
 // < 32), back to canonical on every store.
-#include "common.h"
-#include "bigfield.cuh"
+#include "ntt_big_common.cuh"
 #include "ntt_plan.h"
 #include <algorithm>
 #include <cstring>
@@ -25,111 +24,6 @@
 #include <mutex>
 
 namespace icicle_hip {
-
-  template <class PR>
-  struct BigNtt {
-    using F = FieldOps<PR>;
-    using fe = typename F::fe;
-    static constexpr int W = F::N32; // words per element in memory
-
-    static HD fe load_words(const uint32_t* w) { return F::unpack(w); }
-    static HD fe pow_u64(fe base, uint64_t e)
-    { // base Montgomery, result Montgomery (canonical limbs not required)
-      fe r = F::one();
-      bool started = false;
-      for (int bit = 63; bit >= 0; bit--) {
-        if (started) r = F::sqr(r);
-        if ((e >> bit) & 1) {
-          r = started ? F::mul(r, base) : base;
-          started = true;
-        }
-      }
-      return r;
-    }
-    static HD fe pow_words(fe base, const uint32_t* e, int nwords)
-    {
-      fe r = F::one();
-      bool started = false;
-      for (int bit = nwords * 32 - 1; bit >= 0; bit--) {
-        if (started) r = F::sqr(r);
-        if ((e[bit >> 5] >> (bit & 31)) & 1) {
-          r = started ? F::mul(r, base) : base;
-          started = true;
-        }
-      }
-      return r;
-    }
-    static HD void store_packed(uint32_t* w, const fe& a) { F::pack(w, F::reduce(a)); }
-  };
-
-  struct BigDomain {
-    uint32_t* tw = nullptr; // tw[i*8 .. i*8+7] = packed Montgomery w_max^i, i < max_size
-    int log_max = -1;
-    uint32_t root[8] = {0}; // canonical w_max
-  };
-  template <class PR>
-  struct BigDomainStore {
-    static std::mutex& mtx()
-    {
-      static std::mutex m;
-      return m;
-    }
-    static std::map<int, BigDomain>& map()
-    {
-      static std::map<int, BigDomain> m;
-      return m;
-    }
-  };
-
-  struct BigWords {
-    uint32_t w[8];
-  };
-
-  // tw[i] = root^i. Thread t fills 64 consecutive entries from one pow().
-  template <class PR>
-  __global__ __launch_bounds__(256) void k_big_gen_twiddles(uint32_t* __restrict__ tw, BigWords root_mont, size_t n)
-  {
-    using B = BigNtt<PR>;
-    using F = typename B::F;
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const size_t i0 = t * 64;
-    if (i0 >= n) return;
-    const typename B::fe r = F::unpack(root_mont.w);
-    typename B::fe x = B::pow_u64(r, (uint64_t)i0);
-    for (size_t i = i0; i < i0 + 64 && i < n; i++) {
-      B::store_packed(tw + i * 8, x);
-      x = F::mul(x, r);
-    }
-  }
-
-  // pw[i] = g^i (packed Montgomery), i < n
-  template <class PR>
-  __global__ __launch_bounds__(256) void k_big_coset_powers(uint32_t* __restrict__ pw, BigWords g_mont, uint64_t n)
-  {
-    using B = BigNtt<PR>;
-    using F = typename B::F;
-    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint64_t i0 = t * 16;
-    if (i0 >= n) return;
-    const typename B::fe g = F::unpack(g_mont.w);
-    typename B::fe x = B::pow_u64(g, i0);
-    for (uint64_t i = i0; i < i0 + 16 && i < n; i++) {
-      B::store_packed(pw + i * 8, x);
-      x = F::mul(x, g);
-    }
-  }
-
-  __device__ __forceinline__ void load8(uint32_t* dst, const uint32_t* __restrict__ src)
-  {
-    const uint4 a = ((const uint4*)src)[0], b = ((const uint4*)src)[1];
-    dst[0] = a.x, dst[1] = a.y, dst[2] = a.z, dst[3] = a.w;
-    dst[4] = b.x, dst[5] = b.y, dst[6] = b.z, dst[7] = b.w;
-  }
-  __device__ __forceinline__ void store8(uint32_t* __restrict__ dst, const uint32_t* src)
-  {
-    ((uint4*)dst)[0] = make_uint4(src[0], src[1], src[2], src[3]);
-    ((uint4*)dst)[1] = make_uint4(src[4], src[5], src[6], src[7]);
-  }
 
   // One pass: grid = (ntiles, batch). Dynamic LDS: L*T elements of 9 limbs.
   // Handles every ordering, cosets, both directions and both batch layouts.
@@ -225,51 +119,6 @@ namespace icicle_hip {
       B::store_packed(wbuf, v);
       store8(out + (boff + oaddr * nl.es) * 8, wbuf);
     }
-  }
-
-  // ---- host ------------------------------------------------------------------------------------
-  template <class PR>
-  static bool words_lt_p(const uint32_t* w)
-  {
-    for (int i = 7; i >= 0; i--) {
-      if (w[i] < PR::P32[i]) return true;
-      if (w[i] > PR::P32[i]) return false;
-    }
-    return false;
-  }
-  static bool words_is_zero(const uint32_t* w)
-  {
-    uint32_t o = 0;
-    for (int i = 0; i < 8; i++)
-      o |= w[i];
-    return o == 0;
-  }
-  static bool words_is_one(const uint32_t* w)
-  {
-    uint32_t o = w[0] ^ 1u;
-    for (int i = 1; i < 8; i++)
-      o |= w[i];
-    return o == 0;
-  }
-  template <class PR>
-  static BigWords mont_words(const typename FieldOps<PR>::fe& x)
-  {
-    BigWords r;
-    BigNtt<PR>::store_packed(r.w, x);
-    return r;
-  }
-  template <class PR>
-  static typename FieldOps<PR>::fe host_inverse(const typename FieldOps<PR>::fe& x)
-  { // x^(p-2)
-    uint32_t e[8];
-    uint64_t borrow = 2;
-    for (int i = 0; i < 8; i++) {
-      const uint64_t v = (uint64_t)PR::P32[i];
-      const uint64_t d = v - borrow;
-      e[i] = (uint32_t)d;
-      borrow = (v < borrow) ? 1 : 0;
-    }
-    return BigNtt<PR>::pow_words(x, e, 8);
   }
 
   template <class PR>
@@ -436,18 +285,7 @@ namespace icicle_hip {
     nl.log_max = dom.log_max;
     nl.ninv_mont = 0;
     BigWords ninv{};
-    if (nl.inverse) { // (1/2)^logn; 1/2 = (p+1)/2
-      uint32_t h[8];
-      uint64_t c = 1;
-      for (int i = 0; i < 8; i++) {
-        const uint64_t v = (uint64_t)PR::P32[i] + c;
-        h[i] = (uint32_t)v;
-        c = v >> 32;
-      }
-      for (int i = 0; i < 8; i++)
-        h[i] = (h[i] >> 1) | (i < 7 ? (h[i + 1] << 31) : ((uint32_t)c << 31));
-      ninv = mont_words<PR>(BigNtt<PR>::pow_u64(F::from_canonical(h), (uint64_t)logn));
-    }
+    if (nl.inverse) ninv = mont_words<PR>(host_ninv<PR>(logn));
     nl.coset = !words_is_one(cfg->coset_gen);
     if (nl.coset) {
       HIP_TRY(d_pw.alloc(n * 32, st), ICICLE_ALLOCATION_FAILED);

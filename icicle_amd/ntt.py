@@ -82,3 +82,21 @@ def ntt(field: str, inp, direction: int, cfg=None, out=None, size: int = None, e
     fn = getattr(lib, f"{field}_extension_ntt" if extension else f"{field}_ntt")
     check(fn(ip, size, direction, ctypes.byref(cfg), op), f"{field}_ntt")
     return out
+
+
+def ecntt(curve: str, inp, direction: int, cfg: NTTConfigU256 = None, out=None, size: int = None):
+    """NTT over G1 points (wrappers/rust/icicle-core/src/ecntt/mod.rs): inp is projective_t[size*batch] as uint32
+    words (3*L per point, L = 8 bn254 / 12 bls12_381); uses the domain of the curve's scalar-field NTT."""
+    from .msm import LIMBS
+
+    cfg = cfg or NTTConfigU256.default()
+    ip, i_dev = _ptr(inp)
+    cfg.are_inputs_on_device = i_dev
+    if size is None:
+        size = inp.size // (max(1, cfg.batch_size) * 3 * LIMBS[curve])
+    if out is None:
+        out = np.zeros_like(inp)
+    op, o_dev = _ptr(out)
+    cfg.are_outputs_on_device = o_dev
+    check(getattr(lib, f"{curve}_ecntt")(ip, size, direction, ctypes.byref(cfg), op), f"{curve}_ecntt")
+    return out

@@ -193,6 +193,10 @@ typedef struct {
 
 ICICLE_HIP_DECLARE_NTT_U256(bn254)
 ICICLE_HIP_DECLARE_NTT_U256(bls12_381)
+/* ECNTT: NTT over G1 points with scalar-field twiddles (src/ecntt.cpp:7-11). input/output: projective_t[size*batch]
+ * (3 base-field elements each); config and twiddle domain are those of <curve>_ntt. */
+icicle_error_t bn254_ecntt(const void* input, int size, int dir, const icicle_ntt_config_u256_t* config, void* output);
+icicle_error_t bls12_381_ecntt(const void* input, int size, int dir, const icicle_ntt_config_u256_t* config, void* output);
 
 /* ======================================================================================
  * Montgomery-form conversion (vec-ops): include/icicle/vec_ops.h:19-37 (VecOpsConfig, 32 bytes),
@@ -279,6 +283,8 @@ ICICLE_HIP_DECLARE_NTT_ALIASES(koalabear)
   icicle_error_t icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);
 ICICLE_HIP_DECLARE_NTT_U256_ALIASES(bn254)
 ICICLE_HIP_DECLARE_NTT_U256_ALIASES(bls12_381)
+icicle_error_t icicle_hip_bn254_ecntt(const void* input, int size, int dir, const icicle_ntt_config_u256_t* config, void* output);
+icicle_error_t icicle_hip_bls12_381_ecntt(const void* input, int size, int dir, const icicle_ntt_config_u256_t* config, void* output);
 ICICLE_HIP_DECLARE_CONVERT(icicle_hip_bn254)
 ICICLE_HIP_DECLARE_CONVERT(icicle_hip_bls12_381)
 ICICLE_HIP_DECLARE_CONVERT(icicle_hip_babybear)

@@ -52,9 +52,10 @@ build_curve() {
   local name=$1 id=$2
   [ "$OUT/libicicle_curve_$name.so" -nt "$0" ] && return 0
   echo "[ref] libicicle_curve_$name.so"
-  $CXX $FLAGS -DCURVE_ID=$id -DFIELD_ID=$id -DCURVE=$name -DFIELD=$name -DICICLE_FFI_PREFIX=$name -DMSM=ON -DNTT=ON -DG2_ENABLED \
-    $R/src/curves/ffi_extern.cpp $R/src/curves/montgomery_conversion.cpp $R/src/msm.cpp \
+  $CXX $FLAGS -DCURVE_ID=$id -DFIELD_ID=$id -DCURVE=$name -DFIELD=$name -DICICLE_FFI_PREFIX=$name -DMSM=ON -DNTT=ON -DECNTT=ON -DG2_ENABLED \
+    $R/src/curves/ffi_extern.cpp $R/src/curves/montgomery_conversion.cpp $R/src/msm.cpp $R/src/ecntt.cpp \
     $R/backend/cpu/src/curve/cpu_mont_conversion.cpp $R/backend/cpu/src/curve/cpu_msm.cpp \
+    $R/backend/cpu/src/curve/cpu_ecntt.cpp \
     -L"$OUT" -licicle_field_$name -licicle_device -Wl,-rpath,'$ORIGIN' -o "$OUT/libicicle_curve_$name.so"
 }
 

@@ -300,3 +300,33 @@ def ntt_naive(f: NttField, x, w_n: int, inverse: bool = False, coset_gen: int = 
             o2[bitrev(k, logn)] = out[k]
         out = o2
     return out
+
+
+def ecntt_naive(c: Curve, f: NttField, pts, w_n: int, inverse: bool = False, coset_gen: int = 1, ordering: str = "NN"):
+    """O(N^2) definition of the reference ECNTT for one row: ntt_naive with group elements in place of field
+    elements (the CPU backend instantiates its NTT with E = projective_t, backend/cpu/src/curve/cpu_ecntt.cpp)."""
+    n = len(pts)
+    logn = n.bit_length() - 1
+    p = f.p
+    xin = list(pts)
+    if ordering[0] == "R":
+        xin = [pts[bitrev(j, logn)] for j in range(n)]
+    if not inverse and coset_gen != 1:
+        xin = [ec_mul(c, pow(coset_gen, j, p), v) for j, v in enumerate(xin)]
+    w = pow(w_n, -1, p) if inverse else w_n
+    out = []
+    for k in range(n):
+        acc = INF
+        for j in range(n):
+            acc = ec_add(c, acc, ec_mul(c, pow(w, j * k, p), xin[j]))
+        out.append(acc)
+    if inverse:
+        ninv = pow(n, -1, p)
+        ginv = pow(coset_gen, -1, p)
+        out = [ec_mul(c, ninv * pow(ginv, j, p) % p, v) for j, v in enumerate(out)]
+    if ordering[1] == "R":
+        o2 = [None] * n
+        for k in range(n):
+            o2[bitrev(k, logn)] = out[k]
+        out = o2
+    return out

@@ -218,6 +218,17 @@ class RefCurve:
         a = np.ascontiguousarray(a)
         return bool(fn(_p(a)))
 
+    def ecntt(self, points: np.ndarray, size: int, direction: int, batch=1, columns_batch=False, ordering=0,
+              coset_gen=1) -> np.ndarray:
+        """<curve>_ecntt (src/ecntt.cpp:7-11) on projective_t[size*batch]; needs RefScalarNttField(name).init_domain"""
+        cfg = NTTConfigU256(None, _w8(coset_gen), batch, columns_batch, ordering, False, False, False, None)
+        out = np.zeros_like(points)
+        fn = getattr(self.lib, f"{self.name}_ecntt")
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        rc = fn(_p(points), size, direction, ctypes.byref(cfg), _p(out))
+        assert rc == 0, f"reference ecntt failed rc={rc}"
+        return out
+
     def generate_affine_points(self, n: int) -> np.ndarray:
         """projective_t::rand_host_many(affine_t*, n) (projective.h:43-53): period-100 repetition."""
         out = np.zeros((n, 2 * self.L), dtype=np.uint32)

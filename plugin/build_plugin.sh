@@ -25,7 +25,7 @@ $CXX $FLAGS -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$HERE/hip_backend_device
 for spec in bn254:1 bls12_381:2; do
   c=${spec%%:*}; id=${spec##*:}
   echo "[plugin] curve $c"
-  $CXX $FLAGS -DCURVE_ID=$id -DFIELD_ID=$id -DCURVE=$c -DFIELD=$c -DICICLE_FFI_PREFIX=$c -DMSM=ON -DG2_ENABLED "$HERE/hip_backend_curve.cpp" \
+  $CXX $FLAGS -DCURVE_ID=$id -DFIELD_ID=$id -DCURVE=$c -DFIELD=$c -DICICLE_FFI_PREFIX=$c -DMSM=ON -DNTT=ON -DECNTT=ON -DG2_ENABLED "$HERE/hip_backend_curve.cpp" \
     -L"$REF" -licicle_curve_$c -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_curve_$c.so"
 done
 for spec in bn254:1 bls12_381:2; do   # the curves' scalar fields: Montgomery conversion + NTT over 32-byte elements

@@ -6,6 +6,7 @@
 // through byte-for-byte (same 40-byte layout) except `ext`, whose C++ object belongs to the reference.
 #include <cstring>
 #include "icicle/backend/msm_backend.h"
+#include "icicle/backend/ecntt_backend.h"
 #include "icicle/curves/montgomery_conversion.h"
 #include "icicle/curves/curve_config.h"
 #include "icicle/utils/utils.h"
@@ -100,3 +101,15 @@ REGISTER_MSM_G2_PRE_COMPUTE_BASES_BACKEND("HIP", hip_g2_msm_precompute);
 REGISTER_AFFINE_G2_CONVERT_MONTGOMERY_BACKEND("HIP", hip_g2_affine_convert);
 REGISTER_PROJECTIVE_G2_CONVERT_MONTGOMERY_BACKEND("HIP", hip_g2_projective_convert);
 #endif // G2_ENABLED
+
+// ECNTT (icicle/include/icicle/backend/ecntt_backend.h:16-33): NTTConfig<scalar_t> is passed through byte-for-byte
+static_assert(sizeof(NTTConfig<scalar_t>) == sizeof(hip_ntt_config_u256_t), "NTTConfig<scalar_t> layout drifted");
+static eIcicleError hip_ecntt(const Device& device, const projective_t* input, int size, NTTDir dir, const NTTConfig<scalar_t>& config, projective_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  hip_ntt_config_u256_t c;
+  std::memcpy(&c, &config, sizeof(c));
+  c.ext = nullptr;
+  return (eIcicleError)HIP_FN(ecntt)(input, size, (int)dir, &c, output);
+}
+REGISTER_ECNTT_BACKEND("HIP", hip_ecntt);

@@ -85,4 +85,6 @@ HIP_DECLARE_FIELD(koalabear)
   int icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t, uint32_t*);
 HIP_DECLARE_SCALAR_FIELD(bn254)
 HIP_DECLARE_SCALAR_FIELD(bls12_381)
+int icicle_hip_bn254_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
+int icicle_hip_bls12_381_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 }

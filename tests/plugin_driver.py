@@ -150,6 +150,17 @@ def main():
         assert sf.get_root_of_unity_from_domain(logn) == pyref.omega(F, logn)
         assert np.array_equal(sf.ntt(x, n, 0, batch=batch), exp_f)
         assert np.array_equal(sf.ntt(x, n, 1, batch=batch, ordering=3, coset_gen=7, columns_batch=True), exp_i)
+        # ECNTT on the same domain: "HIP" vs "CPU"
+        Cc = pyref.CURVES[name]
+        cobj = ref.RefCurve(name)
+        m = 64
+        proj = np.concatenate([cobj.generate_affine_points(m), np.tile(to_words([1], Cc.limbs_q), (m, 1))], axis=1)
+        proj = np.ascontiguousarray(proj.astype(np.uint32)).reshape(-1)
+        got_e = cobj.ecntt(proj, m, 0, ordering=1, coset_gen=3)
+        assert rt.set_device("CPU", 0) == 0
+        exp_e = cobj.ecntt(proj, m, 0, ordering=1, coset_gen=3)
+        assert np.array_equal(cobj.to_affine(got_e.reshape(m, -1)), cobj.to_affine(exp_e.reshape(m, -1)))
+        assert rt.set_device("HIP", 0) == 0
         sf.release_domain()
         assert rt.set_device("CPU", 0) == 0
         sf.release_domain()

@@ -1,0 +1,107 @@
+"""GPU parity: <curve>_ecntt through the C ABI vs the reference CPU backend (which runs its generic NTT with
+E = projective_t) and the O(N^2) definition. Projective representatives depend on the order of additions, so
+the comparison is on to_affine() limbs, as for the MSM (icicle/tests/test_curve_api.cpp ecntt test compares
+main vs reference device results the same way)."""
+import numpy as np
+import pytest
+
+from oracle import pyref, ref
+from tests.util import cached_points, from_words, points_to_array, rand_scalars, to_words
+
+pytestmark = pytest.mark.gpu
+CURVES = ["bn254", "bls12_381"]
+DOMAIN_LOG = 12
+
+
+def to_projective(C, pts):
+    """affine python points -> projective_t words; identity -> (0 : 1 : 0)"""
+    L = C.limbs_q
+    rows = []
+    for p in pts:
+        if p == pyref.INF:
+            rows.append(np.concatenate([to_words([0], L)[0], to_words([1], L)[0], to_words([0], L)[0]]))
+        else:
+            rows.append(np.concatenate([to_words([p[0]], L)[0], to_words([p[1]], L)[0], to_words([1], L)[0]]))
+    return np.ascontiguousarray(np.stack(rows).astype(np.uint32))
+
+
+def affine_list(refc, C, proj_words, n):
+    L = C.limbs_q
+    aff = refc.to_affine(proj_words.reshape(n, 3 * L))
+    return [(from_words(a[:L]), from_words(a[L:])) for a in aff]
+
+
+@pytest.fixture(scope="module", params=CURVES)
+def env(request, hip):
+    from icicle_amd import ntt as N
+
+    cname = request.param
+    F = pyref.NTT_FIELDS[cname]
+    sf = ref.RefScalarNttField(cname)
+    root = N.get_root_of_unity(cname, 1 << DOMAIN_LOG)
+    N.init_domain(cname, root)
+    sf.init_domain(root)
+    yield cname, pyref.CURVES[cname], F, ref.RefCurve(cname), N
+    N.release_domain(cname)
+    sf.release_domain()
+
+
+def test_ecntt_vs_definition(env, hip):
+    cname, C, F, refc, N = env
+    for logn in (0, 1, 3):
+        n = 1 << logn
+        pts = list(cached_points(C, n))
+        if n >= 4:
+            pts[2] = pyref.INF
+        x = to_projective(C, pts).reshape(-1)
+        y = N.ecntt(cname, x, N.FORWARD)
+        assert affine_list(refc, C, y, n) == pyref.ecntt_naive(C, F, pts, pyref.omega(F, logn))
+        back = N.ecntt(cname, y, N.INVERSE)
+        assert affine_list(refc, C, back, n) == pts
+        cfg = hip.NTTConfigU256.default()
+        cfg.ordering = N.kRR
+        cfg.set_coset_gen(7)
+        z = N.ecntt(cname, x, N.INVERSE, cfg)
+        assert affine_list(refc, C, z, n) == pyref.ecntt_naive(C, F, pts, pyref.omega(F, logn), inverse=True, coset_gen=7, ordering="RR")
+
+
+@pytest.mark.parametrize("logn", [2, 5, 8, 10])
+def test_ecntt_matrix_vs_reference(env, hip, logn):
+    cname, C, F, refc, N = env
+    rng = np.random.default_rng(500 + logn)
+    n = 1 << logn
+    L = C.limbs_q
+    for trial in range(3 if logn < 10 else 1):
+        batch = int(rng.choice([1, 2, 3])) if logn < 10 else 1
+        columns = bool(rng.integers(0, 2))
+        ordering = int(rng.integers(0, 6))
+        direction = int(rng.integers(0, 2))
+        coset = 1 if rng.integers(0, 2) else rand_scalars(rng, 1, F.p)[0] or 3
+        base = refc.generate_affine_points(n * batch)  # period-100 repetition: equal points and P + P occur
+        proj = np.concatenate([base, np.tile(to_words([1], L), (n * batch, 1))], axis=1).astype(np.uint32)
+        x = np.ascontiguousarray(proj).reshape(-1)
+        cfg = hip.NTTConfigU256.default()
+        cfg.batch_size, cfg.columns_batch, cfg.ordering = batch, columns, ordering
+        cfg.set_coset_gen(coset)
+        got = N.ecntt(cname, x, direction, cfg)
+        exp = refc.ecntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset)
+        assert np.array_equal(refc.to_affine(got.reshape(-1, 3 * L)), refc.to_affine(exp.reshape(-1, 3 * L))), \
+            (cname, logn, batch, columns, ordering, direction, hex(coset))
+
+
+def test_ecntt_device_and_errors(env, hip):
+    cname, C, F, refc, N = env
+    from icicle_amd.runtime import DeviceVec
+
+    n = 64
+    L = C.limbs_q
+    pts = list(cached_points(C, n))
+    x = to_projective(C, pts).reshape(-1)
+    d_in, d_out = DeviceVec.from_host(x), DeviceVec.from_host(np.zeros_like(x))
+    N.ecntt(cname, d_in, N.FORWARD, out=d_out, size=n)
+    y = d_out.to_host()
+    assert np.array_equal(refc.to_affine(y.reshape(n, 3 * L)), refc.to_affine(refc.ecntt(x, n, 0).reshape(n, 3 * L)))
+    with pytest.raises(hip.IcicleError):
+        N.ecntt(cname, x, N.FORWARD, size=48)  # not a power of two
+    with pytest.raises(hip.IcicleError):
+        N.ecntt(cname, x, N.FORWARD, size=1 << (DOMAIN_LOG + 1))  # larger than the domain
