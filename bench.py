@@ -143,10 +143,14 @@ def main():
         m = pmc["msm_bn254_2^26"]
         roofline["traffic"] = (m["fetch_size_kb_raw"] * m["fetch_correction"] + m["write_size_kb"]) * 1024 / 1e9
         roofline["traffic_unit"] = "GB per launch (FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)"
-    # secondary: integer-ALU view. mixed adds per MSM = n * windows(c=16 -> 16); 10 field muls each
-    nwin = 16
-    madds = n * nwin
-    roofline["alu"] = {"mixed_adds_per_s": madds / (acc_ms * 1e-3), "mixed_adds": madds}
+    # secondary: integer-ALU view. mixed adds per MSM = n * windows; 8M + 2S field operations each
+    pc, pw = ctypes.c_int(), ctypes.c_int()
+    pcfg = MSMConfig.default()
+    pcfg.c = args.msm_c
+    check(lib.icicle_hip_msm_plan(n, 254, ctypes.byref(pcfg), ctypes.byref(pc), ctypes.byref(pw)), "msm_plan")
+    madds = n * pw.value
+    roofline["alu"] = {"window_bits": pc.value, "windows": pw.value, "mixed_adds": madds,
+                       "mixed_adds_per_s": madds / (acc_ms * 1e-3)}
 
     out = {
         "metric": "bn254_msm_2^26_per_sec", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,

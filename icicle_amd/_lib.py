@@ -170,7 +170,7 @@ API_SYMBOLS = (
     + [f"icicle_hip_{f}_{s}" for f in SCALAR_NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain",
                                                                  "get_root_of_unity_from_domain")]
     + [f"{pre}{c}_ecntt" for pre in ("", "icicle_hip_") for c in CURVES]
-    + ["icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device"]
+    + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device"]
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
                                                           "get_root_of_unity_from_domain")]
@@ -243,3 +243,4 @@ for _n in API_SYMBOLS:
         getattr(lib, _n).argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_bool, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
 lib.icicle_hip_kernel_timing.argtypes = [ctypes.c_int, ctypes.c_bool, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
 lib.icicle_hip_enable_kernel_timing.argtypes = [ctypes.c_bool]
+lib.icicle_hip_msm_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]

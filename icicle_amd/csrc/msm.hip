@@ -51,4 +51,13 @@ icicle_error_t bls12_381_hip_generate_affine_points(void* out, int n, uint64_t k
 {
   GUARDED(generate_run<bls12_381_g1>(out, n, k0, out_on_device, (hipStream_t)stream));
 }
+// the window plan the backend would use (bench.py's operation counts)
+icicle_error_t icicle_hip_msm_plan(int msm_size, int scalar_bits, const icicle_msm_config_t* config, int* c, int* nwin)
+{
+  if (!config || !c || !nwin || msm_size < 0 || scalar_bits <= 0) return ICICLE_INVALID_ARGUMENT;
+  const MsmPlan pl = make_plan(std::max(msm_size, 1), scalar_bits, *config);
+  *c = pl.c;
+  *nwin = pl.nwin;
+  return ICICLE_SUCCESS;
+}
 }

@@ -184,7 +184,7 @@ namespace icicle_hip {
 
   // threads per block: 512, except the 2^12-point variant (NQ0 = 4, NR = 3; <= 124 VGPRs) which runs 1024 so
   // that a tile is 4 columns wide
-  constexpr int ntt_fast_max_threads(int nq0, int nr) { return (nq0 == 4 && nr == 3) ? 1024 : 512; }
+  constexpr int ntt_fast_max_threads(int nq0, int nr) { return (nq0 == 4 && nr >= 2) ? 1024 : 512; }
 
   template <class PR, int NQ0, int NR, bool DIF, bool INV>
   __global__ __launch_bounds__(ntt_fast_max_threads(NQ0, NR)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
@@ -257,27 +257,64 @@ namespace icicle_hip {
     const uint64_t K0 = (pd.pidx <= 1) ? ((uint64_t)ct * T + tB) : (((uint64_t)ct * T + tB) + (uint64_t)pd.n0 * a);
 
     const uint32_t rloc0 = blockIdx.y * rows_per_block;
-    for (uint32_t rr = 0; rr < rows_per_block && rloc0 + rr < nl.nrows_launch; rr++) {
-      const uint32_t rloc = rloc0 + rr;         // row inside this launch's group
-      const uint32_t bprime = nl.row0 + rloc;   // absolute row
-      const uint64_t boff_abs = (uint64_t)(bprime / nl.lanes) * nl.bs + (bprime % nl.lanes);
-      const uint64_t boff_rel = (uint64_t)(rloc / nl.lanes) * nl.bs + (rloc % nl.lanes);
-      const uint32_t* __restrict__ pin = in + (nl.src_rel ? boff_rel : boff_abs);
-      uint32_t* __restrict__ pout = out + (nl.dst_rel ? boff_rel : boff_abs);
-      uint32_t* tile = lds + (size_t)(rr & 1) * L * TP;
-
+    auto row_offset = [&](uint32_t rloc, bool rel) -> uint64_t {
+      const uint32_t r = rel ? rloc : nl.row0 + rloc; // row inside this launch's group / absolute row
+      return (uint64_t)(r / nl.lanes) * nl.bs + (r % nl.lanes);
+    };
+    // The E operands a thread feeds into its first round, straight from HBM. They are fetched one batch row
+    // AHEAD (software prefetch into registers): without it a block alternates between a load phase and a
+    // compute/LDS/store phase and the waves sit parked on s_waitcnt for more than half of their cycles
+    // (SQ_WAIT_ANY 0.52-0.57 on the column passes, profiles/r01_notes.md).
+    auto load_row = [&](uint32_t rloc, uint32_t* x) {
+      const uint32_t* __restrict__ pin = in + row_offset(rloc, nl.src_rel != 0);
       if (!DIF) {
-        // ================= column pass, DIT =================
 #pragma unroll
         for (int u = 0; u < G0; u++) {
           const uint32_t gi = gB * G0 + u;
           const uint32_t kb = (KB_BITS == 0) ? 0u : (__brev(gi) >> (32 - (KB_BITS > 0 ? KB_BITS : 1)));
           const uint32_t* p = pin + (in_base + (uint64_t)kb * pd.in_sk + (uint64_t)tB * pd.in_st) * es;
           const uint64_t step = (pd.in_sk << KB_BITS) * es;
-          uint32_t x[1 << NQ0];
 #pragma unroll
           for (int m = 0; m < (1 << NQ0); m++) // slot m <- source row kb + brev(m) * 2^(s-NQ0)
-            x[m] = p[(uint64_t)brev_c<NQ0>(m) * step];
+            x[u * (1 << NQ0) + m] = p[(uint64_t)brev_c<NQ0>(m) * step];
+        }
+      } else if (NR == 1) {
+        const uint32_t* p = pin + (in_base + (uint64_t)tB * pd.in_st) * es;
+#pragma unroll
+        for (int m = 0; m < (1 << NQ0); m++)
+          x[m] = p[(uint64_t)m * es];
+      } else { // top round: mapping A, natural rows k = gA + m * L/16
+        const uint32_t* p = pin + (in_base + (uint64_t)gA + (uint64_t)tA * pd.in_st) * es;
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+          x[m] = p[((uint64_t)m << QT) * es];
+      }
+    };
+    // (three-round variants, s >= 9, are already at 110-150 VGPRs: they load each row when it is needed)
+    constexpr bool PREFETCH = NR <= 2;
+    uint32_t xin[E];
+    if (PREFETCH && rloc0 < nl.nrows_launch) load_row(rloc0, xin);
+    for (uint32_t rr = 0; rr < rows_per_block && rloc0 + rr < nl.nrows_launch; rr++) {
+      const uint32_t rloc = rloc0 + rr;
+      uint32_t* __restrict__ pout = out + row_offset(rloc, nl.dst_rel != 0);
+      uint32_t* tile = lds + (size_t)(rr & 1) * L * TP;
+      uint32_t xnext[PREFETCH ? E : 1];
+      const bool has_next = PREFETCH && rr + 1 < rows_per_block && rloc + 1 < nl.nrows_launch;
+      if (PREFETCH) {
+        if (has_next) load_row(rloc + 1, xnext);
+      } else {
+        load_row(rloc, xin);
+      }
+
+      if (!DIF) {
+        // ================= column pass, DIT =================
+#pragma unroll
+        for (int u = 0; u < G0; u++) {
+          const uint32_t gi = gB * G0 + u;
+          uint32_t x[1 << NQ0];
+#pragma unroll
+          for (int m = 0; m < (1 << NQ0); m++)
+            x[m] = xin[u * (1 << NQ0) + m];
           ntt_stages<S, NQ0, false, true>(x, w0);
           if (NR == 1) {
             uint32_t* q = pout + (in_base + (uint64_t)tB * pd.in_st) * es;
@@ -318,11 +355,10 @@ namespace icicle_hip {
       } else {
         // ================= row pass (last pass), DIF =================
         if (NR == 1) {
-          const uint32_t* p = pin + (in_base + (uint64_t)tB * pd.in_st) * es;
           uint32_t x[1 << NQ0];
 #pragma unroll
           for (int m = 0; m < (1 << NQ0); m++)
-            x[m] = p[(uint64_t)m * es];
+            x[m] = xin[m];
           ntt_stages<S, NQ0, true, true>(x, w0);
           uint32_t* q = pout + K0 * es;
           const uint64_t step = pd.out_sk * es;
@@ -330,12 +366,11 @@ namespace icicle_hip {
           for (int m = 0; m < (1 << NQ0); m++)
             q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
         } else {
-          { // top round: mapping A, natural rows k = gA + m * L/16 straight from HBM
-            const uint32_t* p = pin + (in_base + (uint64_t)gA + (uint64_t)tA * pd.in_st) * es;
+          { // top round: mapping A, natural rows k = gA + m * L/16 (prefetched from HBM)
             uint32_t x[16];
 #pragma unroll
             for (int m = 0; m < 16; m++)
-              x[m] = p[((uint64_t)m << QT) * es];
+              x[m] = xin[m];
             ntt_stages<S, 4, true, false>(x, wr[NR - 2]);
 #pragma unroll
             for (int m = 0; m < 16; m++)
@@ -375,6 +410,11 @@ namespace icicle_hip {
         }
       }
       // the next row uses the other LDS buffer; the barrier inside its processing orders the reuse after that
+      if (PREFETCH && has_next) {
+#pragma unroll
+        for (int m = 0; m < E; m++)
+          xin[m] = xnext[m];
+      }
     }
   }
 
@@ -683,8 +723,11 @@ namespace icicle_hip {
       const uint64_t L = (uint64_t)1 << parts[p];
       // fast path: block = T * L/16 threads (<= 512), LDS = 2 buffers of L*(T+1) words (<= 160 KiB)
       const uint64_t epb = L >= 16 ? 16 : L;
-      const uint64_t maxthr = (parts[p] == 12) ? 1024 : 512; // ntt_fast_max_threads()
-      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, maxthr * epb / L));
+      const uint64_t maxthr = (parts[p] == 12 || parts[p] == 8) ? 1024 : 512; // ntt_fast_max_threads()
+      static const int tcol = getenv("ICICLE_HIP_NTT_TCOL") ? atoi(getenv("ICICLE_HIP_NTT_TCOL")) : 32;
+      static const int trow = getenv("ICICLE_HIP_NTT_TROW") ? atoi(getenv("ICICLE_HIP_NTT_TROW")) : 32;
+      const uint64_t tcap = (uint64_t)std::max(1, std::min(64, (p == P - 1) ? trow : tcol));
+      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tcap, maxthr * epb / L));
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
         tmax >>= 1;
       PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);

@@ -234,6 +234,9 @@ icicle_error_t bls12_381_g2_projective_convert_montgomery(const void* input, uin
 
 /* ---- backend-specific helpers (not part of the reference ABI) ---- */
 const char* icicle_hip_version(void);
+/* The window plan msm() would use for this size / config: c = window bits, nwin = number of c-bit windows of a
+ * scalar_bits-bit scalar (signed digits, so ceil((scalar_bits + 1) / c)). For operation counts in benchmarks. */
+icicle_error_t icicle_hip_msm_plan(int msm_size, int scalar_bits, const icicle_msm_config_t* config, int* c, int* nwin);
 /* Device-side synthetic input generator for benchmarks: fills `out` (device or host per flag) with
  * `n` DISTINCT affine points (k0 + i) * G in the reference's canonical affine layout. */
 icicle_error_t bn254_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream);

@@ -1,0 +1,81 @@
+// Strided-tile copy microbenchmark: what HBM bandwidth does the NTT column-pass access pattern allow?
+// A block copies a [ROWS x T] tile of u32: ROWS rows spaced `stride` elements apart, T contiguous words per row
+// (in place: read then write the same addresses), exactly the traffic of one k_ntt_fast column pass without the
+// arithmetic. Build: hipcc --offload-arch=gfx950 -O3 strided_ubench.hip -o strided_ubench
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CK(x)                                                                                                          \
+  do {                                                                                                                 \
+    hipError_t e = (x);                                                                                                \
+    if (e != hipSuccess) {                                                                                             \
+      printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__);                                                  \
+      return 1;                                                                                                        \
+    }                                                                                                                  \
+  } while (0)
+
+// grid.x = tiles; tile index -> (a, ct): base = a * rows * stride + ct * T ; tiles_per_a = stride / T
+template <int RPT> // rows per thread
+__global__ __launch_bounds__(512) void k_tile_copy(uint32_t* __restrict__ buf, uint64_t stride, uint32_t T, uint32_t rows, uint32_t tiles_per_a, int write)
+{
+  const uint32_t a = blockIdx.x / tiles_per_a, ct = blockIdx.x % tiles_per_a;
+  uint32_t* base = buf + (uint64_t)a * rows * stride + (uint64_t)ct * T;
+  const uint32_t t = threadIdx.x % T, g = threadIdx.x / T; // g in [0, rows / RPT)
+  uint32_t v[RPT];
+#pragma unroll
+  for (int m = 0; m < RPT; m++)
+    v[m] = base[(uint64_t)(g + m * (rows / RPT)) * stride + t];
+  if (write) {
+#pragma unroll
+    for (int m = 0; m < RPT; m++)
+      base[(uint64_t)(g + m * (rows / RPT)) * stride + t] = v[m] + 1;
+  } else {
+    uint32_t s = 0;
+#pragma unroll
+    for (int m = 0; m < RPT; m++)
+      s ^= v[m];
+    if (s == 0x12345678u) base[t] = s; // never true in practice: keeps the loads alive
+  }
+}
+
+int main()
+{
+  const uint64_t n = 1ull << 30; // 4 GiB
+  uint32_t* d;
+  CK(hipMalloc(&d, n * 4));
+  CK(hipMemset(d, 1, n * 4));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const uint32_t rows = 256;
+  struct Case {
+    uint64_t stride;
+    uint32_t T;
+    const char* what;
+  };
+  const Case cases[] = {{65536, 32, "pass 0 (stride 256 KiB, 128 B runs)"}, {256, 32, "pass 1 (stride 1 KiB, 128 B runs)"},
+                        {65536, 64, "stride 256 KiB, 256 B runs"},          {256, 64, "stride 1 KiB, 256 B runs"},
+                        {32, 32, "contiguous (stride = run)"}};
+  for (int write = 1; write >= 0; write--)
+    for (const Case& c : cases) {
+      const uint32_t tiles_per_a = (uint32_t)(c.stride / c.T);
+      const uint64_t per_a = (uint64_t)rows * c.stride;
+      const uint32_t ntiles = (uint32_t)(n / per_a) * tiles_per_a;
+      const unsigned threads = c.T * (rows / 16);
+      float best = 1e9;
+      for (int it = 0; it < 4; it++) {
+        CK(hipEventRecord(e0));
+        k_tile_copy<16><<<ntiles, threads>>>(d, c.stride, c.T, rows, tiles_per_a, write);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+      }
+      const double bytes = (double)n * 4 * (write ? 2 : 1);
+      printf("%-44s %s  %8.3f ms  %7.0f GB/s\n", c.what, write ? "read+write" : "read only ", best, bytes / best / 1e6);
+    }
+  return 0;
+}
