@@ -119,19 +119,18 @@ namespace icicle_hip {
   };
 
   // digit word: |d| | (d<0)<<31, |d| in [0, 2^(c-1)], 0 = skip. Signed recoding as cpu_msm.hpp:289-295.
+  // Windows are consumed in order, lowest first: the scalar is shifted right by c after each digit, so every
+  // register index is static (a dynamically indexed w[] lives in scratch memory: 44 B/lane and the kernel waited
+  // on it for 83 % of its cycles).
   struct DigitIter {
     uint32_t w[9];
     uint32_t carry = 0;
-    __device__ __forceinline__ uint32_t next(int wi, int c)
+    __device__ __forceinline__ uint32_t next(int c)
     {
-      const int bit = wi * c;
-      const int word = bit >> 5, sh = bit & 31;
-      uint32_t v = 0;
-      if (word < 8) {
-        const uint64_t two = ((uint64_t)w[word + 1] << 32) | w[word];
-        v = (uint32_t)(two >> sh) & ((1u << c) - 1);
-      }
-      v += carry;
+      uint32_t v = (w[0] & ((1u << c) - 1)) + carry;
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        w[k] = __funnelshift_r(w[k], w[k + 1], c); // (w[k+1]:w[k]) >> c, c < 32
       const uint32_t half = 1u << (c - 1);
       if (v > half) {
         carry = 1;
@@ -175,7 +174,7 @@ namespace icicle_hip {
     DigitIter it;
     load_scalar<C>(it, scalars, t, scalars_refmont);
     for (int wi = 0; wi < nwin; wi++)
-      dig[(b * nwin + wi) * n + i] = it.next(wi, c);
+      dig[(b * nwin + wi) * n + i] = it.next(c);
   }
 
   // exclusive prefix of one value per thread over the block (blockDim.x a multiple of 64, <= 1024);
@@ -247,9 +246,18 @@ namespace icicle_hip {
       const int wi = j * wpf + wp;
       if (wi >= nwin) break;
       const uint32_t* d = dig + (rowbase + wi) * n;
-      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t key = d[i] & 0x7fffffffu;
-        if (key) atomicAdd(&lds[(key - 1) >> sp.lb], 1u);
+      for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 8 * blockDim.x) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { // all loads first: the histogram update depends on each of them
+          const int i = i0 + u * (int)blockDim.x;
+          v[u] = i < hi ? d[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const uint32_t key = v[u] & 0x7fffffffu;
+          if (key) atomicAdd(&lds[(key - 1) >> sp.lb], 1u);
+        }
       }
     }
     __syncthreads();
@@ -278,7 +286,21 @@ namespace icicle_hip {
       const int wi = j * wpf + wp;
       if (wi >= nwin) break;
       const uint32_t* d = dig + (rowbase + wi) * n;
+      // the digit words of the NEXT tile are fetched before this tile is ranked / staged / written, so the
+      // HBM reads overlap the LDS phases (the kernel used to be parked on s_waitcnt for 81 % of its cycles)
+      auto fetch = [&](int tile0, uint32_t* buf) {
+#pragma unroll
+        for (int it = 0; it < SORT_EPT; it++) {
+          const int i = tile0 + it * 1024 + threadIdx.x;
+          buf[it] = i < hi ? d[i] : 0u;
+        }
+      };
+      uint32_t cur[SORT_EPT];
+      fetch(lo, cur);
       for (int tile0 = lo; tile0 < hi; tile0 += SORT_TS) {
+        uint32_t nxt[SORT_EPT];
+        const bool more = tile0 + (int)SORT_TS < hi;
+        if (more) fetch(tile0 + (int)SORT_TS, nxt);
         if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
         __syncthreads();
         uint32_t el[SORT_EPT], dr[SORT_EPT]; // element, (dest << 16 | rank)
@@ -287,7 +309,7 @@ namespace icicle_hip {
           const int i = tile0 + it * 1024 + threadIdx.x;
           dr[it] = 0xffffffffu;
           if (i < hi) {
-            const uint32_t dv = d[i];
+            const uint32_t dv = cur[it];
             const uint32_t key = dv & 0x7fffffffu;
             if (key) {
               const uint32_t km = key - 1, h = km >> sp.lb;
@@ -320,36 +342,63 @@ namespace icicle_hip {
           dst[t.gbase[h] + (sidx - t.cnt[h])] = t.stage[sidx];
         }
         __syncthreads();
+        if (more) {
+#pragma unroll
+          for (int it = 0; it < SORT_EPT; it++)
+            cur[it] = nxt[it];
+        }
       }
     }
   }
 
-  // exclusive scan of one window's [2^hb][nblk] counters (partition-major, block-minor), in place
-  // into offA (positions relative to the window's region); one 1024-thread block per window.
-  static __global__ __launch_bounds__(1024) void k_scan_a(const uint32_t* __restrict__ cntA, uint32_t* __restrict__ offA, uint32_t m)
+  // Row-wise exclusive scans (pass-A counter tables [2^hb][nblk] per window, bucket counts per window).
+  // Two launches over (chunk, row): chunk sums, then each chunk scans itself on top of the sums before it --
+  // a single block per row left 243 of 256 CUs idle and took ~1 ms per table at 2^26.
+  constexpr uint32_t SCAN_CHUNK = 8192; // 1024 threads x 8 consecutive elements
+  static __global__ __launch_bounds__(1024) void k_scan_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ sums, uint32_t m)
   {
-    __shared__ uint32_t part[1024];
-    const size_t base = (size_t)blockIdx.x * m;
-    const uint32_t per = (m + 1023) / 1024;
-    const uint32_t lo = min(m, threadIdx.x * per), hi = min(m, lo + per);
-    uint32_t s = 0;
-    for (uint32_t k = lo; k < hi; k++)
-      s += cntA[base + k];
-    part[threadIdx.x] = s;
+    __shared__ uint32_t wsum[32];
+    const uint32_t c = blockIdx.x, row = blockIdx.y, nchunks = gridDim.x;
+    const uint32_t* src = in + (size_t)row * m;
+    const uint32_t k0 = c * SCAN_CHUNK + threadIdx.x * 8;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      v += (k0 + j < m) ? src[k0 + j] : 0u;
+    const uint32_t ex = block_exscan(v, wsum);
+    if (threadIdx.x == 1023) sums[(size_t)row * nchunks + c] = ex + v;
+  }
+  static __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict__ in, const uint32_t* __restrict__ sums, uint32_t* __restrict__ out, uint32_t* __restrict__ out2, uint32_t* __restrict__ totals, uint32_t m)
+  {
+    __shared__ uint32_t wsum[32];
+    __shared__ uint32_t sbase;
+    const uint32_t c = blockIdx.x, row = blockIdx.y, nchunks = gridDim.x;
+    // sum of the chunks before this one
+    uint32_t part = 0;
+    for (uint32_t q = threadIdx.x; q < c; q += blockDim.x)
+      part += sums[(size_t)row * nchunks + q];
+    const uint32_t pex = block_exscan(part, wsum);
+    if (threadIdx.x == 1023) sbase = pex + part;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
-      __syncthreads();
-      part[threadIdx.x] += v;
-      __syncthreads();
+    const uint32_t base = sbase;
+    const uint32_t* src = in + (size_t)row * m;
+    const uint32_t k0 = c * SCAN_CHUNK + threadIdx.x * 8;
+    uint32_t x[8], v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      x[j] = (k0 + j < m) ? src[k0 + j] : 0u;
+      v += x[j];
     }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t k = lo; k < hi; k++) {
-      const uint32_t x = cntA[base + k];
-      offA[base + k] = run;
-      run += x;
+    uint32_t run = base + block_exscan(v, wsum);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (k0 + j < m) {
+        out[(size_t)row * m + k0 + j] = run;
+        if (out2) out2[(size_t)row * m + k0 + j] = run;
+      }
+      run += x[j];
     }
-    if (threadIdx.x == 1023) offA[(size_t)gridDim.x * m + blockIdx.x] = part[1023]; // window total
+    if (totals && c == nchunks - 1 && threadIdx.x == 1023) totals[row] = run; // row total
   }
 
   // single-level sort (lb == 0): bucket k of window wl IS partition k; count/offs come from pass A's table
@@ -442,38 +491,21 @@ namespace icicle_hip {
     const uint32_t* src = inA + (size_t)wp * cap;
     const int lshift = 31 - sp.lb;
     const uint32_t lmask = nbins - 1;
-    for (uint32_t pos = r0 + threadIdx.x; pos < r1; pos += blockDim.x)
-      atomicAdd(&lds[(src[pos] >> lshift) & lmask], 1u);
+    for (uint32_t p0 = r0 + threadIdx.x; p0 < r1; p0 += 8 * blockDim.x) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t pos = p0 + u * blockDim.x;
+        v[u] = pos < r1 ? src[pos] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (p0 + u * blockDim.x < r1) atomicAdd(&lds[(v[u] >> lshift) & lmask], 1u);
+    }
     __syncthreads();
     uint32_t* cw = count + (size_t)wp * nb + ((size_t)h << sp.lb);
     for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x)
       if (lds[k]) atomicAdd(&cw[k], lds[k]);
-  }
-
-  // exclusive scan over the buckets of one window: one 1024-thread block per window
-  static __global__ __launch_bounds__(1024) void k_scan_buckets(const uint32_t* __restrict__ count, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor, uint32_t nb)
-  {
-    __shared__ uint32_t part[1024];
-    const int wp = blockIdx.x;
-    const uint32_t per = (nb + 1023) / 1024;
-    const uint32_t lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
-    uint32_t s = 0;
-    for (uint32_t k = lo; k < hi; k++)
-      s += count[(size_t)wp * nb + k];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
-      __syncthreads();
-      part[threadIdx.x] += v;
-      __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t k = lo; k < hi; k++) {
-      offs[(size_t)wp * nb + k] = run;
-      cursor[(size_t)wp * nb + k] = run;
-      run += count[(size_t)wp * nb + k];
-    }
   }
 
   static __global__ __launch_bounds__(1024) void k_b_scatter(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted, uint32_t nparts, int wpf, int pf, SortPlan sp, size_t cap, uint32_t nb)
@@ -484,6 +516,7 @@ namespace icicle_hip {
     const uint32_t D = 1u << sp.lb;
     TileLds t = tile_lds(lds, D);
     uint32_t* boffs = lds + tile_lds_bytes(D) / 4;
+    uint32_t* gmap = boffs + sp.nblk + 1; // [SORT_TS / 64]
     const uint32_t wp = p >> sp.hb, h = p & ((1u << sp.hb) - 1);
     const uint32_t nparts_w = 1u << sp.hb;
     const size_t row = (size_t)p * sp.nblk;
@@ -497,18 +530,27 @@ namespace icicle_hip {
     const uint32_t lmask = D - 1;
     const uint32_t imask = (1u << (31 - sp.lb - sp.jb)) - 1;
     const uint32_t jmask = (1u << sp.jb) - 1;
-    for (uint32_t tile0 = r0; tile0 < r1; tile0 += SORT_TS) {
-      if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
-      __syncthreads();
-      uint32_t el[SORT_EPT], dr[SORT_EPT];
+    auto fetch = [&](uint32_t tile0, uint32_t* buf) { // next tile's elements, see k_a_scatter
 #pragma unroll
       for (int it = 0; it < SORT_EPT; it++) {
         const uint32_t pos = tile0 + it * 1024 + threadIdx.x;
-        dr[it] = 0xffffffffu;
+        buf[it] = pos < r1 ? src[pos] : 0u;
+      }
+    };
+    uint32_t cur[SORT_EPT];
+    fetch(r0, cur);
+    for (uint32_t tile0 = r0; tile0 < r1; tile0 += SORT_TS) {
+      uint32_t nxt[SORT_EPT];
+      const bool more = tile0 + SORT_TS < r1;
+      if (more) fetch(tile0 + SORT_TS, nxt);
+      if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
+      // source block (scalar chunk) of an element = last bsrc with boffs[bsrc] <= pos. One binary search per
+      // 64 consecutive positions (256 threads, once per tile); an element then starts from its group's answer
+      // and walks forward (pieces are ~64 elements long, so 0-2 steps) instead of 10 dependent LDS reads each.
+      if (threadIdx.x < SORT_TS / 64) {
+        const uint32_t pos = tile0 + threadIdx.x * 64;
+        uint32_t blo = 0, bhi = sp.nblk;
         if (pos < r1) {
-          const uint32_t e = src[pos];
-          // source block (scalar chunk) of this element: last bsrc with boffs[bsrc] <= pos
-          uint32_t blo = 0, bhi = sp.nblk;
           while (bhi - blo > 1) {
             const uint32_t mid = (blo + bhi) >> 1;
             if (boffs[mid] <= pos) {
@@ -517,6 +559,20 @@ namespace icicle_hip {
               bhi = mid;
             }
           }
+        }
+        gmap[threadIdx.x] = blo;
+      }
+      __syncthreads();
+      uint32_t el[SORT_EPT], dr[SORT_EPT];
+#pragma unroll
+      for (int it = 0; it < SORT_EPT; it++) {
+        const uint32_t pos = tile0 + it * 1024 + threadIdx.x;
+        dr[it] = 0xffffffffu;
+        if (pos < r1) {
+          const uint32_t e = cur[it];
+          uint32_t blo = gmap[(it * 1024 + threadIdx.x) >> 6];
+          while (blo + 1 < (uint32_t)sp.nblk && boffs[blo + 1] <= pos)
+            blo++;
           const uint32_t i = (blo << sp.chunk_log) + (e & imask);
           const uint32_t j = (e >> (31 - sp.lb - sp.jb)) & jmask;
           const uint32_t bin = (e >> lshift) & lmask;
@@ -546,6 +602,11 @@ namespace icicle_hip {
         dst[t.gbase[bin] + (sidx - t.cnt[bin])] = t.stage[sidx];
       }
       __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int it = 0; it < SORT_EPT; it++)
+          cur[it] = nxt[it];
+      }
     }
   }
 
@@ -966,7 +1027,7 @@ namespace icicle_hip {
     const uint32_t maxblkB = (uint32_t)std::min<size_t>(nparts + (elems_max >> CHUNKB_LOG) + 2, 0x7fffffffu);
     const uint32_t ovf_cap = (uint32_t)std::min<size_t>(elems_max / pl.seg + 16, 0x7fffffffu);
 
-    TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt;
+    TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt, d_scansum;
     HIP_TRY(d_mont.alloc((shared ? 1 : (size_t)BB) * npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_dig.alloc((size_t)BB * pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
     if (!single_level) HIP_TRY(d_partA.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
@@ -983,9 +1044,10 @@ namespace icicle_hip {
     HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovfcnt.alloc(16, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_scansum.alloc(TW * (std::max<size_t>((size_t)sp.nblk << sp.hb, nb) / SCAN_CHUNK + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
 
     const size_t ldsA = tile_lds_bytes(1u << sp.hb) + ((size_t)4 << sp.hb);
-    const size_t ldsB = tile_lds_bytes(1u << sp.lb) + ((size_t)sp.nblk + 1) * 4;
+    const size_t ldsB = tile_lds_bytes(1u << sp.lb) + ((size_t)sp.nblk + 1) * 4 + (SORT_TS / 64) * 4;
     if (ldsA > 156 * 1024 || ldsB > 156 * 1024) return ICICLE_INVALID_ARGUMENT;
     HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
@@ -1018,7 +1080,11 @@ namespace icicle_hip {
       // the per-window totals live right after the [tw][2^hb][nblk] table of THIS launch
       k_a_count<<<dim3(sp.nblk, (unsigned)tw), 1024, ((size_t)4 << sp.hb), st>>>(dig, cntA, n, pl.nwin, wpf, pf, sp);
       LAUNCH_CHECK("k_a_count", st);
-      k_scan_a<<<(unsigned)tw, 1024, 0, st>>>(cntA, offA, (uint32_t)(nparts_w * sp.nblk));
+      {
+        const uint32_t m = (uint32_t)(nparts_w * sp.nblk), nch = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        k_scan_sums<<<dim3(nch, (unsigned)tw), 1024, 0, st>>>(cntA, d_scansum.as<uint32_t>(), m);
+        k_scan_apply<<<dim3(nch, (unsigned)tw), 1024, 0, st>>>(cntA, d_scansum.as<uint32_t>(), offA, nullptr, offA + (size_t)tw * m, m);
+      }
       LAUNCH_CHECK("k_scan_a", st);
       if (single_level) {
         k_a_scatter<true><<<dim3(sp.nblk, (unsigned)tw), 1024, ldsA, st>>>(dig, offA, sorted, n, pl.nwin, wpf, pf, sp, cap);
@@ -1036,7 +1102,11 @@ namespace icicle_hip {
         HIP_TRY(hipMemsetAsync(count, 0, gbk * 4, st), ICICLE_COPY_FAILED);
         k_b_count<<<nblkB, 1024, ((size_t)1 << sp.lb) * 4, st>>>(partA, offA, d_bstart.as<uint32_t>(), count, (uint32_t)gparts, (int)tw, sp, cap, nb);
         LAUNCH_CHECK("k_b_count", st);
-        k_scan_buckets<<<(unsigned)tw, 1024, 0, st>>>(count, offs, d_cursor.as<uint32_t>(), nb);
+        {
+          const uint32_t nch = (nb + SCAN_CHUNK - 1) / SCAN_CHUNK;
+          k_scan_sums<<<dim3(nch, (unsigned)tw), 1024, 0, st>>>(count, d_scansum.as<uint32_t>(), nb);
+          k_scan_apply<<<dim3(nch, (unsigned)tw), 1024, 0, st>>>(count, d_scansum.as<uint32_t>(), offs, d_cursor.as<uint32_t>(), nullptr, nb);
+        }
         LAUNCH_CHECK("k_scan_buckets", st);
         k_b_scatter<<<nblkB, 1024, ldsB, st>>>(partA, offA, d_bstart.as<uint32_t>(), d_cursor.as<uint32_t>(), sorted, (uint32_t)gparts, (int)tw, pf, sp, cap, nb);
         LAUNCH_CHECK("k_b_scatter", st);
