@@ -236,6 +236,52 @@ namespace icicle_hip {
       return r;
     }
 
+    // ---- Jacobian doubling chain (x = X/Z^2, y = Y/Z^3) -------------------------------------------
+    // The window combine multiplies each window sum by 2^(c*w): up to ~250 SEQUENTIAL doublings on one
+    // lane, the latency floor of a small MSM. dbl-2009-l (a = 0) costs 2M + 5S against 6M + 2S + 1 for
+    // the complete projective doubling. Not complete: Z = 0 stays Z = 0 and from_jac() maps it (and
+    // only it) back to the identity, which also covers a point of order two (Y = 0 -> Z3 = 0).
+    // Coordinates are kept below 4p (below4) so the same constants hold for Fq and for Fq2 in TIGHT mode.
+    struct Jac {
+      fe x, y, z;
+    };
+    static HD Jac to_jac(const Proj& p) // (X : Y : Z) -> (X Z : Y Z^2 : Z)
+    {
+      Jac r;
+      fe zz = F::sqr(p.z);
+      r.x = F::mul(p.x, p.z);
+      r.y = F::mul(p.y, zz);
+      r.z = p.z;
+      return r;
+    }
+    static HD Proj from_jac(const Jac& j) // (X : Y : Z) -> (X Z : Y : Z^3)
+    {
+      if (F::is_zero(j.z)) return proj_identity();
+      Proj r;
+      fe zz = F::sqr(j.z);
+      r.x = F::mul(j.x, j.z);
+      r.y = j.y;
+      r.z = F::mul(zz, j.z);
+      return r;
+    }
+    static HD Jac dbl_jac(const Jac& p)
+    {
+      fe A = F::sqr(p.x);
+      fe B = F::sqr(p.y);
+      fe CC = F::sqr(B);
+      fe t = F::sqr(F::add(p.x, B));
+      fe D = F::below4(F::dbl(F::template sub<4>(t, F::add(A, CC)))); // 2((X + B)^2 - A - C)
+      fe E = F::add(F::dbl(A), A);                                     // 3 X^2
+      fe Fv = F::sqr(E);
+      Jac r;
+      r.x = F::below4(F::template sub<8>(Fv, F::dbl(D)));             // F - 2D
+      fe m = F::mul(E, F::template sub<4>(D, r.x));
+      fe c8 = F::dbl(F::below4(F::dbl(F::dbl(CC))));                    // 8 Y^4
+      r.y = F::below4(F::template sub<8>(m, c8));
+      r.z = F::dbl(F::mul(p.y, p.z));
+      return r;
+    }
+
     // k * p for a small unsigned k (bucket reduction segment offsets), MSB-first double-and-add
     static HD Proj mul_small(const Proj& p, uint32_t k)
     {

@@ -772,7 +772,8 @@ namespace icicle_hip {
   // 5c. window combine: result = sum_w 2^(c*w) * winsum[w], written in the reference's
   //     projective_t layout (canonical words). One 128-lane block: lane w scales its own window
   //     sum by c*w doublings (the same critical path as a serial Horner, but the doublings of
-  //     different windows overlap), then a tree through LDS. <1 % of the work.
+  //     different windows overlap; Jacobian doubling chain, 2M + 5S per step), then a tree through
+  //     LDS. <1 % of the work at 2^26, but the latency floor of a small MSM.
   //     (A <<<1,1>>> serial Horner is provably wave-uniform, so hipcc compiles ALL of its field
   //     arithmetic to SALU code, which is several times slower per multiply than the VALU path.)
   template <class C>
@@ -786,8 +787,12 @@ namespace icicle_hip {
     typename E::Proj v = E::proj_identity();
     if (lane < wpf) {
       v = winsum[lane];
-      for (int i = 0; i < lane * c; i++)
-        v = E::dbl(v);
+      if (lane > 0) { // 2^(c*lane) * v: Jacobian doubling chain (ec.cuh), 2M + 5S per step
+        typename E::Jac j = E::to_jac(v);
+        for (int i = 0; i < lane * c; i++)
+          j = E::dbl_jac(j);
+        v = E::from_jac(j);
+      }
     }
     sh[lane] = v;
     __syncthreads();
@@ -848,8 +853,10 @@ namespace icicle_hip {
       p = E::to_proj(a);
     }
     for (int j = 1; j < pf; j++) {
+      typename E::Jac jp = E::to_jac(p);
       for (int s = 0; s < shift; s++)
-        p = E::dbl(p);
+        jp = E::dbl_jac(jp);
+      p = E::from_jac(jp);
       uint32_t o[PW];
       store_affine<C>(o, p, refmont);
       for (int k = 0; k < PW; k++)

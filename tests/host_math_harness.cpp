@@ -104,6 +104,14 @@ namespace {
       E::store_proj_canonical(out, p);
       return 0;
     }
+    case 5: { // the window-combine chain: 2^aux[0] * pts[0] via to_jac / dbl_jac / from_jac
+      auto p = E::words_are_zero(pts) ? E::proj_identity() : E::add(E::to_proj(load(pts)), E::proj_identity()); // a non-trivial Z
+      auto j = E::to_jac(p);
+      for (uint32_t i = 0; i < aux[0]; i++)
+        j = E::dbl_jac(j);
+      E::store_proj_canonical(out, E::from_jac(j));
+      return 0;
+    }
     default: return -1;
     }
   }

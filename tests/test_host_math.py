@@ -111,6 +111,10 @@ def test_ec_ops(lib, ci, c):
     assert got == pyref.INF and raw[1] != 0
     for k in [0, 1, 5, 16]:
         assert run(4, [base[2]], [k])[0] == pyref.ec_mul(c, 1 << k, base[2])
+    for k in [0, 1, 2, 7, 64, 300]:  # Jacobian doubling chain of the window combine
+        assert run(5, [base[2]], [k])[0] == pyref.ec_mul(c, 1 << k, base[2])
+    got, raw = run(5, [pyref.INF], [9])
+    assert got == pyref.INF and raw[1] != 0
 
 
 @pytest.mark.parametrize("ci,c", [(2, pyref.BN254_G2), (3, pyref.BLS12_381_G2)])
@@ -169,6 +173,10 @@ def test_g2_ec_ops(lib, ci, c):
         assert run(2, [base[3]], [k])[0] == pyref.g2_mul(c, k, base[3])
     for k in [0, 1, 5, 16]:
         assert run(4, [base[2]], [k])[0] == pyref.g2_mul(c, 1 << k, base[2])
+    for k in [0, 1, 2, 7, 64, 300]:
+        assert run(5, [base[2]], [k])[0] == pyref.g2_mul(c, 1 << k, base[2])
+    got, raw = run(5, [pyref.INF2], [9])
+    assert got == pyref.INF2 and raw[1] != (0, 0)
 
 
 @pytest.mark.parametrize("fi,f", [(0, pyref.BABYBEAR), (1, pyref.KOALABEAR)])
