@@ -640,10 +640,53 @@ namespace icicle_hip {
     }
   }
 
+  // Size-balanced scheduling. A wave of k_accumulate runs until its longest bucket is done: with ~128 points
+  // per bucket (Poisson, sigma 11) the longest of 64 is ~155, i.e. ~15 % of the lane-cycles of the dominant
+  // kernel were idle (SQ_INSTS_VALU per mixed add 2912 vs ~2540 in the instruction stream). perm[] lists the
+  // buckets by descending size class, so the 64 lanes of a wave get buckets of (almost) the same length and the
+  // empty buckets end up in waves that exit at once. Counting sort over 257 classes of min(count, seg).
+  constexpr uint32_t SZ_BINS = 257;
+  constexpr uint32_t SZ_CHUNK = 16384; // buckets per block (1024 threads x 16)
+  __device__ __forceinline__ uint32_t size_class(uint32_t cnt, uint32_t seg)
+  {
+    const uint32_t q = (uint32_t)(((uint64_t)min(cnt, seg) * 256u) / seg); // 0..256
+    return 256u - q;                                                       // heavy first
+  }
+  static __global__ __launch_bounds__(1024) void k_bsize_count(const uint32_t* __restrict__ count, uint32_t* __restrict__ table, size_t nbk, uint32_t seg)
+  {
+    __shared__ uint32_t hist[SZ_BINS];
+    for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
+      hist[k] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SZ_CHUNK;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const size_t b = base + it * 1024 + threadIdx.x;
+      if (b < nbk) atomicAdd(&hist[size_class(count[b], seg)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
+      table[(size_t)k * gridDim.x + blockIdx.x] = hist[k];
+  }
+  static __global__ __launch_bounds__(1024) void k_bsize_scatter(const uint32_t* __restrict__ count, const uint32_t* __restrict__ table_off, uint32_t* __restrict__ perm, size_t nbk, uint32_t seg)
+  {
+    __shared__ uint32_t cursor[SZ_BINS];
+    for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
+      cursor[k] = table_off[(size_t)k * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SZ_CHUNK;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const size_t b = base + it * 1024 + threadIdx.x;
+      if (b < nbk) perm[atomicAdd(&cursor[size_class(count[b], seg)], 1u)] = (uint32_t)b;
+    }
+  }
+
   template <class C, int MINW>
-  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
+  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, const uint32_t* __restrict__ perm, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
   {
     // bases_stride: words between the base arrays of consecutive MSMs of a batch (0 = shared bases)
+    // perm: thread t < nbk accumulates bucket perm[t] (size-balanced order)
     using E = EC<C>;
     constexpr int PW = 2 * E::N32; // words per affine point
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -651,9 +694,9 @@ namespace icicle_hip {
     uint32_t start;
     typename E::Proj* dst;
     if (t < nbk) {
-      bucket = t;
+      bucket = perm[t];
       start = 0;
-      dst = buckets + t;
+      dst = buckets + bucket;
     } else {
       const size_t o = t - nbk;
       if (o >= *ovf_count) return;
@@ -1034,7 +1077,7 @@ namespace icicle_hip {
     const uint32_t maxblkB = (uint32_t)std::min<size_t>(nparts + (elems_max >> CHUNKB_LOG) + 2, 0x7fffffffu);
     const uint32_t ovf_cap = (uint32_t)std::min<size_t>(elems_max / pl.seg + 16, 0x7fffffffu);
 
-    TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt, d_scansum;
+    TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt, d_scansum, d_perm, d_sztab, d_szoff;
     HIP_TRY(d_mont.alloc((shared ? 1 : (size_t)BB) * npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_dig.alloc((size_t)BB * pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
     if (!single_level) HIP_TRY(d_partA.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
@@ -1051,6 +1094,10 @@ namespace icicle_hip {
     HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovfcnt.alloc(16, st), ICICLE_ALLOCATION_FAILED);
+    const size_t szblk_max = (nbk + SZ_CHUNK - 1) / SZ_CHUNK;
+    HIP_TRY(d_perm.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_sztab.alloc(szblk_max * SZ_BINS * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_szoff.alloc(szblk_max * SZ_BINS * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_scansum.alloc(TW * (std::max<size_t>((size_t)sp.nblk << sp.hb, nb) / SCAN_CHUNK + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
 
     const size_t ldsA = tile_lds_bytes(1u << sp.hb) + ((size_t)4 << sp.hb);
@@ -1121,6 +1168,15 @@ namespace icicle_hip {
       HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16, st), ICICLE_COPY_FAILED);
       k_plan_overflow<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(count, gbk, pl.seg, d_ovfcnt.as<uint32_t>(), d_ovf.as<OvfSeg>(), ovf_cap);
       LAUNCH_CHECK("k_plan_overflow", st);
+      {
+        const unsigned szblk = (unsigned)((gbk + SZ_CHUNK - 1) / SZ_CHUNK);
+        const uint32_t m = szblk * SZ_BINS, nch = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        k_bsize_count<<<szblk, 1024, 0, st>>>(count, d_sztab.as<uint32_t>(), gbk, pl.seg);
+        k_scan_sums<<<dim3(nch, 1), 1024, 0, st>>>(d_sztab.as<uint32_t>(), d_scansum.as<uint32_t>(), m);
+        k_scan_apply<<<dim3(nch, 1), 1024, 0, st>>>(d_sztab.as<uint32_t>(), d_scansum.as<uint32_t>(), d_szoff.as<uint32_t>(), nullptr, nullptr, m);
+        k_bsize_scatter<<<szblk, 1024, 0, st>>>(count, d_szoff.as<uint32_t>(), d_perm.as<uint32_t>(), gbk, pl.seg);
+        LAUNCH_CHECK("k_bsize_scatter", st);
+      }
       KernelTimer::begin(0, st);
       {
         // waves per SIMD the register allocator must leave room for: 3 fits BN254 G1 (157 VGPRs) without
@@ -1131,7 +1187,7 @@ namespace icicle_hip {
         const size_t nthreads_acc = gbk + ovf_cap;
         const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
         const size_t bstride = shared ? 0 : npts_one * PW;
-#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), nb, gbk, cap, pl.seg, wpf, bstride
+#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), d_perm.as<uint32_t>(), nb, gbk, cap, pl.seg, wpf, bstride
         if constexpr (BIGPT) {
           if constexpr (sizeof(typename E::XYZZ) <= 288) {
             if (minw >= 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
