@@ -255,6 +255,7 @@ namespace icicle_hip {
     // column pass: slot (k, t) at in_base + k*sk + t*st on both sides
     // row pass   : load  (k, t) at in_base + k*1  + t*st ; store K0(t) + k_out*out_sk
     const uint64_t K0 = (pd.pidx <= 1) ? ((uint64_t)ct * T + tB) : (((uint64_t)ct * T + tB) + (uint64_t)pd.n0 * a);
+    const uint64_t K0rev = (DIF && nl.out_rev) ? bitrev64(K0, nl.logn - SS) : 0; // kNR: see the last round's store
 
     const uint32_t rloc0 = blockIdx.y * rows_per_block;
     auto row_offset = [&](uint32_t rloc, bool rel) -> uint64_t {
@@ -360,11 +361,18 @@ namespace icicle_hip {
           for (int m = 0; m < (1 << NQ0); m++)
             x[m] = xin[m];
           ntt_stages<S, NQ0, true, true>(x, w0);
-          uint32_t* q = pout + K0 * es;
-          const uint64_t step = pd.out_sk * es;
+          if (nl.out_rev) {
+            uint32_t* q = pout + K0rev * L * es;
 #pragma unroll
-          for (int m = 0; m < (1 << NQ0); m++)
-            q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+            for (int m = 0; m < (1 << NQ0); m++)
+              q[(uint64_t)m * es] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+          } else {
+            uint32_t* q = pout + K0 * es;
+            const uint64_t step = pd.out_sk * es;
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+          }
         } else {
           { // top round: mapping A, natural rows k = gA + m * L/16 (prefetched from HBM)
             uint32_t x[16];
@@ -401,11 +409,46 @@ namespace icicle_hip {
             for (int m = 0; m < (1 << NQ0); m++)
               x[m] = tile[((gi << NQ0) + m) * TP + tB];
             ntt_stages<S, NQ0, true, true>(x, w0);
-            uint32_t* q = pout + (K0 + (uint64_t)kb * pd.out_sk) * es;
-            const uint64_t step = (pd.out_sk << KB_BITS) * es;
+            if (nl.out_rev) {
+              // bit-reversed output (kNR): bitrev(K0 + k*out_sk) = bitrev_s(k) + L * bitrev(K0), and bitrev_s(k) of
+              // slot m is the LDS row (gi << NQ0) + m: a column's L results form one contiguous run of memory.
+              // Back into the tile (same slots this thread just read), then stored with lanes along the run.
 #pragma unroll
-            for (int m = 0; m < (1 << NQ0); m++)
-              q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+              for (int m = 0; m < (1 << NQ0); m++)
+                tile[((gi << NQ0) + m) * TP + tB] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+            } else {
+              uint32_t* q = pout + (K0 + (uint64_t)kb * pd.out_sk) * es;
+              const uint64_t step = (pd.out_sk << KB_BITS) * es;
+#pragma unroll
+              for (int m = 0; m < (1 << NQ0); m++)
+                q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+            }
+          }
+          if (nl.out_rev) {
+            __syncthreads();
+            // element e = it * nthreads + tid -> (t, r) = (e / L, e % L). With T >= 16: r is fixed per thread and t
+            // advances by nthreads / L = T / 16 per step. The column index t sits in the low log2(T) bits of K0,
+            // i.e. in the TOP bits of bitrev(K0): bitrev(K0) = bitrev(K0 with t = 0) + (bitrev_lt(t) << (bits - lt)).
+            const uint32_t bits = nl.logn - SS, lt = 31 - __clz(T);
+            const uint64_t k0b = (pd.pidx <= 1) ? ((uint64_t)ct * T) : (((uint64_t)ct * T) + (uint64_t)pd.n0 * a);
+            if (T >= 16) {
+              const uint32_t r = threadIdx.x % L, th = threadIdx.x / L;
+              uint32_t* q = pout + (bitrev64(k0b, bits) * L + r) * es;
+#pragma unroll
+              for (int it = 0; it < E; it++) {
+                const uint32_t t = (uint32_t)it * (T >> 4) + th;
+                const uint64_t trev = (uint64_t)(__brev(t) >> (32 - lt));
+                q[((trev << (bits - lt)) * L) * es] = tile[r * TP + t];
+              }
+            } else { // narrow tiles (tiny first factor): plain per-element addressing
+              const uint32_t nthr = T * NG16;
+#pragma unroll
+              for (int it = 0; it < E; it++) {
+                const uint32_t e = (uint32_t)it * nthr + threadIdx.x;
+                const uint32_t t = e / L, r = e % L;
+                pout[(bitrev64(k0b + t, bits) * L + r) * es] = tile[r * TP + t];
+              }
+            }
           }
         }
       }
@@ -691,7 +734,7 @@ namespace icicle_hip {
     TempBuf d_work;
     uint32_t* W = nullptr;
 
-    const bool fast = !nl.in_rev && !nl.out_rev && !nl.coset;
+    const bool fast = !nl.in_rev && !nl.coset; // kNN / kNM / kMN and kNR; reversed input and cosets: generic kernel
     // Row groups (experimental, OFF by default: ICICLE_HIP_NTT_GROUP_MB=<MiB>): a group of rows runs
     // through ALL passes before the next group starts so that pass p+1 could read pass p's output from
     // the 256 MiB Infinity Cache. Measured on MI355X (profiles/r01_notes.md): 3.4x SLOWER at 64-192 MiB
