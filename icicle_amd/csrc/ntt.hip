@@ -131,7 +131,8 @@ namespace icicle_hip {
 
 
   // ---- fast pass: register-blocked radix-2 butterflies, 4 stages per LDS round trip -------------
-  // Natural-order, no-coset transforms (kNN/kNM/kMN, any batch layout, both directions).
+  // Every ordering, coset or not, any batch layout, both directions (bit-reversed INPUT arrives here after the
+  // reordering pre-pass; only single-pass transforms with reversed input are left to the generic kernel).
   // A pass computes 2^s-point transforms on a [L x T] tile (T adjacent columns => every HBM access is
   // a run of T contiguous words). A thread owns 16 tile elements per "round" and runs up to 4 butterfly
   // stages on them in registers; the FIRST round loads its operands straight from HBM and the LAST
@@ -182,12 +183,13 @@ namespace icicle_hip {
     return r;
   }
 
-  // threads per block: 512, except the 2^12-point variant (NQ0 = 4, NR = 3; <= 124 VGPRs) which runs 1024 so
-  // that a tile is 4 columns wide
-  constexpr int ntt_fast_max_threads(int nq0, int nr) { return (nq0 == 4 && nr >= 2) ? 1024 : 512; }
+  // waves per SIMD the register allocator must leave room for: the two-round variants are LDS-limited to 4 waves
+  // per SIMD (2 blocks of 8 waves per CU) and fit 128 VGPRs; the three-round, coset and bit-reversed-output
+  // variants (separate instantiations, so that they do not cost the plain path registers) get 2
+  constexpr int ntt_fast_min_waves(int nr, bool extra) { return (nr <= 2 && !extra) ? 4 : 2; }
 
-  template <class PR, int NQ0, int NR, bool DIF, bool INV>
-  __global__ __launch_bounds__(ntt_fast_max_threads(NQ0, NR)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
+  template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV>
+  __global__ __launch_bounds__(512, ntt_fast_min_waves(NR, COSET && DIF)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
   {
     using S = SmallField<PR>;
     constexpr int SS = NQ0 + 4 * (NR - 1);
@@ -217,6 +219,12 @@ namespace icicle_hip {
       if (nl.inverse) idx = (((uint64_t)1 << nl.log_max) - idx) & max_mask;
       return tw[idx];
     };
+
+    // coset factor g^e (forward) or N^-1 * g^-e (inverse) from the two-level table: lo[e & 4095] * hi[e >> 12]
+    auto cpow = [&](uint64_t e) -> uint32_t { return S::mul(ctab[e & 4095], ctab[4096 + (e >> 12)]); };
+    // COSET variants are separate instantiations: the 16 per-thread factors must not cost the plain path registers
+    const bool coset_in = COSET && !nl.inverse && pd.pidx == 0;  // x[j] *= g^j on the way in (first pass)
+    const bool coset_out = COSET && nl.inverse && pd.is_last;    // X[k] *= g^-k / N on the way out (last pass)
 
     // ---- per-thread twiddles, loaded once per block ---------------------------------------------
     uint32_t w0[(1 << NQ0)]; // lowest round: group-independent (wave-uniform => scalar registers)
@@ -250,12 +258,42 @@ namespace icicle_hip {
       }
     }
 
+    // ---- coset factors, once per block (they do not depend on the batch row) ------------------------
+    // forward, column pass 0: g^j = g^(column) * g^(row * in_sk); the column part is linear through the whole
+    //   column transform and is folded into the inter-pass twiddle, the row part is one product per operand.
+    // inverse, last pass: X[K] *= g^-K / N replaces the plain 1/N factor (the table is pre-scaled by 1/N).
+    uint32_t cfac[COSET ? E : 1];
+    if (!DIF && coset_in) {
+      const uint32_t gcol = cpow(in_base + (uint64_t)tB * pd.in_st);
+#pragma unroll
+      for (int m = 0; m < E; m++)
+        wip[m] = S::mul(wip[m], gcol);
+#pragma unroll
+      for (int u = 0; u < G0; u++) {
+        const uint32_t gi = gB * G0 + u;
+        const uint32_t kb = (KB_BITS == 0) ? 0u : (__brev(gi) >> (32 - (KB_BITS > 0 ? KB_BITS : 1)));
+#pragma unroll
+        for (int m = 0; m < (1 << NQ0); m++)
+          cfac[u * (1 << NQ0) + m] = cpow(((uint64_t)kb + ((uint64_t)brev_c<NQ0>(m) << KB_BITS)) * pd.in_sk);
+      }
+    }
+
     // ---- per-thread HBM offsets (in elements, times the element stride) ----------------------------
     const uint64_t es = nl.es;
     // column pass: slot (k, t) at in_base + k*sk + t*st on both sides
     // row pass   : load  (k, t) at in_base + k*1  + t*st ; store K0(t) + k_out*out_sk
     const uint64_t K0 = (pd.pidx <= 1) ? ((uint64_t)ct * T + tB) : (((uint64_t)ct * T + tB) + (uint64_t)pd.n0 * a);
-    const uint64_t K0rev = (DIF && nl.out_rev) ? bitrev64(K0, nl.logn - SS) : 0; // kNR: see the last round's store
+    const uint64_t K0rev = (DIF && OUTREV) ? bitrev64(K0, nl.logn - SS) : 0; // kNR: see the last round's store
+    if (DIF && INV && coset_out) { // slot (u, m) of the lowest round holds X[K0 + (kb + brev(m) * 2^(s-NQ0)) * out_sk]
+#pragma unroll
+      for (int u = 0; u < G0; u++) {
+        const uint32_t gi = gB * G0 + u;
+        const uint32_t kb = (NR == 1 || KB_BITS == 0) ? 0u : (__brev(gi) >> (32 - (KB_BITS > 0 ? KB_BITS : 1)));
+#pragma unroll
+        for (int m = 0; m < (1 << NQ0); m++)
+          cfac[u * (1 << NQ0) + m] = cpow(K0 + ((uint64_t)kb + ((uint64_t)brev_c<NQ0>(m) << (NR == 1 ? 0 : KB_BITS))) * pd.out_sk);
+      }
+    }
 
     const uint32_t rloc0 = blockIdx.y * rows_per_block;
     auto row_offset = [&](uint32_t rloc, bool rel) -> uint64_t {
@@ -316,6 +354,11 @@ namespace icicle_hip {
 #pragma unroll
           for (int m = 0; m < (1 << NQ0); m++)
             x[m] = xin[u * (1 << NQ0) + m];
+          if (coset_in) { // row part of g^j (the column part sits in wip)
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              x[m] = S::mul(x[m], cfac[u * (1 << NQ0) + m]);
+          }
           ntt_stages<S, NQ0, false, true>(x, w0);
           if (NR == 1) {
             uint32_t* q = pout + (in_base + (uint64_t)tB * pd.in_st) * es;
@@ -360,18 +403,29 @@ namespace icicle_hip {
 #pragma unroll
           for (int m = 0; m < (1 << NQ0); m++)
             x[m] = xin[m];
+          if (coset_in) {
+            const uint64_t j0 = in_base + (uint64_t)tB * pd.in_st;
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              x[m] = S::mul(x[m], cpow(j0 + (uint64_t)m));
+          }
           ntt_stages<S, NQ0, true, true>(x, w0);
-          if (nl.out_rev) {
+          if (INV) { // slot m holds X[K0 + brev(m) * out_sk]
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              x[m] = S::mul(x[m], coset_out ? cfac[m] : nl.ninv_mont);
+          }
+          if (OUTREV) {
             uint32_t* q = pout + K0rev * L * es;
 #pragma unroll
             for (int m = 0; m < (1 << NQ0); m++)
-              q[(uint64_t)m * es] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+              q[(uint64_t)m * es] = x[m];
           } else {
             uint32_t* q = pout + K0 * es;
             const uint64_t step = pd.out_sk * es;
 #pragma unroll
             for (int m = 0; m < (1 << NQ0); m++)
-              q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+              q[(uint64_t)brev_c<NQ0>(m) * step] = x[m];
           }
         } else {
           { // top round: mapping A, natural rows k = gA + m * L/16 (prefetched from HBM)
@@ -379,6 +433,12 @@ namespace icicle_hip {
 #pragma unroll
             for (int m = 0; m < 16; m++)
               x[m] = xin[m];
+            if (coset_in) { // single-pass transform: rows k = gA + m * L/16 of column tA
+              const uint64_t j0 = in_base + (uint64_t)gA + (uint64_t)tA * pd.in_st;
+#pragma unroll
+              for (int m = 0; m < 16; m++)
+                x[m] = S::mul(x[m], cpow(j0 + ((uint64_t)m << QT)));
+            }
             ntt_stages<S, 4, true, false>(x, wr[NR - 2]);
 #pragma unroll
             for (int m = 0; m < 16; m++)
@@ -409,22 +469,27 @@ namespace icicle_hip {
             for (int m = 0; m < (1 << NQ0); m++)
               x[m] = tile[((gi << NQ0) + m) * TP + tB];
             ntt_stages<S, NQ0, true, true>(x, w0);
-            if (nl.out_rev) {
+            if (INV) { // slot m holds X[K0 + (kb + brev(m) * 2^(s-NQ0)) * out_sk]
+#pragma unroll
+              for (int m = 0; m < (1 << NQ0); m++)
+                x[m] = S::mul(x[m], coset_out ? cfac[u * (1 << NQ0) + m] : nl.ninv_mont);
+            }
+            if (OUTREV) {
               // bit-reversed output (kNR): bitrev(K0 + k*out_sk) = bitrev_s(k) + L * bitrev(K0), and bitrev_s(k) of
               // slot m is the LDS row (gi << NQ0) + m: a column's L results form one contiguous run of memory.
               // Back into the tile (same slots this thread just read), then stored with lanes along the run.
 #pragma unroll
               for (int m = 0; m < (1 << NQ0); m++)
-                tile[((gi << NQ0) + m) * TP + tB] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+                tile[((gi << NQ0) + m) * TP + tB] = x[m];
             } else {
               uint32_t* q = pout + (K0 + (uint64_t)kb * pd.out_sk) * es;
               const uint64_t step = (pd.out_sk << KB_BITS) * es;
 #pragma unroll
               for (int m = 0; m < (1 << NQ0); m++)
-                q[(uint64_t)brev_c<NQ0>(m) * step] = INV ? S::mul(x[m], nl.ninv_mont) : x[m];
+                q[(uint64_t)brev_c<NQ0>(m) * step] = x[m];
             }
           }
-          if (nl.out_rev) {
+          if (OUTREV) {
             __syncthreads();
             // element e = it * nthreads + tid -> (t, r) = (e / L, e % L). With T >= 16: r is fixed per thread and t
             // advances by nthreads / L = T / 16 per step. The column index t sits in the low log2(T) bits of K0,
@@ -459,6 +524,47 @@ namespace icicle_hip {
           xin[m] = xnext[m];
       }
     }
+  }
+
+  // ---- bit-reversed input (kRN / kRR): explicit reordering pre-pass ---------------------------------
+  // Reading x[bitrev(j)] inside pass 0 would turn its 128-byte runs into 4-byte gathers, so the rows are
+  // bit-reversed once into the work buffer (one extra read + write of the data, ~1/3 of a transform) and the
+  // natural-order passes run from there. Row-major rows: 32 x 32 tiles through LDS, index = hi5 | mid | lo5,
+  // read along lo5, written along bitrev(hi5) -- both sides in 128-byte runs.
+  __global__ __launch_bounds__(1024) void k_bitrev_rows_tiled(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t logn, uint64_t bs)
+  {
+    __shared__ uint32_t tile[32][33];
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const uint32_t midbits = logn - 10;
+    const uint64_t mid = blockIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.y * bs;
+    tile[ty][tx] = in[base + (((uint64_t)ty << (logn - 5)) | (mid << 5) | tx)];
+    __syncthreads();
+    const uint64_t rmid = bitrev64(mid, midbits);
+    const uint32_t hi = __brev(tx) >> 27, lo = __brev(ty) >> 27;
+    out[base + (((uint64_t)ty << (logn - 5)) | (rmid << 5) | tx)] = tile[hi][lo];
+  }
+  // any layout: one thread per (element, transform), transforms fastest (coalesced for columns_batch)
+  __global__ __launch_bounds__(256) void k_bitrev_rows_simple(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t logn, uint32_t nbatch, uint32_t lanes, uint64_t bs, uint64_t es, bool batch_fastest)
+  {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t n = (uint64_t)1 << logn;
+    if (t >= n * nbatch) return;
+    const uint64_t j = batch_fastest ? t / nbatch : t % n;
+    const uint32_t b = (uint32_t)(batch_fastest ? t % nbatch : t / n);
+    const uint64_t boff = (uint64_t)(b / lanes) * bs + (b % lanes);
+    out[boff + bitrev64(j, logn) * es] = in[boff + j * es];
+  }
+
+  // two-level coset table for the fast path: ctab[i] = g^i (i < 4096), ctab[4096 + i] = scale * g^(4096 i);
+  // g is the generator (forward) or its inverse (inverse transform, scale = 1/N so one product applies both)
+  template <class PR>
+  __global__ __launch_bounds__(256) void k_coset_tables(uint32_t* __restrict__ ctab, uint32_t g_mont, uint32_t scale_mont, uint32_t nhi)
+  {
+    using S = SmallField<PR>;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4096) ctab[i] = S::pow(g_mont, (uint64_t)i);
+    if (i < nhi) ctab[4096 + i] = S::mul(scale_mont, S::pow(g_mont, (uint64_t)i << 12));
   }
 
   // coset powers: pw[j] = g^j (forward) or g^-j (inverse), Montgomery
@@ -606,30 +712,36 @@ namespace icicle_hip {
   }
 
   template <class PR>
-  using pass_fn_t = void (*)(const uint32_t*, uint32_t*, const uint32_t*, PassDesc, NttLaunch, uint32_t);
+  using pass_fn_t = void (*)(const uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, PassDesc, NttLaunch, uint32_t);
 
-  template <class PR, int NQ0, int NR>
-  static pass_fn_t<PR> pick_variant(bool dif, bool inv)
+  template <class PR, int NQ0, int NR, bool COSET>
+  static pass_fn_t<PR> pick_variant2(bool dif, bool inv, bool outrev)
   {
-    if (!dif) return (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, false, false>;
-    return inv ? (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, true, true> : (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, true, false>;
+    if (!dif) return (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, false, false, COSET, false>;
+    if (outrev) return inv ? (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, true, true, COSET, true> : (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, true, false, COSET, true>;
+    return inv ? (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, true, true, COSET, false> : (pass_fn_t<PR>)k_ntt_fast<PR, NQ0, NR, true, false, COSET, false>;
+  }
+  template <class PR, int NQ0, int NR>
+  static pass_fn_t<PR> pick_variant(bool dif, bool inv, bool coset, bool outrev)
+  {
+    return coset ? pick_variant2<PR, NQ0, NR, true>(dif, inv, outrev) : pick_variant2<PR, NQ0, NR, false>(dif, inv, outrev);
   }
   template <class PR>
-  static pass_fn_t<PR> pick_pass(int s, bool dif, bool inv)
+  static pass_fn_t<PR> pick_pass(int s, bool dif, bool inv, bool coset, bool outrev)
   {
     switch (s) {
-    case 1: return pick_variant<PR, 1, 1>(dif, inv);
-    case 2: return pick_variant<PR, 2, 1>(dif, inv);
-    case 3: return pick_variant<PR, 3, 1>(dif, inv);
-    case 4: return pick_variant<PR, 4, 1>(dif, inv);
-    case 5: return pick_variant<PR, 1, 2>(dif, inv);
-    case 6: return pick_variant<PR, 2, 2>(dif, inv);
-    case 7: return pick_variant<PR, 3, 2>(dif, inv);
-    case 8: return pick_variant<PR, 4, 2>(dif, inv);
-    case 9: return pick_variant<PR, 1, 3>(dif, inv);
-    case 10: return pick_variant<PR, 2, 3>(dif, inv);
-    case 11: return pick_variant<PR, 3, 3>(dif, inv);
-    case 12: return pick_variant<PR, 4, 3>(dif, inv);
+    case 1: return pick_variant<PR, 1, 1>(dif, inv, coset, outrev);
+    case 2: return pick_variant<PR, 2, 1>(dif, inv, coset, outrev);
+    case 3: return pick_variant<PR, 3, 1>(dif, inv, coset, outrev);
+    case 4: return pick_variant<PR, 4, 1>(dif, inv, coset, outrev);
+    case 5: return pick_variant<PR, 1, 2>(dif, inv, coset, outrev);
+    case 6: return pick_variant<PR, 2, 2>(dif, inv, coset, outrev);
+    case 7: return pick_variant<PR, 3, 2>(dif, inv, coset, outrev);
+    case 8: return pick_variant<PR, 4, 2>(dif, inv, coset, outrev);
+    case 9: return pick_variant<PR, 1, 3>(dif, inv, coset, outrev);
+    case 10: return pick_variant<PR, 2, 3>(dif, inv, coset, outrev);
+    case 11: return pick_variant<PR, 3, 3>(dif, inv, coset, outrev);
+    case 12: return pick_variant<PR, 4, 3>(dif, inv, coset, outrev);
     }
     return nullptr;
   }
@@ -704,12 +816,10 @@ namespace icicle_hip {
       nl.ninv_mont = S::pow(two_inv, (uint64_t)logn);
     }
     nl.coset = (cfg->coset_gen != 1);
+    uint32_t coset_g = S::one();
     if (nl.coset) {
-      HIP_TRY(d_pw.alloc(n * 4, st), ICICLE_ALLOCATION_FAILED);
-      uint32_t g = S::to_mont(cfg->coset_gen);
-      if (nl.inverse) g = S::inv(g);
-      k_coset_powers<PR><<<(unsigned)((n / 16 + 256) / 256), 256, 0, st>>>(d_pw.as<uint32_t>(), g, n);
-      LAUNCH_CHECK("k_coset_powers", st);
+      coset_g = S::to_mont(cfg->coset_gen);
+      if (nl.inverse) coset_g = S::inv(coset_g);
     }
 
     if (logn == 0) { // size-1 transforms are the identity in every mode
@@ -723,25 +833,36 @@ namespace icicle_hip {
       return ICICLE_SUCCESS;
     }
     int parts[3], P;
-    {
-      // sub-transform size: 2^8 (three passes at 2^24). ICICLE_HIP_NTT_SMAX=12 selects two passes of 2^12.
-      static const int smax_env = getenv("ICICLE_HIP_NTT_SMAX") ? atoi(getenv("ICICLE_HIP_NTT_SMAX")) : 0;
-      const int smax = (smax_env >= 4 && smax_env <= 12) ? smax_env : 8;
-      split_logn(logn, smax, parts, &P);
-    }
+    // sub-transforms of 2^8 points (three passes at 2^24). Two passes of 2^12 (1024-thread blocks, 4-column tiles)
+    // and 64-column tiles were built and measured in round 1 and lost: profiles/r01_notes.md.
+    split_logn(logn, 8, parts, &P);
     // P >= 2: passes 0..P-2 run in a work buffer (the last pass permutes across tiles, so it can
     // never be in place; this also makes input == output legal, test_mod_arithmetic_api.h:627,679)
     TempBuf d_work;
     uint32_t* W = nullptr;
 
-    const bool fast = !nl.in_rev && !nl.coset; // kNN / kNM / kMN and kNR; reversed input and cosets: generic kernel
+    // fast path: natural-order input (kNN / kNM / kMN / kNR), or bit-reversed input after the reordering pre-pass
+    // below (kRN / kRR, P >= 2); cosets and single-pass reversed-input transforms use the generic kernel
+    const bool prerev = nl.in_rev && P >= 2;
+    const bool fast = !nl.in_rev || prerev;
+    TempBuf d_ctab;
+    if (nl.coset && fast) { // two-level table, 4096 + N/4096 entries
+      const uint32_t nhi = (uint32_t)std::max<uint64_t>(1, n >> 12);
+      HIP_TRY(d_ctab.alloc((size_t)(4096 + nhi) * 4, st), ICICLE_ALLOCATION_FAILED);
+      k_coset_tables<PR><<<(std::max(4096u, nhi) + 255) / 256, 256, 0, st>>>(d_ctab.as<uint32_t>(), coset_g, nl.inverse ? nl.ninv_mont : S::one(), nhi);
+      LAUNCH_CHECK("k_coset_tables", st);
+    } else if (nl.coset) { // generic kernel: full table of powers
+      HIP_TRY(d_pw.alloc(n * 4, st), ICICLE_ALLOCATION_FAILED);
+      k_coset_powers<PR><<<(unsigned)((n / 16 + 256) / 256), 256, 0, st>>>(d_pw.as<uint32_t>(), coset_g, n);
+      LAUNCH_CHECK("k_coset_powers", st);
+    }
     // Row groups (experimental, OFF by default: ICICLE_HIP_NTT_GROUP_MB=<MiB>): a group of rows runs
     // through ALL passes before the next group starts so that pass p+1 could read pass p's output from
     // the 256 MiB Infinity Cache. Measured on MI355X (profiles/r01_notes.md): 3.4x SLOWER at 64-192 MiB
     // groups, because a block then serves 1-2 rows and the per-block twiddle gathers (46 per thread)
     // are no longer amortised over the batch. Kept for experiments only.
     uint32_t rows_per_group = nl.nbatch;
-    if (fast && P >= 2 && !cfg->columns_batch && lanes == 1) {
+    if (fast && !prerev && P >= 2 && !cfg->columns_batch && lanes == 1) {
       size_t group_mb = 0;
       if (const char* e = getenv("ICICLE_HIP_NTT_GROUP_MB")) group_mb = (size_t)atoi(e);
       if (group_mb > 0) {
@@ -755,22 +876,28 @@ namespace icicle_hip {
       W = d_work.as<uint32_t>();
     }
     KernelTimer::begin(1, st);
+    if (prerev) {
+      if (!cfg->columns_batch && lanes == 1 && logn >= 10 && nl.nbatch <= 65535) {
+        k_bitrev_rows_tiled<<<dim3((unsigned)(n >> 10), nl.nbatch), 1024, 0, st>>>(d_in, W, (uint32_t)logn, nl.bs);
+      } else {
+        const uint64_t tot = n * nl.nbatch;
+        k_bitrev_rows_simple<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(d_in, W, (uint32_t)logn, nl.nbatch, lanes, nl.bs, nl.es, cfg->columns_batch != 0);
+      }
+      LAUNCH_CHECK("k_bitrev_rows", st);
+      nl.in_rev = 0; // the passes below see natural-order rows in W
+    }
     for (uint32_t g0 = 0; g0 < nl.nbatch; g0 += rows_per_group) {
     nl.row0 = g0;
     nl.nrows_launch = std::min<uint32_t>(rows_per_group, nl.nbatch - g0);
     for (int p = 0; p < P; p++) {
-      const uint32_t* src = (p == 0) ? d_in : W;
+      const uint32_t* src = (p == 0 && !prerev) ? d_in : W;
       uint32_t* dst = (p == P - 1) ? d_out : W;
       nl.src_rel = (grouped && p != 0) ? 1 : 0;
       nl.dst_rel = (grouped && p != P - 1) ? 1 : 0;
       const uint64_t L = (uint64_t)1 << parts[p];
       // fast path: block = T * L/16 threads (<= 512), LDS = 2 buffers of L*(T+1) words (<= 160 KiB)
       const uint64_t epb = L >= 16 ? 16 : L;
-      const uint64_t maxthr = (parts[p] == 12 || parts[p] == 8) ? 1024 : 512; // ntt_fast_max_threads()
-      static const int tcol = getenv("ICICLE_HIP_NTT_TCOL") ? atoi(getenv("ICICLE_HIP_NTT_TCOL")) : 32;
-      static const int trow = getenv("ICICLE_HIP_NTT_TROW") ? atoi(getenv("ICICLE_HIP_NTT_TROW")) : 32;
-      const uint64_t tcap = (uint64_t)std::max(1, std::min(64, (p == P - 1) ? trow : tcol));
-      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tcap, maxthr * epb / L));
+      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, 512 * epb / L));
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
         tmax >>= 1;
       PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
@@ -783,10 +910,12 @@ namespace icicle_hip {
         const uint64_t total_blocks = (uint64_t)pd.ntiles * nl.nrows_launch;
         const uint32_t rpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nl.nrows_launch, total_blocks / 4096));
         const uint32_t gy = (nl.nrows_launch + rpb - 1) / rpb;
-        pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0);
+        // the coset factors touch the first pass (forward) or the last one (inverse) only
+        const bool cvar = nl.coset && (nl.inverse ? pd.is_last != 0 : p == 0);
+        pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, nl.out_rev != 0 && pd.is_last != 0);
         if (!fn) return ICICLE_INVALID_ARGUMENT;
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
-        fn<<<dim3(pd.ntiles, gy), threads, lds_bytes, st>>>(src, dst, dom.tw, pd, nl, rpb);
+        fn<<<dim3(pd.ntiles, gy), threads, lds_bytes, st>>>(src, dst, dom.tw, d_ctab.as<uint32_t>(), pd, nl, rpb);
       } else {
         const uint32_t tot = (uint32_t)(L * pd.T);
         const unsigned threads = std::max(64u, std::min(1024u, tot / 2));
