@@ -531,18 +531,30 @@ namespace icicle_hip {
   // bit-reversed once into the work buffer (one extra read + write of the data, ~1/3 of a transform) and the
   // natural-order passes run from there. Row-major rows: 32 x 32 tiles through LDS, index = hi5 | mid | lo5,
   // read along lo5, written along bitrev(hi5) -- both sides in 128-byte runs.
-  __global__ __launch_bounds__(1024) void k_bitrev_rows_tiled(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t logn, uint64_t bs)
+  __global__ __launch_bounds__(256) void k_bitrev_rows_tiled(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t logn, uint64_t bs)
   {
     __shared__ uint32_t tile[32][33];
-    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const uint32_t tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5; // 256 threads, 4 rows each
     const uint32_t midbits = logn - 10;
     const uint64_t mid = blockIdx.x;
     const uint64_t base = (uint64_t)blockIdx.y * bs;
-    tile[ty][tx] = in[base + (((uint64_t)ty << (logn - 5)) | (mid << 5) | tx)];
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t ty = ty0 + 8 * i;
+      v[i] = in[base + (((uint64_t)ty << (logn - 5)) | (mid << 5) | tx)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      tile[ty0 + 8 * i][tx] = v[i];
     __syncthreads();
     const uint64_t rmid = bitrev64(mid, midbits);
-    const uint32_t hi = __brev(tx) >> 27, lo = __brev(ty) >> 27;
-    out[base + (((uint64_t)ty << (logn - 5)) | (rmid << 5) | tx)] = tile[hi][lo];
+    const uint32_t hi = __brev(tx) >> 27;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t ty = ty0 + 8 * i, lo = __brev(ty) >> 27;
+      out[base + (((uint64_t)ty << (logn - 5)) | (rmid << 5) | tx)] = tile[hi][lo];
+    }
   }
   // any layout: one thread per (element, transform), transforms fastest (coalesced for columns_batch)
   __global__ __launch_bounds__(256) void k_bitrev_rows_simple(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t logn, uint32_t nbatch, uint32_t lanes, uint64_t bs, uint64_t es, bool batch_fastest)
@@ -878,7 +890,7 @@ namespace icicle_hip {
     KernelTimer::begin(1, st);
     if (prerev) {
       if (!cfg->columns_batch && lanes == 1 && logn >= 10 && nl.nbatch <= 65535) {
-        k_bitrev_rows_tiled<<<dim3((unsigned)(n >> 10), nl.nbatch), 1024, 0, st>>>(d_in, W, (uint32_t)logn, nl.bs);
+        k_bitrev_rows_tiled<<<dim3((unsigned)(n >> 10), nl.nbatch), 256, 0, st>>>(d_in, W, (uint32_t)logn, nl.bs);
       } else {
         const uint64_t tot = n * nl.nbatch;
         k_bitrev_rows_simple<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(d_in, W, (uint32_t)logn, nl.nbatch, lanes, nl.bs, nl.es, cfg->columns_batch != 0);
