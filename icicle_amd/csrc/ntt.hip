@@ -58,7 +58,7 @@ namespace icicle_hip {
     using S = SmallField<PR>;
     extern __shared__ uint32_t tile[];
     const uint32_t L = 1u << pd.s, T = pd.T;
-    const uint32_t bprime = blockIdx.y;
+    const uint32_t bprime = nl.row0 + blockIdx.y; // launched in slices of <= 65535 rows
     const uint64_t boff = (uint64_t)(bprime / nl.lanes) * nl.bs + (bprime % nl.lanes);
     const uint32_t a = blockIdx.x / pd.tiles_per_a, ct = blockIdx.x % pd.tiles_per_a;
     const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
@@ -932,7 +932,11 @@ namespace icicle_hip {
         const uint32_t tot = (uint32_t)(L * pd.T);
         const unsigned threads = std::max(64u, std::min(1024u, tot / 2));
         HIP_TRY(hipFuncSetAttribute((const void*)k_ntt_pass_generic<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
-        k_ntt_pass_generic<PR><<<dim3(pd.ntiles, nl.nbatch), threads, (size_t)tot * 4, st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, nl);
+        for (uint32_t r0 = 0; r0 < nl.nbatch; r0 += 65535) {
+          NttLaunch ns = nl;
+          ns.row0 = r0;
+          k_ntt_pass_generic<PR><<<dim3(pd.ntiles, std::min<uint32_t>(65535, nl.nbatch - r0)), threads, (size_t)tot * 4, st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, ns);
+        }
       }
       LAUNCH_CHECK("k_ntt_pass", st);
     }

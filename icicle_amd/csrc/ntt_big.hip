@@ -36,7 +36,7 @@ namespace icicle_hip {
     extern __shared__ uint32_t lds_raw[];
     fe* tile = reinterpret_cast<fe*>(lds_raw);
     const uint32_t L = 1u << pd.s, T = pd.T;
-    const uint64_t boff = (uint64_t)blockIdx.y * nl.bs;
+    const uint64_t boff = (uint64_t)(nl.row0 + blockIdx.y) * nl.bs; // launched in slices of <= 65535 rows
     const uint32_t a = blockIdx.x / pd.tiles_per_a, ct = blockIdx.x % pd.tiles_per_a;
     const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
     const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
@@ -314,7 +314,11 @@ namespace icicle_hip {
       const PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
       const uint32_t tot = (uint32_t)(L * pd.T);
       const unsigned threads = std::max(64u, std::min(512u, tot / 2));
-      k_big_ntt_pass<PR><<<dim3(pd.ntiles, nl.nbatch), threads, (size_t)tot * sizeof(fe), st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, nl, ninv);
+      for (uint32_t r0 = 0; r0 < nl.nbatch; r0 += 65535) {
+        NttLaunch ns = nl;
+        ns.row0 = r0;
+        k_big_ntt_pass<PR><<<dim3(pd.ntiles, std::min<uint32_t>(65535, nl.nbatch - r0)), threads, (size_t)tot * sizeof(fe), st>>>(src, dst, dom.tw, d_pw.as<uint32_t>(), pd, ns, ninv);
+      }
       LAUNCH_CHECK("k_big_ntt_pass", st);
     }
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);

@@ -146,3 +146,37 @@ def test_distributed_ntt_single_rank_path(env, hip):
         chunk = torch.from_numpy(x.view(np.int32).copy()).cuda()
         got = D.ntt_distributed(fname, chunk, logn, inverse, 0, 1, None).cpu().numpy().view(np.uint32)
         assert np.array_equal(got, N.ntt(fname, x, N.INVERSE if inverse else N.FORWARD))
+
+
+def test_ntt_extension_field_orderings_and_cosets(env, hip):
+    """the quartic-extension NTT through every ordering / coset combination (the lanes ride the same fast path)"""
+    fname, F, rf, N = env
+    rng = np.random.default_rng(55)
+    for logn, batch in ((6, 2), (11, 1), (14, 2)):
+        n = 1 << logn
+        for trial in range(4):
+            columns = bool(rng.integers(0, 2))
+            ordering = int(rng.integers(0, 4))
+            direction = int(rng.integers(0, 2))
+            coset = 1 if trial == 0 else int(rng.integers(2, F.p))
+            x = rng.integers(0, F.p, size=n * batch * 4, dtype=np.uint32)
+            cfg = hip.NTTConfigU32.default()
+            cfg.batch_size, cfg.columns_batch, cfg.ordering, cfg.coset_gen = batch, columns, ordering, coset
+            got = N.ntt(fname, x, direction, cfg, extension=True)
+            exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset, extension=True)
+            assert np.array_equal(got, exp), (logn, batch, columns, ordering, direction, coset)
+
+
+def test_ntt_many_tiny_transforms(env, hip):
+    """more rows than one grid dimension holds (70000 transforms of 4 and 256 points), every path"""
+    fname, F, rf, N = env
+    rng = np.random.default_rng(56)
+    # (no coset at this batch size: the reference's CPU coset path takes ~20 s per 70000 rows)
+    for logn, ordering, coset, batch in ((2, 2, 1, 70000), (2, 0, 5, 300), (8, 2, 7, 300), (8, 2, 1, 70000), (8, 1, 1, 70000)):
+        n = 1 << logn
+        x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+        cfg = hip.NTTConfigU32.default()
+        cfg.batch_size, cfg.ordering, cfg.coset_gen = batch, ordering, coset
+        got = N.ntt(fname, x, N.FORWARD, cfg)
+        exp = rf.ntt(x, n, 0, batch=batch, ordering=ordering, coset_gen=coset)
+        assert np.array_equal(got, exp), (logn, ordering, coset)

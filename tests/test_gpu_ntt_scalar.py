@@ -154,3 +154,16 @@ def test_roundtrip_large(env, hip):
     assert to_ints(y[:8])[0] == s
     back = N.ntt(fname, y, N.INVERSE, cfg)
     assert np.array_equal(back, x)
+
+
+def test_many_tiny_transforms(env, hip):
+    """more rows than one grid dimension holds"""
+    fname, F, rf, N = env
+    rng = np.random.default_rng(57)
+    n, batch = 4, 66000
+    x = np.tile(rand_elems(rng, F.p, 1000 * n).reshape(1000 * n, 8), (batch // 1000, 1)).reshape(-1).copy()
+    cfg = hip.NTTConfigU256.default()
+    cfg.batch_size, cfg.ordering = batch, 2
+    got = N.ntt(fname, x, N.FORWARD, cfg)
+    exp = rf.ntt(x, n, 0, batch=batch, ordering=2)
+    assert np.array_equal(got, exp)
