@@ -28,7 +28,7 @@ def time_it(fn, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def msm_case(curve, logn, batch=1, pf=1, g2=False):
+def msm_case(curve, logn, batch=1, pf=1, g2=False, c=0):
     n = 1 << logn
     L = M.LIMBS[curve] * (2 if g2 else 1)
     sym = f"{curve}_g2" if g2 else curve
@@ -42,7 +42,11 @@ def msm_case(curve, logn, batch=1, pf=1, g2=False):
     cfg = MSMConfig.default()
     cfg.batch_size = batch
     cfg.is_async = True
+    cfg.c = c
     ms = time_it(lambda: M.msm(curve, sc.data_ptr(), bases.data_ptr(), cfg, results=res.data_ptr(), msm_size=n, g2=g2))
+    if c:
+        print(f"msm {sym:12s} 2^{logn:<2d} c={c:<2d} {ms:9.3f} ms", flush=True)
+        return
     print(f"msm {sym:12s} 2^{logn:<2d} batch {batch:<4d} {ms:9.3f} ms  {batch * n / ms / 1e6:8.2f} Gpoint/s", flush=True)
 
 
@@ -82,6 +86,12 @@ def ntt_scalar_case(field, logn, batch):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "csweep":
+        for logn, cs in ((16, (9, 10, 11, 12, 13)), (20, (12, 13, 14, 15, 16)), (22, (14, 15, 16, 17, 18)), (24, (16, 17, 18, 19, 20)), (26, (18, 19, 20, 21))):
+            msm_case("bn254", logn)
+            for c in cs:
+                msm_case("bn254", logn, c=c)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "host":
         # PCIe-inclusive: operands handed over as host (pageable numpy) buffers, result back on the host
         import numpy as np
