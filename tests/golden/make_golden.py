@@ -81,11 +81,80 @@ def ntt_fixture(fname, seed):
     return out
 
 
+def g2_fixture(cname, seed):
+    """G2 MSM (reference built with G2_ENABLED): inputs, affine results"""
+    C = pyref.G2_CURVES[cname]
+    refc = ref.RefCurve(cname, g2=True)
+    L = C.base.limbs_q
+    rng = np.random.default_rng(seed)
+    n = 129
+    pts = pyref.g2_gen_points(C, n, k0=0xBEEF + seed)
+    pts[5] = pyref.INF2
+    pts[40] = pts[41]
+    pts[60] = pyref.g2_neg(C, pts[61])
+    sc = rand_scalars(rng, 2 * n, C.base.r)
+    sc[0], sc[1], sc[2] = 0, 1, C.base.r - 1
+    sc[40] = sc[41] = 999
+    sc[60] = sc[61] = 31
+    bases = np.concatenate([to_words([p[0][0] for p in pts], L), to_words([p[0][1] for p in pts], L),
+                            to_words([p[1][0] for p in pts], L), to_words([p[1][1] for p in pts], L)], axis=1)
+    scalars = to_words(sc, 8)
+    out = {"scalars": scalars, "bases": bases}
+    out["res_single"] = refc.to_affine(refc.msm(scalars[:n], bases))
+    out["res_batch2_shared"] = refc.to_affine(refc.msm(scalars, bases, batch=2, shared=True))
+    exp = pyref.g2_msm_naive(C, sc[:24], pts[:24])
+    got = refc.to_affine(refc.msm(scalars[:24], bases[:24]))[0]
+    assert [int(v) for v in got] == [int(v) for v in np.concatenate([to_words([exp[0][0]], L)[0], to_words([exp[0][1]], L)[0],
+                                                                     to_words([exp[1][0]], L)[0], to_words([exp[1][1]], L)[0]])]
+    return out
+
+
+def scalar_ntt_fixture(cname, seed):
+    """NTT over the curve's 256-bit scalar field + ECNTT over G1 on the same domain"""
+    F = pyref.NTT_FIELDS[cname]
+    C = pyref.CURVES[cname]
+    sf = ref.RefScalarNttField(cname)
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(seed)
+    logn, batch = 9, 2
+    n = 1 << logn
+    root = sf.get_root_of_unity(1 << 11)
+    assert root == pyref.omega(F, 11)
+    sf.init_domain(root)
+    x = to_words(rand_scalars(rng, n * batch, F.p), 8).reshape(-1)
+    g = rand_scalars(rng, 1, F.p)[0]
+    out = {"x": x, "domain_root": to_words([root], 8)[0], "coset_gen": to_words([g], 8)[0]}
+    out["fwd_NN"] = sf.ntt(x, n, 0, batch=batch)
+    out["inv_NN"] = sf.ntt(x, n, 1, batch=batch)
+    out["fwd_NR_coset"] = sf.ntt(x, n, 0, batch=batch, ordering=1, coset_gen=g)
+    out["inv_RN_coset"] = sf.ntt(x, n, 1, batch=batch, ordering=2, coset_gen=g)
+    out["fwd_columns"] = sf.ntt(x, n, 0, batch=batch, columns_batch=True)
+    m = 32
+    pts = pyref.gen_points(C, m, k0=4242 + seed)
+    pts[7] = pyref.INF
+    Lq = C.limbs_q
+    rows = []
+    for p_ in pts:
+        xyz = (0, 1, 0) if p_ == pyref.INF else (p_[0], p_[1], 1)
+        rows.append(np.concatenate([to_words([v], Lq)[0] for v in xyz]))
+    proj = np.ascontiguousarray(np.stack(rows).astype(np.uint32)).reshape(-1)
+    out["ec_points"] = proj
+    out["ec_fwd_NN_affine"] = refc.to_affine(refc.ecntt(proj, m, 0).reshape(m, 3 * Lq))
+    out["ec_inv_NR_coset_affine"] = refc.to_affine(refc.ecntt(proj, m, 1, ordering=1, coset_gen=g).reshape(m, 3 * Lq))
+    assert [(int(sum(int(v) << (32 * k) for k, v in enumerate(a[:Lq]))), int(sum(int(v) << (32 * k) for k, v in enumerate(a[Lq:]))))
+            for a in out["ec_fwd_NN_affine"][:4]] == pyref.ecntt_naive(C, F, pts, pyref.omega(F, 5))[:4]
+    sf.release_domain()
+    return out
+
+
 def main():
     for i, c in enumerate(("bn254", "bls12_381")):
         np.savez_compressed(os.path.join(HERE, f"msm_{c}.npz"), **msm_fixture(c, 11 + i))
     for i, f in enumerate(("babybear", "koalabear")):
         np.savez_compressed(os.path.join(HERE, f"ntt_{f}.npz"), **ntt_fixture(f, 21 + i))
+    for i, c in enumerate(("bn254", "bls12_381")):
+        np.savez_compressed(os.path.join(HERE, f"msm_g2_{c}.npz"), **g2_fixture(c, 31 + i))
+        np.savez_compressed(os.path.join(HERE, f"scalar_ntt_{c}.npz"), **scalar_ntt_fixture(c, 41 + i))
     print("golden fixtures written to", HERE)
 
 

@@ -62,3 +62,67 @@ def test_ntt_golden(hip, fname):
         assert np.array_equal(run(g["x_ext"], 0, batch=1, size=64, ext=True), g["fwd_ext"])
     finally:
         N.release_domain(fname)
+
+
+def _g2_affine_py(cname, proj):
+    from oracle import pyref
+    from tests.util import to_words
+
+    C = pyref.G2_CURVES[cname]
+    L = C.base.limbs_q
+    rows = []
+    for row in proj:
+        v = [sum(int(x) << (32 * k) for k, x in enumerate(row[i * L:(i + 1) * L])) for i in range(6)]
+        a = pyref.g2_proj_to_affine(C, (v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+        rows.append(np.concatenate([to_words([a[0][0]], L)[0], to_words([a[0][1]], L)[0], to_words([a[1][0]], L)[0], to_words([a[1][1]], L)[0]]))
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_g2_msm_golden(hip, cname):
+    from icicle_amd import msm as M
+
+    g = np.load(os.path.join(GOLD, f"msm_g2_{cname}.npz"))
+    n = g["bases"].shape[0]
+    got = M.msm(cname, np.ascontiguousarray(g["scalars"][:n]), g["bases"], g2=True)
+    assert np.array_equal(_g2_affine_py(cname, got), g["res_single"])
+    cfg = hip.MSMConfig.default()
+    cfg.batch_size = 2
+    assert np.array_equal(_g2_affine_py(cname, M.msm(cname, g["scalars"], g["bases"], cfg, g2=True)), g["res_batch2_shared"])
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_scalar_ntt_and_ecntt_golden(hip, cname):
+    from icicle_amd import ntt as N
+    from oracle import pyref
+
+    g = np.load(os.path.join(GOLD, f"scalar_ntt_{cname}.npz"))
+    words = lambda w: sum(int(x) << (32 * k) for k, x in enumerate(w))
+    N.init_domain(cname, words(g["domain_root"]))
+    try:
+        cg = words(g["coset_gen"])
+
+        def run(direction, **kw):
+            cfg = hip.NTTConfigU256.default()
+            cfg.batch_size = 2
+            cfg.ordering = kw.get("ordering", 0)
+            cfg.columns_batch = kw.get("columns", False)
+            cfg.set_coset_gen(kw.get("coset", 1))
+            return N.ntt(cname, g["x"], direction, cfg, size=512)
+
+        assert np.array_equal(run(0), g["fwd_NN"])
+        assert np.array_equal(run(1), g["inv_NN"])
+        assert np.array_equal(run(0, ordering=1, coset=cg), g["fwd_NR_coset"])
+        assert np.array_equal(run(1, ordering=2, coset=cg), g["inv_RN_coset"])
+        assert np.array_equal(run(0, columns=True), g["fwd_columns"])
+        C = pyref.CURVES[cname]
+        m = 32
+        y = N.ecntt(cname, g["ec_points"], N.FORWARD, size=m)
+        assert np.array_equal(_affine_py(cname, y.reshape(m, -1)), g["ec_fwd_NN_affine"])
+        cfg = hip.NTTConfigU256.default()
+        cfg.ordering = 1
+        cfg.set_coset_gen(cg)
+        y = N.ecntt(cname, g["ec_points"], N.INVERSE, cfg, size=m)
+        assert np.array_equal(_affine_py(cname, y.reshape(m, -1)), g["ec_inv_NR_coset_affine"])
+    finally:
+        N.release_domain(cname)

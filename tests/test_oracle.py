@@ -147,3 +147,23 @@ def test_reference_scalar_field_ntt_matches_definition(fname):
         assert from_words(y.reshape(n, 8)) == pyref.ntt_naive(F, vals, pyref.omega(F, 4), inverse=True, coset_gen=12345, ordering="RR")
     finally:
         rf.release_domain()
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_reference_build_matches_new_row_goldens(cname):
+    """the committed G2 / scalar-field NTT / ECNTT fixtures are what the reference build produces today"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"msm_g2_{cname}.npz"))
+    rc = ref.RefCurve(cname, g2=True)
+    n = g["bases"].shape[0]
+    assert np.array_equal(rc.to_affine(rc.msm(np.ascontiguousarray(g["scalars"][:n]), g["bases"])), g["res_single"])
+    s = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"scalar_ntt_{cname}.npz"))
+    sf = ref.RefScalarNttField(cname)
+    sf.init_domain(from_words(s["domain_root"]))
+    try:
+        assert np.array_equal(sf.ntt(s["x"], 512, 0, batch=2), s["fwd_NN"])
+        assert np.array_equal(sf.ntt(s["x"], 512, 1, batch=2, ordering=2, coset_gen=from_words(s["coset_gen"])), s["inv_RN_coset"])
+        r1 = ref.RefCurve(cname)
+        L = pyref.CURVES[cname].limbs_q
+        assert np.array_equal(r1.to_affine(r1.ecntt(s["ec_points"], 32, 0).reshape(32, 3 * L)), s["ec_fwd_NN_affine"])
+    finally:
+        sf.release_domain()
