@@ -6,7 +6,7 @@
 // SURVEY.md App. C lists the fine print (orderings, coset, batch layouts, kNM/kMN = natural).
 //
 // Design (not the CPU's Winograd-leaf hierarchy): N = N0*N1[*N2] is split into at most three
-// passes of <= 2^12-point sub-transforms. A pass stages a [2^s x T] tile (T adjacent columns, so
+// passes of 2^8-point (above 2^24: up to 2^10-point) sub-transforms. A pass stages a [2^s x T] tile (T adjacent columns, so
 // every HBM access is a run of T contiguous elements) in LDS, runs the s radix-2 stages there,
 // applies the inter-pass twiddle w_M^(j*K) on the way out, and the LAST pass scatters straight
 // into natural order (runs of T again) -- so an NN transform is exactly P reads + P writes of the

@@ -87,7 +87,10 @@ def ntt_scalar_case(field, logn, batch):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "csweep":
-        for logn, cs in ((16, (9, 10, 11, 12, 13)), (20, (12, 13, 14, 15, 16)), (22, (14, 15, 16, 17, 18)), (24, (16, 17, 18, 19, 20)), (26, (18, 19, 20, 21))):
+        sweep = ((16, (9, 10, 11, 12, 13)), (20, (12, 13, 14, 15, 16)), (22, (14, 15, 16, 17, 18)), (24, (16, 17, 18, 19, 20)), (26, (18, 19, 20, 21)))
+        if len(sys.argv) > 2:
+            sweep = tuple(x for x in sweep if x[0] == int(sys.argv[2]))
+        for logn, cs in sweep:
             msm_case("bn254", logn)
             for c in cs:
                 msm_case("bn254", logn, c=c)
