@@ -683,7 +683,7 @@ namespace icicle_hip {
   }
 
   template <class C, int MINW>
-  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, const uint32_t* __restrict__ perm, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
+  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, const uint32_t* __restrict__ perm, uint32_t ovf_cap, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
   {
     // bases_stride: words between the base arrays of consecutive MSMs of a batch (0 = shared bases)
     // perm: thread t < nbk accumulates bucket perm[t] (size-balanced order)
@@ -693,12 +693,15 @@ namespace icicle_hip {
     size_t bucket;
     uint32_t start;
     typename E::Proj* dst;
-    if (t < nbk) {
-      bucket = perm[t];
+    // overflow segments first: each is a full `seg` points, the heaviest work items of the launch, so they must
+    // not be left for the tail (unused overflow slots exit at once)
+    if (t >= ovf_cap) {
+      if (t - ovf_cap >= nbk) return;
+      bucket = perm[t - ovf_cap];
       start = 0;
       dst = buckets + bucket;
     } else {
-      const size_t o = t - nbk;
+      const size_t o = t;
       if (o >= *ovf_count) return;
       bucket = ovf[o].bucket;
       start = ovf[o].start;
@@ -1187,7 +1190,7 @@ namespace icicle_hip {
         const size_t nthreads_acc = gbk + ovf_cap;
         const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
         const size_t bstride = shared ? 0 : npts_one * PW;
-#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), d_perm.as<uint32_t>(), nb, gbk, cap, pl.seg, wpf, bstride
+#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), d_perm.as<uint32_t>(), ovf_cap, nb, gbk, cap, pl.seg, wpf, bstride
         if constexpr (BIGPT) {
           if constexpr (sizeof(typename E::XYZZ) <= 288) {
             if (minw >= 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
