@@ -283,3 +283,44 @@ def test_msm_skewed_large_overflow_segments(hip, cname):
     sc[::1000] = to_words(rand_scalars(rng, len(sc[::1000]), C.r), 8)
     _check(hip, cname, sc, bases, refc)
     _check(hip, cname, sc, bases, refc, c=16)
+
+
+def test_concurrent_host_threads(hip):
+    """four host threads issue MSMs and NTTs at the same time (ctypes releases the GIL during the call): every
+    call leases its own temporaries, so the results must be those of the serial runs"""
+    import threading
+
+    from icicle_amd import msm as M
+    from icicle_amd import ntt as N
+    from icicle_amd import runtime
+
+    C = pyref.BN254
+    rng = np.random.default_rng(91)
+    n = 3000
+    bases = points_to_array(C, cached_points(C, n))
+    scal = [to_words(rand_scalars(rng, n, C.r), 8) for _ in range(4)]
+    serial = [M.msm("bn254", s, bases) for s in scal]
+    F = pyref.BABYBEAR
+    N.init_domain("babybear", N.get_root_of_unity("babybear", 1 << 14))
+    xs = [rng.integers(0, F.p, size=1 << 14, dtype=np.uint32) for _ in range(4)]
+    serial_ntt = [N.ntt("babybear", x, N.FORWARD) for x in xs]
+    out, out_ntt, errs = [None] * 4, [None] * 4, []
+
+    def work(i):
+        try:
+            runtime.set_device(0)  # the active device is per host thread (icicle_set_device)
+            for _ in range(5):
+                out[i] = M.msm("bn254", scal[i], bases)
+                out_ntt[i] = N.ntt("babybear", xs[i], N.FORWARD)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    N.release_domain("babybear")
+    assert not errs, errs
+    refc = ref.RefCurve("bn254")
+    for i in range(4):
+        assert np.array_equal(refc.to_affine(out[i]), refc.to_affine(serial[i]))
+        assert np.array_equal(out_ntt[i], serial_ntt[i])
