@@ -44,3 +44,49 @@ def affine_convert_montgomery(curve: str, inp, to_montgomery: bool, cfg=None, ou
 def projective_convert_montgomery(curve: str, inp, to_montgomery: bool, cfg=None, out=None, n=None):
     L = {"bn254": 8, "bls12_381": 12}[curve]
     return _run(f"{curve}_projective_convert_montgomery", inp, n if n is not None else inp.size // (3 * L), to_montgomery, cfg, out)
+
+
+_WORDS = {"bn254": 8, "bls12_381": 8, "babybear": 1, "koalabear": 1}
+
+
+def _vec2(op: str, field: str, a, b, size, cfg, out):
+    """mirror of wrappers/rust/icicle-core/src/vec_ops: add / sub / mul / scalar-mul of field vectors"""
+    cfg = cfg or VecOpsConfig.default()
+    ap, cfg.is_a_on_device = _ptr(a)
+    bp, cfg.is_b_on_device = _ptr(b)
+    if size is None:
+        size = b.size // _WORDS[field] // max(1, cfg.batch_size)
+    if out is None:
+        out = np.zeros_like(b)
+    op_, cfg.is_result_on_device = _ptr(out)
+    check(getattr(lib, f"{field}_{op}")(ap, bp, size, ctypes.byref(cfg), op_), f"{field}_{op}")
+    return out
+
+
+def vector_add(field, a, b, cfg=None, out=None, size=None):
+    return _vec2("vector_add", field, a, b, size, cfg, out)
+
+
+def vector_sub(field, a, b, cfg=None, out=None, size=None):
+    return _vec2("vector_sub", field, a, b, size, cfg, out)
+
+
+def vector_mul(field, a, b, cfg=None, out=None, size=None):
+    return _vec2("vector_mul", field, a, b, size, cfg, out)
+
+
+def scalar_mul_vec(field, scalars, b, cfg=None, out=None, size=None):
+    """scalars: one per batch entry"""
+    return _vec2("scalar_mul_vec", field, scalars, b, size, cfg, out)
+
+
+def bit_reverse(field, inp, cfg=None, out=None, size=None):
+    cfg = cfg or VecOpsConfig.default()
+    ip, cfg.is_a_on_device = _ptr(inp)
+    if size is None:
+        size = inp.size // _WORDS[field] // max(1, cfg.batch_size)
+    if out is None:
+        out = np.zeros_like(inp)
+    op_, cfg.is_result_on_device = _ptr(out)
+    check(getattr(lib, f"{field}_bit_reverse")(ip, size, ctypes.byref(cfg), op_), f"{field}_bit_reverse")
+    return out

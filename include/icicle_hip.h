@@ -232,6 +232,25 @@ icicle_error_t bn254_g2_projective_convert_montgomery(const void* input, uint64_
 icicle_error_t bls12_381_g2_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 icicle_error_t bls12_381_g2_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 
+/* Element-wise vector operations next to the NTT path, for the four NTT fields (src/vec_ops.cpp:71-84 vector_add,
+ * :136-149 vector_sub, :169-182 vector_mul, :362-366 scalar_mul_vec -- one scalar per batch entry --, :440-444
+ * bit_reverse). `size` is per batch entry; config.batch_size / columns_batch as in the reference. */
+#define ICICLE_HIP_DECLARE_VEC_ARITH(F)                                                                                \
+  icicle_error_t F##_vector_add(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t F##_vector_sub(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t F##_vector_mul(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t F##_scalar_mul_vec(const void* scalar_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t F##_bit_reverse(const void* input, uint64_t size, const icicle_vec_ops_config_t* config, void* output); \
+  icicle_error_t icicle_hip_##F##_vector_add(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t icicle_hip_##F##_vector_sub(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t icicle_hip_##F##_vector_mul(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t icicle_hip_##F##_scalar_mul_vec(const void* scalar_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t icicle_hip_##F##_bit_reverse(const void* input, uint64_t size, const icicle_vec_ops_config_t* config, void* output);
+ICICLE_HIP_DECLARE_VEC_ARITH(babybear)
+ICICLE_HIP_DECLARE_VEC_ARITH(koalabear)
+ICICLE_HIP_DECLARE_VEC_ARITH(bn254)
+ICICLE_HIP_DECLARE_VEC_ARITH(bls12_381)
+
 /* ---- backend-specific helpers (not part of the reference ABI) ---- */
 const char* icicle_hip_version(void);
 /* The window plan msm() would use for this size / config: c = window bits, nwin = number of c-bit windows of a

@@ -29,6 +29,34 @@ static eIcicleError hip_scalar_convert(const Device& device, const scalar_t* inp
 }
 REGISTER_CONVERT_MONTGOMERY_BACKEND("HIP", hip_scalar_convert);
 
+// element-wise vector ops next to the NTT (icicle/include/icicle/backend/vec_ops_backend.h:25-31,87-132,216-222)
+#define HIP_VEC2(NAME)                                                                                                 \
+  static eIcicleError hip_##NAME(const Device& device, const scalar_t* a, const scalar_t* b, uint64_t size, const VecOpsConfig& config, scalar_t* output) \
+  {                                                                                                                    \
+    if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;                                    \
+    hip_vec_ops_config_t c;                                                                                            \
+    std::memcpy(&c, &config, sizeof(c));                                                                               \
+    c.ext = nullptr;                                                                                                   \
+    return (eIcicleError)HIP_FN(NAME)(a, b, size, &c, output);                                                         \
+  }
+HIP_VEC2(vector_add)
+HIP_VEC2(vector_sub)
+HIP_VEC2(vector_mul)
+HIP_VEC2(scalar_mul_vec)
+static eIcicleError hip_bit_reverse(const Device& device, const scalar_t* input, uint64_t size, const VecOpsConfig& config, scalar_t* output)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  hip_vec_ops_config_t c;
+  std::memcpy(&c, &config, sizeof(c));
+  c.ext = nullptr;
+  return (eIcicleError)HIP_FN(bit_reverse)(input, size, &c, output);
+}
+REGISTER_VECTOR_ADD_BACKEND("HIP", hip_vector_add);
+REGISTER_VECTOR_SUB_BACKEND("HIP", hip_vector_sub);
+REGISTER_VECTOR_MUL_BACKEND("HIP", hip_vector_mul);
+REGISTER_SCALAR_MUL_VEC_BACKEND("HIP", hip_scalar_mul_vec);
+REGISTER_BIT_REVERSE_BACKEND("HIP", hip_bit_reverse);
+
 #ifdef HIP_PLUGIN_SCALAR_FIELD_256
 typedef hip_ntt_config_u256_t hip_ntt_config_t;
 static_assert(sizeof(scalar_t) == 32, "HIP_PLUGIN_SCALAR_FIELD_256 is for the curves' scalar fields");

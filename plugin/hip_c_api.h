@@ -85,6 +85,16 @@ HIP_DECLARE_FIELD(koalabear)
   int icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t, uint32_t*);
 HIP_DECLARE_SCALAR_FIELD(bn254)
 HIP_DECLARE_SCALAR_FIELD(bls12_381)
+#define HIP_DECLARE_VEC_ARITH(F)                                                                                        \
+  int icicle_hip_##F##_vector_add(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);              \
+  int icicle_hip_##F##_vector_sub(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);              \
+  int icicle_hip_##F##_vector_mul(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);              \
+  int icicle_hip_##F##_scalar_mul_vec(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);          \
+  int icicle_hip_##F##_bit_reverse(const void*, uint64_t, const hip_vec_ops_config_t*, void*);
+HIP_DECLARE_VEC_ARITH(babybear)
+HIP_DECLARE_VEC_ARITH(koalabear)
+HIP_DECLARE_VEC_ARITH(bn254)
+HIP_DECLARE_VEC_ARITH(bls12_381)
 int icicle_hip_bn254_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 int icicle_hip_bls12_381_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 }

@@ -98,6 +98,27 @@ def main():
         assert np.array_equal(fobj.ntt(x, n, 0, batch=batch), exp_f)
         assert np.array_equal(fobj.ntt(x, n, 1, batch=batch, ordering=2, coset_gen=5), exp_i)
         assert np.array_equal(fobj.ntt(x[: 4 * 256], 256, 0, extension=True), exp_e)
+        # element-wise vec-ops registered next to the NTT: dispatched to "HIP" by the reference frontend
+        import ctypes
+
+        def vec2(op, a, b):
+            cfg = ref.VecOpsConfig(None, False, False, False, False, 1, False, None)
+            out = np.zeros_like(b)
+            fn = getattr(fobj.lib, f"{fobj.name}_{op}")
+            if op == "bit_reverse":
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+                assert fn(b.ctypes.data, b.size, ctypes.byref(cfg), out.ctypes.data) == 0
+            else:
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+                assert fn(a.ctypes.data, b.ctypes.data, b.size, ctypes.byref(cfg), out.ctypes.data) == 0
+            return out
+
+        va, vb = x[:n].copy(), x[n:2 * n].copy()
+        hip_res = [vec2(op, va, vb) for op in ("vector_add", "vector_sub", "vector_mul", "bit_reverse")]
+        assert rt.set_device("CPU", 0) == 0
+        cpu_res = [vec2(op, va, vb) for op in ("vector_add", "vector_sub", "vector_mul", "bit_reverse")]
+        assert all(np.array_equal(h, c) for h, c in zip(hip_res, cpu_res))
+        assert rt.set_device("HIP", 0) == 0
         rc, d_in = rt.malloc(x.nbytes)
         rc, d_out = rt.malloc(x.nbytes)
         rt.to_device(d_in, x)
