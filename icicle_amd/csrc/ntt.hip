@@ -249,12 +249,19 @@ namespace icicle_hip {
     const uint32_t baseT = (NR == 1) ? 0u : (((gB >> QT) << (QT + 4)) | (gB & ((1u << QT) - 1)));
     uint32_t wip[E]; // inter-pass twiddles of the E elements this thread stores (column passes)
     if (!DIF) {
+      // w_M^(jnext * K), K = k (pass 0) or a + n0*k (pass 1). In pass 1 jnext is the column itself, so
+      // jnext * K walks the whole table at random (a 64-byte line per 4-byte twiddle, +25 % traffic on that pass);
+      // split as w^(jnext*a) * w^(jnext*n0*k): the first index stays in a 256 KiB prefix of the table, the second
+      // takes 2^16 distinct values shared by every block -- both live in L2 / Infinity Cache.
       const uint64_t jnext = ((uint64_t)ct * T + tB) / pd.cprime;
+      const uint32_t wa = (pd.pidx == 0) ? 0u : tw_load(jnext * a * pd.tw_stride);
 #pragma unroll
       for (int m = 0; m < E; m++) {
         const uint32_t k = (NR == 1) ? (uint32_t)m : baseT + ((uint32_t)m << QT);
-        const uint64_t K = (pd.pidx == 0) ? (uint64_t)k : ((uint64_t)a + (uint64_t)pd.n0 * k);
-        wip[m] = tw_load(jnext * K * pd.tw_stride);
+        if (pd.pidx == 0)
+          wip[m] = tw_load(jnext * k * pd.tw_stride);
+        else
+          wip[m] = S::mul(wa, tw_load(jnext * pd.n0 * k * pd.tw_stride));
       }
     }
 
