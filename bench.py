@@ -217,7 +217,9 @@ def main():
         N.release_domain("babybear")
 
     # ---------------- N > 1 only: ONE large NTT split over the ranks (4-step, all-to-all over RCCL/xGMI) -----
-    if world > 1 and not args.no_ntt:
+    # Opt-in (ICICLE_BENCH_NTT_SPLIT=1): it adds three all-to-all exchanges that no single-GPU box can rehearse, and
+    # a collective that stalls would take the primary line down with it.
+    if world > 1 and not args.no_ntt and os.environ.get("ICICLE_BENCH_NTT_SPLIT", "0") == "1":
         try:
             slog = 26
             N.init_domain("babybear", N.get_root_of_unity("babybear", 1 << slog))
