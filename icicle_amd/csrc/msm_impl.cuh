@@ -622,7 +622,9 @@ namespace icicle_hip {
     uint32_t nextra; // number of overflow segments of the bucket (valid when first)
   };
 
-  static __global__ __launch_bounds__(256) void k_plan_overflow(const uint32_t* __restrict__ count, size_t nbk, uint32_t seg, uint32_t* __restrict__ ovf_count, OvfSeg* __restrict__ ovf, uint32_t ovf_cap)
+  // ovf_count[0] = overflow segments, [1] = overflowing buckets, [2] = largest number of segments of one bucket;
+  // firsts[i] = slot of the first segment of the i-th overflowing bucket
+  static __global__ __launch_bounds__(256) void k_plan_overflow(const uint32_t* __restrict__ count, size_t nbk, uint32_t seg, uint32_t* __restrict__ ovf_count, OvfSeg* __restrict__ ovf, uint32_t* __restrict__ firsts, uint32_t ovf_cap)
   {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nbk) return;
@@ -630,6 +632,10 @@ namespace icicle_hip {
     if (cnt <= seg) return;
     const uint32_t extra = (cnt + seg - 1) / seg - 1;
     const uint32_t slot = atomicAdd(ovf_count, extra);
+    if (slot < ovf_cap) {
+      firsts[atomicAdd(ovf_count + 1, 1u)] = slot;
+      atomicMax(ovf_count + 2, extra);
+    }
     for (uint32_t sgi = 0; sgi < extra && slot + sgi < ovf_cap; sgi++) {
       OvfSeg o;
       o.bucket = (uint32_t)t;
@@ -733,32 +739,37 @@ namespace icicle_hip {
     *dst = E::to_proj(acc, empty);
   }
 
-  // buckets[b] += its overflow partials: one 64-lane block per overflowing bucket at a time (lanes fold
-  // strided partials, then a tree through LDS), so a bucket with thousands of segments -- a 1-bit top
-  // window, all-equal scalars -- costs log-depth, not a serial chain.
+  // buckets[b] += its overflow partials. A group of G lanes handles one overflowing bucket: lanes fold strided
+  // partials, then a tree through LDS, so a bucket with thousands of segments -- a 1-bit top window, all-equal
+  // scalars -- costs log-depth, not a serial chain. G = 16 when no bucket has more than 16 segments (the usual
+  // case: the short top window of uniform scalars has ~15 per bucket, and a wave then folds four buckets at once
+  // instead of spending 7 wave-wide additions on each), otherwise 64.
   template <class C>
-  __global__ __launch_bounds__(64) void k_fold_overflow(typename EC<C>::Proj* __restrict__ buckets, const typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, uint32_t ovf_cap)
+  __global__ __launch_bounds__(64) void k_fold_overflow(typename EC<C>::Proj* __restrict__ buckets, const typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ firsts, const uint32_t* __restrict__ ovf_count, uint32_t ovf_cap)
   {
     using E = EC<C>;
     __shared__ typename E::Proj sh[64];
-    const uint32_t n = min(*ovf_count, ovf_cap);
-    const int lane = threadIdx.x;
-    for (uint32_t o = blockIdx.x; o < n; o += gridDim.x) {
-      if (!ovf[o].first) continue; // block-uniform
-      const uint32_t ne = min(ovf[o].nextra, n - o);
+    const uint32_t n = min(ovf_count[0], ovf_cap), nfirst = ovf_count[1];
+    const uint32_t G = ovf_count[2] <= 16 ? 16u : 64u, per_block = 64 / G;
+    const uint32_t lane = threadIdx.x, sub = lane / G, gl = lane % G;
+    for (uint32_t q0 = blockIdx.x * per_block; q0 < nfirst; q0 += gridDim.x * per_block) {
+      const uint32_t q = q0 + sub;
+      const bool act = q < nfirst;
+      const uint32_t o = act ? firsts[q] : 0;
+      const uint32_t ne = act ? min(ovf[o].nextra, n - o) : 0;
       typename E::Proj v = E::proj_identity();
-      for (uint32_t k = lane; k < ne; k += 64)
+      for (uint32_t k = gl; k < ne; k += G)
         v = E::add(v, ovf_part[o + k]);
       sh[lane] = v;
       __syncthreads();
-      for (int s = 32; s >= 1; s >>= 1) {
-        if (lane < s) {
+      for (uint32_t s = G / 2; s >= 1; s >>= 1) {
+        if (gl < s) {
           v = E::add(v, sh[lane + s]);
           sh[lane] = v;
         }
         __syncthreads();
       }
-      if (lane == 0) buckets[ovf[o].bucket] = E::add(buckets[ovf[o].bucket], v);
+      if (act && gl == 0) buckets[ovf[o].bucket] = E::add(buckets[ovf[o].bucket], v);
       __syncthreads();
     }
   }
@@ -1080,7 +1091,7 @@ namespace icicle_hip {
     const uint32_t maxblkB = (uint32_t)std::min<size_t>(nparts + (elems_max >> CHUNKB_LOG) + 2, 0x7fffffffu);
     const uint32_t ovf_cap = (uint32_t)std::min<size_t>(elems_max / pl.seg + 16, 0x7fffffffu);
 
-    TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt, d_scansum, d_perm, d_sztab, d_szoff;
+    TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt, d_scansum, d_perm, d_sztab, d_szoff, d_firsts;
     HIP_TRY(d_mont.alloc((shared ? 1 : (size_t)BB) * npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_dig.alloc((size_t)BB * pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
     if (!single_level) HIP_TRY(d_partA.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
@@ -1096,6 +1107,7 @@ namespace icicle_hip {
     HIP_TRY(d_win.alloc(TW * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_firsts.alloc((size_t)std::min<size_t>(ovf_cap, nbk) * 4 + 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovfcnt.alloc(16, st), ICICLE_ALLOCATION_FAILED);
     const size_t szblk_max = (nbk + SZ_CHUNK - 1) / SZ_CHUNK;
     HIP_TRY(d_perm.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
@@ -1169,7 +1181,7 @@ namespace icicle_hip {
         LAUNCH_CHECK("k_b_scatter", st);
       }
       HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16, st), ICICLE_COPY_FAILED);
-      k_plan_overflow<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(count, gbk, pl.seg, d_ovfcnt.as<uint32_t>(), d_ovf.as<OvfSeg>(), ovf_cap);
+      k_plan_overflow<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(count, gbk, pl.seg, d_ovfcnt.as<uint32_t>(), d_ovf.as<OvfSeg>(), d_firsts.as<uint32_t>(), ovf_cap);
       LAUNCH_CHECK("k_plan_overflow", st);
       {
         const unsigned szblk = (unsigned)((gbk + SZ_CHUNK - 1) / SZ_CHUNK);
@@ -1208,7 +1220,7 @@ namespace icicle_hip {
       }
       LAUNCH_CHECK("k_accumulate", st);
       KernelTimer::end(0, st);
-      k_fold_overflow<C><<<std::min<uint32_t>(ovf_cap, 4096), 64, 0, st>>>(buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
+      k_fold_overflow<C><<<std::min<uint32_t>(ovf_cap, 4096), 64, 0, st>>>(buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_firsts.as<uint32_t>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
       LAUNCH_CHECK("k_fold_overflow", st);
       const size_t nsg = tw * nseg;
       k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(buckets, d_seg.as<typename E::Proj>(), nb, m, (int)tw);
