@@ -177,6 +177,38 @@ namespace icicle_hip {
       dig[(b * nwin + wi) * n + i] = it.next(c);
   }
 
+  // k_digits fused with pass A's histogram (k_a_count): block (b, mb) owns scalar chunk b of MSM mb, writes its digits
+  // and counts, per target window, how many fall into each of the 2^hb partitions -- the counts come from registers
+  // instead of a second read of the 13 x 4 B per scalar digit array. Dynamic LDS: wpf * 2^hb counters.
+  template <class C>
+  __global__ __launch_bounds__(1024) void k_digits_count(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int c, int nwin, int wpf, SortPlan sp, bool scalars_refmont)
+  {
+    extern __shared__ uint32_t lds[];
+    const int b = blockIdx.x, mb = blockIdx.y;
+    const uint32_t D = 1u << sp.hb, nh = (uint32_t)wpf * D;
+    for (uint32_t k = threadIdx.x; k < nh; k += blockDim.x)
+      lds[k] = 0;
+    __syncthreads();
+    const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      DigitIter it;
+      load_scalar<C>(it, scalars, (size_t)mb * n + i, scalars_refmont);
+      int wp = 0;
+      for (int wi = 0; wi < nwin; wi++) {
+        const uint32_t d = it.next(c);
+        dig[((size_t)mb * nwin + wi) * n + i] = d;
+        const uint32_t key = d & 0x7fffffffu;
+        if (key) atomicAdd(&lds[(uint32_t)wp * D + ((key - 1) >> sp.lb)], 1u);
+        if (++wp == wpf) wp = 0;
+      }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nh; k += blockDim.x) {
+      const uint32_t wp = k >> sp.hb, h = k & (D - 1);
+      cntA[((((size_t)mb * wpf + wp) << sp.hb) + h) * sp.nblk + b] = lds[k];
+    }
+  }
+
   // exclusive prefix of one value per thread over the block (blockDim.x a multiple of 64, <= 1024);
   // wsum: >= 17 words of LDS scratch
   __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wsum)
@@ -1144,11 +1176,19 @@ namespace icicle_hip {
       }
       const uint32_t* sc = d_scalars + (size_t)b0 * n * FR::N32;
       const size_t nscal = (size_t)bb * n;
-      k_digits<C><<<(unsigned)((nscal + 255) / 256), 256, 0, st>>>(sc, dig, n, nscal, pl.c, pl.nwin, cfg->are_scalars_montgomery_form);
-      LAUNCH_CHECK("k_digits", st);
+      const size_t lds_dc = ((size_t)wpf << sp.hb) * 4;
+      // digits + pass-A histogram in one pass over the scalars, when there are enough chunks to fill the chip
+      // (a block walks a whole chunk; with few chunks the thread-per-scalar k_digits + k_a_count pair is faster)
+      if (lds_dc <= 64 * 1024 && bb <= 65535 && (size_t)sp.nblk * bb >= 512) {
+        k_digits_count<C><<<dim3(sp.nblk, (unsigned)bb), 1024, lds_dc, st>>>(sc, dig, cntA, n, pl.c, pl.nwin, wpf, sp, cfg->are_scalars_montgomery_form);
+        LAUNCH_CHECK("k_digits_count", st);
+      } else {
+        k_digits<C><<<(unsigned)((nscal + 255) / 256), 256, 0, st>>>(sc, dig, n, nscal, pl.c, pl.nwin, cfg->are_scalars_montgomery_form);
+        LAUNCH_CHECK("k_digits", st);
+        k_a_count<<<dim3(sp.nblk, (unsigned)tw), 1024, ((size_t)4 << sp.hb), st>>>(dig, cntA, n, pl.nwin, wpf, pf, sp);
+        LAUNCH_CHECK("k_a_count", st);
+      }
       // the per-window totals live right after the [tw][2^hb][nblk] table of THIS launch
-      k_a_count<<<dim3(sp.nblk, (unsigned)tw), 1024, ((size_t)4 << sp.hb), st>>>(dig, cntA, n, pl.nwin, wpf, pf, sp);
-      LAUNCH_CHECK("k_a_count", st);
       {
         const uint32_t m = (uint32_t)(nparts_w * sp.nblk), nch = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
         k_scan_sums<<<dim3(nch, (unsigned)tw), 1024, 0, st>>>(cntA, d_scansum.as<uint32_t>(), m);
