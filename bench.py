@@ -151,6 +151,10 @@ def main():
     madds = n * pw.value
     roofline["alu"] = {"window_bits": pc.value, "windows": pw.value, "mixed_adds": madds,
                        "mixed_adds_per_s": madds / (acc_ms * 1e-3)}
+    # every mixed add gathers one 64-byte point at a random address; a pure random-64-byte-gather microbenchmark
+    # reaches 1.49e10 gathers/s on this chip (profiles/r01_alu_ubench.txt), the second roof this kernel sits under
+    roofline["gather"] = {"gathers_per_s": madds / (acc_ms * 1e-3), "measured_ceiling": 1.49e10,
+                          "frac": madds / (acc_ms * 1e-3) / 1.49e10, "unit": "random 64-byte gathers/s"}
 
     out = {
         "metric": "bn254_msm_2^26_per_sec", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
