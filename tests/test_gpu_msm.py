@@ -229,36 +229,39 @@ def test_generated_points_are_distinct_multiples_of_g(hip):
     assert np.array_equal(pts, exp)
 
 
-def test_msm_full_size_split_property(hip):
-    """BASELINE config 1 size (2^26 BN254, inputs resident in HBM): a size-independent property instead of
-    the CPU oracle -- MSM(all) == MSM(first half) + MSM(second half), with the halves combined by the
-    reference's own ecadd, plus a reference check on a 2^16 prefix of the same inputs."""
+@pytest.mark.parametrize("cname,logn,top", [("bn254", 26, 0x30644E72), ("bls12_381", 25, 0x73EDA753)])
+def test_msm_full_size_split_property(hip, cname, logn, top):
+    """BASELINE config 1 size (2^26 BN254) and the per-GPU share of config 3 (BLS12-381 2^28 over 8 GPUs = 2^25),
+    inputs resident in HBM: a size-independent property instead of the CPU oracle -- MSM(all) == MSM(first half) +
+    MSM(second half), with the halves combined by the reference's own ecadd, plus a reference check on a 2^16
+    prefix of the same inputs."""
     import ctypes
     import torch
     from icicle_amd import msm as M
     from icicle_amd._lib import lib, check
 
-    refc = ref.RefCurve("bn254")
-    n = 1 << 26
+    refc = ref.RefCurve(cname)
+    L = M.LIMBS[cname]
+    n = 1 << logn
     dev = torch.device("cuda", 0)
-    bases = torch.empty((n, 16), dtype=torch.int32, device=dev)
-    check(lib.bn254_hip_generate_affine_points(bases.data_ptr(), n, 12345, True, None))
+    bases = torch.empty((n, 2 * L), dtype=torch.int32, device=dev)
+    check(getattr(lib, f"{cname}_hip_generate_affine_points")(bases.data_ptr(), n, 12345, True, None))
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     sc = torch.randint(-(2 ** 31), 2 ** 31, (n, 8), dtype=torch.int32, device=dev, generator=g)
-    sc[:, 7] = torch.randint(0, 0x30644E72, (n,), dtype=torch.int32, device=dev, generator=g)
+    sc[:, 7] = torch.randint(0, top, (n,), dtype=torch.int32, device=dev, generator=g)
     torch.cuda.synchronize()
 
     def run(lo, hi):
         cfg = hip.MSMConfig.default()
-        out = np.zeros((1, 24), dtype=np.uint32)
-        M.msm("bn254", sc[lo:hi].data_ptr(), bases[lo:hi].data_ptr(), cfg, results=out, msm_size=hi - lo)
+        out = np.zeros((1, 3 * L), dtype=np.uint32)
+        M.msm(cname, sc[lo:hi].data_ptr(), bases[lo:hi].data_ptr(), cfg, results=out, msm_size=hi - lo)
         return out
 
     full, a, b = run(0, n), run(0, n // 2), run(n // 2, n)
-    s = np.zeros(24, dtype=np.uint32)
-    refc.lib.bn254_ecadd(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(s.ctypes.data))
-    assert np.array_equal(refc.to_affine(full), refc.to_affine(s.reshape(1, 24)))
+    s = np.zeros(3 * L, dtype=np.uint32)
+    getattr(refc.lib, f"{cname}_ecadd")(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(s.ctypes.data))
+    assert np.array_equal(refc.to_affine(full), refc.to_affine(s.reshape(1, 3 * L)))
     assert refc.is_on_curve(full[0])
     m = 1 << 16
     hs = np.ascontiguousarray(sc[:m].cpu().numpy().view(np.uint32))
