@@ -10,7 +10,7 @@
 //   * a run of T = 4 elements is already a 128 B HBM transaction, so tiles are narrow and tall;
 //   * the tile lives in LDS as 9 x 29-bit limbs per element (36 B, odd word stride) so the
 //     butterflies use bigfield.cuh's lazy arithmetic without re-packing between stages;
-//   * a butterfly is one 9-limb Montgomery product (~230 VALU ops): the pass is ALU-bound, not
+//   * a butterfly is one 9-limb Montgomery product (~230 VALU ops), two stages per LDS round trip: the pass is ALU-bound, not
 //     HBM-bound (2^24 elements: ~1.5 GB of traffic per direction vs ~6e10 lane-ops).
 // Data stays in the caller's (canonical or Montgomery) form: twiddles are kept in Montgomery form
 // and montmul(x, w*R) = x*w. Lazy bounds (units of p): loads 1.2, 3.2 and 7.2 after the two
@@ -67,9 +67,50 @@ namespace icicle_hip {
     }
     __syncthreads();
 
-    // ---- s radix-2 DIT stages in LDS; w_L^e = tw[e * (max/L)]
+    // ---- s radix-2 DIT stages in LDS, two per round trip; w_L^e = tw[e * (max/L)]
+    // A thread takes the four elements i, i+h, i+2h, i+3h (h = 2^q) through stages q and q+1 in registers: half the
+    // LDS traffic, index arithmetic and barriers of one stage per trip. Lazy bounds as before: the first two stages
+    // skip the trivial-twiddle products (1.2 -> 3.2 -> 7.2), every later stage adds 2.
     const uint32_t lstride_log = nl.log_max - pd.s;
-    for (int q = 0; q < pd.s; q++) {
+    auto stage_tw = [&](int q, uint32_t pos) -> fe { return tw_load(((uint64_t)pos << (pd.s - 1 - q)) << lstride_log); };
+    int q = 0;
+    for (; q + 1 < pd.s; q += 2) {
+      const uint32_t h = 1u << q;
+      for (uint32_t id = threadIdx.x; id < tot / 4; id += blockDim.x) {
+        const uint32_t t = id % T, bf = id / T;
+        const uint32_t pos = bf & (h - 1);
+        const uint32_t i = ((bf >> q) << (q + 2)) + pos;
+        fe x0 = tile[i * T + t], x1 = tile[(i + h) * T + t], x2 = tile[(i + 2 * h) * T + t], x3 = tile[(i + 3 * h) * T + t];
+        if (q == 0) {
+          // stage 0: twiddle 1 everywhere; stage 1: twiddle 1 on (x0, x2), w^(L/4) on (x1, x3)
+          fe a0 = F::add(x0, x1), a1 = F::template sub<2>(x0, x1);
+          fe a2 = F::add(x2, x3), a3 = F::template sub<2>(x2, x3);
+          a3 = F::mul(a3, stage_tw(1, 1));
+          x0 = F::add(a0, a2);
+          x2 = F::template sub<4>(a0, a2);
+          x1 = F::add(a1, a3);
+          x3 = F::template sub<4>(a1, a3);
+        } else {
+          const fe w = stage_tw(q, pos);
+          x1 = F::mul(x1, w);
+          x3 = F::mul(x3, w);
+          fe a0 = F::add(x0, x1), a1 = F::template sub<2>(x0, x1);
+          fe a2 = F::add(x2, x3), a3 = F::template sub<2>(x2, x3);
+          a2 = F::mul(a2, stage_tw(q + 1, pos));
+          a3 = F::mul(a3, stage_tw(q + 1, pos + h));
+          x0 = F::add(a0, a2);
+          x2 = F::template sub<2>(a0, a2);
+          x1 = F::add(a1, a3);
+          x3 = F::template sub<2>(a1, a3);
+        }
+        tile[i * T + t] = x0;
+        tile[(i + h) * T + t] = x1;
+        tile[(i + 2 * h) * T + t] = x2;
+        tile[(i + 3 * h) * T + t] = x3;
+      }
+      __syncthreads();
+    }
+    if (q < pd.s) { // odd number of stages: the last one alone
       const uint32_t half = 1u << q;
       for (uint32_t id = threadIdx.x; id < tot / 2; id += blockDim.x) {
         const uint32_t t = id % T, bf = id / T;
@@ -77,9 +118,7 @@ namespace icicle_hip {
         const uint32_t i = ((bf >> q) << (q + 1)) + pos;
         const fe u = tile[i * T + t];
         fe v = tile[(i + half) * T + t];
-        // stage 0 has only the trivial twiddle, stage 1 has it on half of the butterflies: skip those
-        // products while the operands are still small (bounds 1.2 -> 3.2 -> 7.2, then +2 per stage)
-        if (q >= 2 || (q == 1 && pos != 0)) v = F::mul(v, tw_load(((uint64_t)pos << (pd.s - 1 - q)) << lstride_log));
+        if (q >= 1 && !(q == 1 && pos == 0)) v = F::mul(v, stage_tw(q, pos));
         tile[i * T + t] = F::add(u, v);
         tile[(i + half) * T + t] = (q == 1) ? F::template sub<4>(u, v) : F::template sub<2>(u, v);
       }
@@ -313,7 +352,7 @@ namespace icicle_hip {
         tmax >>= 1;
       const PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
       const uint32_t tot = (uint32_t)(L * pd.T);
-      const unsigned threads = std::max(64u, std::min(512u, tot / 2));
+      const unsigned threads = std::max(64u, std::min(512u, tot / 4)); // one thread per 4-element group of a stage pair
       for (uint32_t r0 = 0; r0 < nl.nbatch; r0 += 65535) {
         NttLaunch ns = nl;
         ns.row0 = r0;
