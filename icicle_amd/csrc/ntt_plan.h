@@ -47,10 +47,12 @@ namespace icicle_hip {
     int src_rel = 0, dst_rel = 0;
   };
 
+#if defined(__HIPCC__)
   __device__ __forceinline__ uint64_t bitrev64(uint64_t x, uint32_t bits)
   {
     return bits == 0 ? 0 : (__brevll(x) >> (64 - bits));
   }
+#endif
 
 
   // <= 3 passes; sub-transforms of at most 2^smax points while that covers logn, larger above

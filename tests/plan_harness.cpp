@@ -1,0 +1,55 @@
+// Host check of the NTT pass plan (icicle_amd/csrc/ntt_plan.h): for every size, every pass's tiles must touch each
+// slot of a row exactly once on the way in, and the last pass's natural-order scatter must hit each output once.
+// The address formulas are the kernels' (k_ntt_fast / k_ntt_pass_generic / k_big_ntt_pass).
+#include "../icicle_amd/csrc/ntt_plan.h"
+#include <cstdio>
+#include <vector>
+using namespace icicle_hip;
+
+static int check(int logn, int smax, uint32_t tmax_cap)
+{
+  int parts[3], P;
+  split_logn(logn, smax, parts, &P);
+  int sum = 0;
+  for (int i = 0; i < P; i++)
+    sum += parts[i];
+  if (sum != logn || P < 1 || P > 3) return 1;
+  const uint64_t n = 1ull << logn;
+  for (int p = 0; p < P; p++) {
+    const uint64_t L = 1ull << parts[p];
+    const uint64_t epb = L >= 16 ? 16 : L;
+    uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(tmax_cap, 512 * epb / L));
+    while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
+      tmax >>= 1;
+    const PassDesc pd = make_pass(parts, P, p, n, /*log_max=*/logn, tmax);
+    if (pd.T < 1 || (uint64_t)pd.ntiles * pd.T * L != n) return 10 + p;
+    std::vector<uint8_t> in(n, 0), out(n, 0);
+    for (uint32_t tile = 0; tile < pd.ntiles; tile++) {
+      const uint32_t a = tile / pd.tiles_per_a, ct = tile % pd.tiles_per_a;
+      const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
+      for (uint64_t k = 0; k < L; k++)
+        for (int t = 0; t < pd.T; t++) {
+          const uint64_t addr = in_base + k * pd.in_sk + (uint64_t)t * pd.in_st;
+          if (addr >= n || in[addr]++) return 20 + p;
+          if (pd.is_last) {
+            const uint64_t K0 = (pd.pidx <= 1) ? ((uint64_t)ct * pd.T + t) : (((uint64_t)ct * pd.T + t) + (uint64_t)pd.n0 * a);
+            const uint64_t o = K0 + k * pd.out_sk;
+            if (o >= n || out[o]++) return 30 + p;
+          } else {
+            const uint64_t c = (uint64_t)ct * pd.T + t;
+            if (c / pd.cprime >= (1ull << parts[p + 1])) return 40 + p; // jnext is a digit of the next pass
+          }
+        }
+    }
+  }
+  return 0;
+}
+
+extern "C" int plan_check(int max_logn)
+{
+  for (int logn = 1; logn <= max_logn; logn++) {
+    if (int rc = check(logn, 8, 32)) return logn * 100 + rc;  // 31-bit fields
+    if (int rc = check(logn, 8, 4)) return logn * 100 + rc;   // 256-bit fields: tiles of at most 4 columns
+  }
+  return 0;
+}

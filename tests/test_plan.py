@@ -1,0 +1,17 @@
+"""CPU: the NTT pass decomposition (icicle_amd/csrc/ntt_plan.h) compiled for the host -- every pass covers a row exactly
+once and the last pass's scatter is a permutation, for every size up to 2^22 and both tile-width regimes."""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_ntt_plan_covers_every_slot_once():
+    so = os.path.join(HERE, "_build", "libplan.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    src = os.path.join(HERE, "plan_harness.cpp")
+    hdr = os.path.join(HERE, "..", "icicle_amd", "csrc", "ntt_plan.h")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", src, "-o", so])
+    assert ctypes.CDLL(so).plan_check(22) == 0
