@@ -83,6 +83,28 @@ namespace icicle_hip {
       BF_SET_BOUND(r, 1);
       return r;
     }
+    // R^2 mod p as limbs: mul(x_plain, r2()) = x*R (into Montgomery form); also "1" in the doubly-scaled form x*R^2
+    static HD fe r2()
+    {
+      fe r;
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        r.l[i] = PR::R2[i];
+      BF_SET_BOUND(r, 1);
+      return r;
+    }
+    // the plain integer 1: mul(x, plain_one()) = x/R (one Montgomery scaling removed)
+    static HD fe plain_one()
+    {
+      fe r = zero();
+      r.l[0] = 1;
+      BF_SET_BOUND(r, 1);
+      return r;
+    }
+    using bfe = fe;
+    static HD bfe base_r2() { return r2(); }
+    static HD bfe base_plain_one() { return plain_one(); }
+    static HD fe mul_base(const fe& a, const bfe& s) { return mul(a, s); }
     // constant given as [N] Montgomery limbs (< p)
     template <class ARR>
     static HD fe from_const(const ARR& c)

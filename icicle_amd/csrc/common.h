@@ -139,6 +139,23 @@ namespace icicle_hip {
     hipStream_t m_stream = nullptr;
   };
 
+  // ---- RCCL, bound lazily (multi-device calls only): the library is dlopen'ed on first use so that single-GPU
+  // users never load it and a process that already holds an RCCL (PyTorch ships its own librccl.so) shares that copy.
+  constexpr int RCCL_UINT32 = 3; // ncclDataType_t ncclUint32 (rccl.h)
+  struct RcclApi {
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist);
+    int (*CommDestroy)(void* comm);
+    int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t st);
+    int (*Send)(const void* send, size_t count, int dtype, int peer, void* comm, hipStream_t st);
+    int (*Recv)(void* recv, size_t count, int dtype, int peer, void* comm, hipStream_t st);
+    int (*GroupStart)();
+    int (*GroupEnd)();
+    const char* (*GetErrorString)(int);
+  };
+  const RcclApi* rccl_api(); // nullptr when no RCCL can be loaded
+  // one communicator per device of `devs` (ncclCommInitAll), created once per device list and cached
+  icicle_error_t rccl_comms_for(const std::vector<int>& devs, std::vector<void*>& comms);
+
   // ---- dominant-kernel timing with hipEvents on the launch stream (bench.py roofline figure) ----
   struct KernelTimer {
     static bool enabled();

@@ -9,8 +9,15 @@
 // the work and uses the same complete projective addition as the reference, which has no
 // exceptional cases at all (identity = (0:1:0), projective.h:26).
 //
+// Scaling convention of the hot loop (no Montgomery copy of the bases is ever made): the gathered affine point is
+// used AS IT LIES IN HBM -- plain canonical integers (x2, y2) -- and the accumulator keeps X, Y in Montgomery form
+// (X*R, Y*R) but ZZ, ZZZ doubly scaled (ZZ*R^2, ZZZ*R^2). Then montmul(x2, ZZ*R^2) = (x2*ZZ)*R is U2 in Montgomery
+// form at no cost, every other product of madd-2008-s sees two Montgomery operands, and montmul(ZZ*R^2, PP*R) =
+// (ZZ*PP)*R^2 keeps ZZ, ZZZ in their form. The only conversions are per BUCKET, not per point: the first point of
+// a bucket is multiplied by R^2 (2 products) and to_proj() removes one R from ZZ (1 product).
+//
 // Bounds (units of p, see bigfield.cuh; machine-checked under -DBIGFIELD_BOUNDS):
-//   affine (Montgomery)  x <= 1.2, y <= 2.2         XYZZ  X <= 8, Y <= 4, ZZ,ZZZ <= 2
+//   affine (plain words) x <= 1.2, y <= 2.2         XYZZ  X <= 8, Y <= 4, ZZ,ZZZ <= 2
 //   projective           X,Y,Z <= 4
 //
 // The same code serves G1 (coordinates in Fq, FieldOps) and G2 (coordinates in Fq2, fq2.cuh):
@@ -63,8 +70,8 @@ namespace icicle_hip {
         o |= w[i];
       return o == 0;
     }
-    // packed Montgomery copy kept in HBM by the MSM (same 2*N32 words per point)
-    static HD Aff load_mont(const uint32_t* w)
+    // affine words as they lie in HBM -> limbs, NO Montgomery conversion (plain integers if the words are canonical)
+    static HD Aff load_plain(const uint32_t* w)
     {
       Aff a;
       a.x = F::unpack(w);
@@ -87,10 +94,14 @@ namespace icicle_hip {
     }
 
     // ---- XYZZ --------------------------------------------------------------------------------
-    // 2*(x,y) for an affine point (dbl-2008-s-1 with ZZ1 = ZZZ1 = 1, a = 0)
-    static HD XYZZ dbl_affine(const Aff& p)
+    // 2*(x,y) for a PLAIN affine point, result in the accumulator's scaling (dbl-2008-s-1 with ZZ1 = ZZZ1 = 1, a = 0).
+    // Rare path (a bucket holding the same point twice): 4 extra products for the scalings.
+    static HD XYZZ dbl_affine(const Aff& plain)
     {
       XYZZ r;
+      Aff p;
+      p.x = F::mul_base(plain.x, F::base_r2());
+      p.y = F::mul_base(plain.y, F::base_r2());
       fe U = F::dbl(p.y);                // <= 4.4
       fe V = F::sqr(U);                  // ~1.2
       fe W = F::mul(U, V);               // ~1.1
@@ -102,20 +113,20 @@ namespace icicle_hip {
       if constexpr (F::TIGHT) r.x = F::below4(r.x);        // Fq2 over BN254: stored X stays < 4p
       fe t = F::template sub<8>(S, r.x);                   // <= 9.1
       r.y = F::template sub<2>(F::mul(M, t), F::mul(W, p.y)); // <= 3.3
-      r.zz = V;
-      r.zzz = W;
+      r.zz = F::mul_base(V, F::base_r2());
+      r.zzz = F::mul_base(W, F::base_r2());
       return r;
     }
 
-    // acc += b (b affine, not the identity). `empty` is the accumulator's "is identity" flag.
-    // madd-2008-s: 8M + 2S.
+    // acc += b (b = PLAIN affine limbs, not the identity). `empty` is the accumulator's "is identity" flag.
+    // madd-2008-s: 8M + 2S. Scaling: see the file header.
     static HD void madd(XYZZ& acc, bool& empty, const Aff& b)
     {
       if (empty) {
-        acc.x = b.x;
-        acc.y = b.y;
-        acc.zz = F::one();
-        acc.zzz = F::one();
+        acc.x = F::mul_base(b.x, F::base_r2());
+        acc.y = F::mul_base(b.y, F::base_r2());
+        acc.zz = F::r2();
+        acc.zzz = F::r2();
         empty = false;
         return;
       }
@@ -158,13 +169,16 @@ namespace icicle_hip {
       r.z = F::zero();
       return r;
     }
+    // (X*R, Y*R, ZZ*R^2, ZZZ*R^2) -> (X*ZZZ : Y*ZZ : ZZ*ZZZ), every coordinate scaled by the same R^2, i.e. the
+    // Montgomery form of the projective point (X*ZZZ*R : Y*ZZ*R : ZZ*ZZZ*R) = the same point
     static HD Proj to_proj(const XYZZ& a, bool empty)
     {
       if (empty) return proj_identity();
       Proj r;
+      const fe zz1 = F::mul_base(a.zz, F::base_plain_one()); // ZZ*R
       r.x = F::mul(a.x, a.zzz);
       r.y = F::mul(a.y, a.zz);
-      r.z = F::mul(a.zz, a.zzz);
+      r.z = F::mul(zz1, a.zzz);
       return r;
     }
     static HD Proj to_proj(const Aff& a)

@@ -57,6 +57,15 @@ namespace icicle_hip {
       r.c1 = B::zero();
       return r;
     }
+    static HD fe r2() // (R^2, 0): see FieldOps::r2
+    {
+      fe r;
+      r.c0 = B::r2();
+      r.c1 = B::zero();
+      return r;
+    }
+    static HD bfe base_r2() { return B::r2(); }
+    static HD bfe base_plain_one() { return B::plain_one(); }
     // constant given as [2][N] Montgomery limbs
     template <class ARR>
     static HD fe from_const(const ARR& c)

@@ -5,7 +5,7 @@
 // The CPU backend gives each worker private buckets and random-access RMWs into them; on MI355X
 // the same sum is reorganised so that the only random access left is a read-only gather:
 //
-//   1. k_bases_to_mont   bases -> packed Montgomery copy in HBM (one pass, 2 field muls per point)
+//   1. (no Montgomery copy of the bases: k_accumulate gathers the caller's canonical words, see ec.cuh)
 //   2. k_digits          scalars -> signed c-bit digits, one u32 per (window, scalar), coalesced
 //   3. two-level counting sort of point indices by bucket, every scatter staged through an LDS
 //      tile-sort so that HBM sees runs, not 4-byte random writes:
@@ -77,22 +77,30 @@ namespace icicle_hip {
   }
 
   // ------------------------------------------------------------------------------------------
-  // 1. bases -> packed Montgomery (thread per coordinate)
+  // 1. bases staging (thread per coordinate) -- NOT on the default path: bucket accumulation gathers the caller's
+  //    canonical affine words directly (ec.cuh header). Only bases given in the reference's Montgomery form
+  //    (are_points_montgomery_form: x*2^(32*N32) -> x) or at an address that is not 16-byte aligned are copied.
   template <class C>
-  __global__ __launch_bounds__(256) void k_bases_to_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t ncoord, bool in_refmont)
+  __global__ __launch_bounds__(256) void k_bases_stage(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t ncoord, bool in_refmont)
   {
-    using F = typename EC<C>::F;
+    using BF = FieldOps<typename C::fq>; // per base-field coordinate (G2: 4 per point)
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= ncoord) return;
-    uint32_t w[F::N32];
+    uint32_t w[BF::N32];
 #pragma unroll
-    for (int i = 0; i < F::N32; i++)
-      w[i] = in[t * F::N32 + i];
-    typename F::fe v = in_refmont ? F::from_refmont(w) : F::from_canonical(w);
-    F::pack(w, F::reduce(v));
+    for (int i = 0; i < BF::N32; i++)
+      w[i] = in[t * BF::N32 + i];
+    if (in_refmont) {
+      typename BF::fe cst;
 #pragma unroll
-    for (int i = 0; i < F::N32; i++)
-      out[t * F::N32 + i] = w[i];
+      for (int k = 0; k < BF::N; k++)
+        cst.l[k] = C::fq::REFMONT_TO_CANON[k];
+      BF_SET_BOUND(cst, 1);
+      BF::pack(w, BF::reduce(BF::mul(BF::unpack(w), cst)));
+    }
+#pragma unroll
+    for (int i = 0; i < BF::N32; i++)
+      out[t * BF::N32 + i] = w[i];
   }
 
   // ------------------------------------------------------------------------------------------
@@ -721,7 +729,7 @@ namespace icicle_hip {
   }
 
   template <class C, int MINW>
-  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases_mont, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, const uint32_t* __restrict__ perm, uint32_t ovf_cap, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
+  __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, const uint32_t* __restrict__ perm, uint32_t ovf_cap, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
   {
     // bases_stride: words between the base arrays of consecutive MSMs of a batch (0 = shared bases)
     // perm: thread t < nbk accumulates bucket perm[t] (size-balanced order)
@@ -746,7 +754,7 @@ namespace icicle_hip {
       dst = ovf_part + o;
     }
     const size_t wp = bucket / nb; // window index within the launch = (MSM index) * wpf + target window
-    bases_mont += (wp / wpf) * bases_stride;
+    bases += (wp / wpf) * bases_stride;
     const uint32_t total = count[bucket];
     const uint32_t cnt = min(total - min(total, start), seg);
     const uint32_t* src = sorted + wp * cap + offs[bucket] + start;
@@ -754,7 +762,7 @@ namespace icicle_hip {
     bool empty = true;
     for (uint32_t j = 0; j < cnt; j++) {
       const uint32_t e = src[j];
-      const uint4* p = reinterpret_cast<const uint4*>(bases_mont + (size_t)(e & 0x7fffffffu) * PW);
+      const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)(e & 0x7fffffffu) * PW);
       uint32_t w[PW];
 #pragma unroll
       for (int q = 0; q < PW / 4; q++) {
@@ -765,7 +773,7 @@ namespace icicle_hip {
         w[4 * q + 3] = v.w;
       }
       if (E::words_are_zero(w)) continue; // identity base: contributes nothing (cpu_msm.hpp:282)
-      typename E::Aff a = E::cneg(E::load_mont(w), (e >> 31) != 0);
+      typename E::Aff a = E::cneg(E::load_plain(w), (e >> 31) != 0);
       E::madd(acc, empty, a);
     }
     *dst = E::to_proj(acc, empty);
@@ -809,15 +817,16 @@ namespace icicle_hip {
   // ------------------------------------------------------------------------------------------
   // 5a. per-segment running sums. Segment = m consecutive buckets [k0, k0+m) of one window;
   //     val = sum_{k} (k+1) * B_k  =  tri + k0 * line   (bucket index k carries weight k+1).
+  //     Only segments [seg_lo, seg_lo + nsegr) of every window are reduced (the whole window unless a multi-device
+  //     bucket exchange left this device a slice of the buckets); segval is compact: [window][nsegr].
   template <class C>
-  __global__ __launch_bounds__(64) void k_reduce_segments(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ segval, uint32_t nb, uint32_t m, int wpf)
+  __global__ __launch_bounds__(64) void k_reduce_segments(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ segval, uint32_t nb, uint32_t m, int wpf, uint32_t seg_lo, uint32_t nsegr)
   {
     using E = EC<C>;
-    const uint32_t nseg = nb / m;
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= (size_t)wpf * nseg) return;
-    const size_t wp = t / nseg;
-    const uint32_t seg = t % nseg;
+    if (t >= (size_t)wpf * nsegr) return;
+    const size_t wp = t / nsegr;
+    const uint32_t seg = seg_lo + (uint32_t)(t % nsegr);
     const uint32_t k0 = seg * m;
     const typename E::Proj* b = buckets + wp * nb + k0;
     typename E::Proj line = E::proj_identity(), tri = E::proj_identity();
@@ -979,16 +988,20 @@ namespace icicle_hip {
   }
 
   // sum of n projective points in the reference's canonical layout (multi-GPU partial-result combine)
+  // Block b sums points pts[b*3*N32 + i*stride], i < n (stride in words; gridDim.x = batch: the partials of batch
+  // element b sit `stride` words apart) into out[b*3*N32].
   template <class C>
-  __global__ __launch_bounds__(64) void k_proj_sum(const uint32_t* __restrict__ pts, int n, uint32_t* __restrict__ out)
+  __global__ __launch_bounds__(64) void k_proj_sum(const uint32_t* __restrict__ pts, int n, size_t stride, uint32_t* __restrict__ out)
   {
     using E = EC<C>;
     using F = typename E::F;
     __shared__ typename E::Proj sh[64];
     const int lane = threadIdx.x;
+    pts += (size_t)blockIdx.x * 3 * E::N32;
+    out += (size_t)blockIdx.x * 3 * E::N32;
     typename E::Proj v = E::proj_identity();
     for (int i = lane; i < n; i += 64) {
-      const uint32_t* w = pts + (size_t)i * 3 * E::N32;
+      const uint32_t* w = pts + (size_t)i * stride;
       typename E::Proj p;
       p.x = F::from_canonical(w);
       p.y = F::from_canonical(w + E::N32);
@@ -1012,14 +1025,32 @@ namespace icicle_hip {
   {
     if (n < 0 || !out || (n > 0 && !pts)) return ICICLE_INVALID_ARGUMENT;
     ICICLE_TRY(bind_current_device());
-    k_proj_sum<C><<<1, 64, 0, st>>>((const uint32_t*)pts, n, (uint32_t*)out);
+    k_proj_sum<C><<<1, 64, 0, st>>>((const uint32_t*)pts, n, (size_t)3 * EC<C>::N32, (uint32_t*)out);
     LAUNCH_CHECK("k_proj_sum", st);
     return ICICLE_SUCCESS;
   }
 
+  // dst[i] += src[i] over bucket arrays (multi-device bucket exchange: partial bucket sums of shards / peers)
+  template <class C>
+  __global__ __launch_bounds__(128) void k_bucket_add(typename EC<C>::Proj* __restrict__ dst, const typename EC<C>::Proj* __restrict__ src, size_t n)
+  {
+    using E = EC<C>;
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    dst[t] = E::add(dst[t], src[t]);
+  }
+
+  // Hook between bucket accumulation and bucket reduction (multi-device variant E2, msm_multi.cuh): may replace the
+  // bucket contents with sums over shards / devices, skip this call's reduction, or restrict it to a segment range.
+  template <class C>
+  struct MsmBucketHook {
+    virtual ~MsmBucketHook() = default;
+    virtual icicle_error_t after_accumulate(typename EC<C>::Proj* buckets, size_t tw, uint32_t nb, uint32_t nseg, uint32_t m, hipStream_t st, bool* skip_reduce, uint32_t* seg_lo, uint32_t* nsegr) = 0;
+  };
+
   // ------------------------------------------------------------------------------------------
   template <class C>
-  static icicle_error_t msm_run(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v)
+  static icicle_error_t msm_run_single(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v, MsmBucketHook<C>* hook = nullptr)
   {
     using E = EC<C>;
     using FR = FieldOps<typename C::fr>;
@@ -1107,7 +1138,7 @@ namespace icicle_hip {
     // (wrappers/rust/icicle-core/src/msm/tests.rs:92-254 batches; small MSMs would otherwise leave the
     // GPU idle). BB is bounded by a memory budget and by the grid.y limit.
     const size_t per_msm_bytes = (size_t)pl.nwin * n * 4 + (single_level ? 1 : 2) * (size_t)wpf * cap * 4 + (size_t)wpf * nb * (sizeof(typename E::Proj) + 12) +
-                                 (size_t)wpf * nparts_w * sp.nblk * 8 + (shared ? 0 : npts_one * PW * 4);
+                                 (size_t)wpf * nparts_w * sp.nblk * 8 + (shared || !(cfg->are_points_montgomery_form) ? 0 : npts_one * PW * 4);
     size_t budget = (size_t)48 << 30;
     {
       size_t free_b = 0, total_b = 0;
@@ -1115,6 +1146,7 @@ namespace icicle_hip {
     }
     int BB = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / std::max<size_t>(per_msm_bytes, 1)));
     BB = std::min(BB, std::max(1, 60000 / wpf));
+    if (hook && BB < batch) return ICICLE_INVALID_ARGUMENT; // a bucket exchange needs the whole batch in one launch group
     const size_t TW = (size_t)BB * wpf; // windows per launch
     const size_t nbk = TW * nb;
     const size_t nparts = TW << sp.hb;
@@ -1124,7 +1156,9 @@ namespace icicle_hip {
     const uint32_t ovf_cap = (uint32_t)std::min<size_t>(elems_max / pl.seg + 16, 0x7fffffffu);
 
     TempBuf d_mont, d_dig, d_partA, d_sorted, d_cntA, d_offA, d_bstart, d_count, d_offs, d_cursor, d_buckets, d_seg, d_win, d_ovf, d_ovfpart, d_ovfcnt, d_scansum, d_perm, d_sztab, d_szoff, d_firsts;
-    HIP_TRY(d_mont.alloc((shared ? 1 : (size_t)BB) * npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
+    // bases are gathered where they lie unless they need converting (reference-Montgomery input) or realigning
+    const bool stage_bases = cfg->are_points_montgomery_form || (((uintptr_t)d_bases) & 15) != 0;
+    if (stage_bases) HIP_TRY(d_mont.alloc((shared ? 1 : (size_t)BB) * npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_dig.alloc((size_t)BB * pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
     if (!single_level) HIP_TRY(d_partA.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_sorted.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
@@ -1168,11 +1202,14 @@ namespace icicle_hip {
       const size_t tw = (size_t)bb * wpf;
       const size_t gbk = tw * nb;
       const size_t gparts = tw << sp.hb;
-      if (b0 == 0 || !shared) {
-        const uint32_t* src = d_bases + (shared ? 0 : (size_t)b0 * npts_one * PW);
-        const size_t ncoord = (shared ? 1 : (size_t)bb) * npts_one * 2;
-        k_bases_to_mont<C><<<dim3((unsigned)((ncoord + 255) / 256)), 256, 0, st>>>(src, d_mont.as<uint32_t>(), ncoord, cfg->are_points_montgomery_form);
-        LAUNCH_CHECK("k_bases_to_mont", st);
+      const uint32_t* acc_bases = d_bases + (shared ? 0 : (size_t)b0 * npts_one * PW);
+      if (stage_bases) {
+        if (b0 == 0 || !shared) {
+          const size_t ncoord = (shared ? 1 : (size_t)bb) * npts_one * 2 * (E::N32 / FieldOps<typename C::fq>::N32);
+          k_bases_stage<C><<<dim3((unsigned)((ncoord + 255) / 256)), 256, 0, st>>>(acc_bases, d_mont.as<uint32_t>(), ncoord, cfg->are_points_montgomery_form);
+          LAUNCH_CHECK("k_bases_stage", st);
+        }
+        acc_bases = d_mont.as<uint32_t>();
       }
       const uint32_t* sc = d_scalars + (size_t)b0 * n * FR::N32;
       const size_t nscal = (size_t)bb * n;
@@ -1242,7 +1279,7 @@ namespace icicle_hip {
         const size_t nthreads_acc = gbk + ovf_cap;
         const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
         const size_t bstride = shared ? 0 : npts_one * PW;
-#define ACC_ARGS d_mont.as<uint32_t>(), sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), d_perm.as<uint32_t>(), ovf_cap, nb, gbk, cap, pl.seg, wpf, bstride
+#define ACC_ARGS acc_bases, sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), d_perm.as<uint32_t>(), ovf_cap, nb, gbk, cap, pl.seg, wpf, bstride
         if constexpr (BIGPT) {
           if constexpr (sizeof(typename E::XYZZ) <= 288) {
             if (minw >= 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
@@ -1262,10 +1299,18 @@ namespace icicle_hip {
       KernelTimer::end(0, st);
       k_fold_overflow<C><<<std::min<uint32_t>(ovf_cap, 4096), 64, 0, st>>>(buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_firsts.as<uint32_t>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
       LAUNCH_CHECK("k_fold_overflow", st);
-      const size_t nsg = tw * nseg;
-      k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(buckets, d_seg.as<typename E::Proj>(), nb, m, (int)tw);
-      LAUNCH_CHECK("k_reduce_segments", st);
-      k_reduce_window<C><<<(unsigned)tw, ReduceWindowLanes<C>::value, 0, st>>>(d_seg.as<typename E::Proj>(), d_win.as<typename E::Proj>(), nseg);
+      uint32_t seg_lo = 0, nsegr = nseg;
+      if (hook) {
+        bool skip = false;
+        ICICLE_TRY(hook->after_accumulate(buckets, tw, nb, nseg, m, st, &skip, &seg_lo, &nsegr));
+        if (skip) continue; // another shard of this device (or the exchange step) produces the result
+      }
+      const size_t nsg = tw * nsegr;
+      if (nsg) {
+        k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(buckets, d_seg.as<typename E::Proj>(), nb, m, (int)tw, seg_lo, nsegr);
+        LAUNCH_CHECK("k_reduce_segments", st);
+      }
+      k_reduce_window<C><<<(unsigned)tw, ReduceWindowLanes<C>::value, 0, st>>>(d_seg.as<typename E::Proj>(), d_win.as<typename E::Proj>(), nsegr);
       LAUNCH_CHECK("k_reduce_window", st);
       k_final<C><<<bb, 128, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c);
       LAUNCH_CHECK("k_final", st);
@@ -1280,6 +1325,10 @@ namespace icicle_hip {
     }
     return ICICLE_SUCCESS;
   }
+
+} // namespace icicle_hip
+#include "msm_multi.cuh"
+namespace icicle_hip {
 
   template <class C>
   static icicle_error_t msm_precompute_run(const void* in_v, int n, const icicle_msm_config_t* cfg, void* out_v)

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <dlfcn.h>
 #include <optional>
 
 namespace icicle_hip {
@@ -156,6 +157,58 @@ namespace icicle_hip {
       a->base = nullptr;
       a->cap = 0;
     }
+  }
+
+  // ---- RCCL loader ------------------------------------------------------------------------------
+  const RcclApi* rccl_api()
+  {
+    static RcclApi api;
+    static const bool ok = []() {
+      void* h = nullptr;
+      // prefer a copy already in the process (PyTorch's), then the ROCm one
+      for (const char* name : {"librccl.so", "librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        if (h) break;
+      }
+      if (!h)
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+          h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+          if (h) break;
+        }
+      if (!h) return false;
+      auto sym = [&](const char* n) { return dlsym(h, n); };
+      api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+      api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+      api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+      api.Send = (decltype(api.Send))sym("ncclSend");
+      api.Recv = (decltype(api.Recv))sym("ncclRecv");
+      api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+      api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+      return api.CommInitAll && api.AllGather && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
+    }();
+    return ok ? &api : nullptr;
+  }
+
+  icicle_error_t rccl_comms_for(const std::vector<int>& devs, std::vector<void*>& comms)
+  {
+    static std::mutex mtx;
+    static std::map<std::vector<int>, std::vector<void*>> cache;
+    const RcclApi* api = rccl_api();
+    if (!api) return ICICLE_API_NOT_IMPLEMENTED;
+    std::lock_guard<std::mutex> g(mtx);
+    auto it = cache.find(devs);
+    if (it == cache.end()) {
+      std::vector<void*> c(devs.size(), nullptr);
+      const int rc = api->CommInitAll(c.data(), (int)devs.size(), devs.data());
+      if (rc != 0) {
+        fprintf(stderr, "[icicle_hip] ncclCommInitAll failed: %s\n", api->GetErrorString ? api->GetErrorString(rc) : "?");
+        return ICICLE_INVALID_DEVICE;
+      }
+      it = cache.emplace(devs, std::move(c)).first;
+    }
+    comms = it->second;
+    return ICICLE_SUCCESS;
   }
 
   // ---- kernel timing ---------------------------------------------------------------------------

@@ -14,7 +14,6 @@ The reference has NO multi-device mechanism beyond "one host thread per device"
 Both functions also run with the gloo backend on CPU tensors for the exchange step (the local
 compute is injected), which is how tests/test_dist_cpu.py covers the N > 1 control flow without GPUs.
 """
-import numpy as np
 
 
 def shard_range(n: int, rank: int, world: int):
@@ -137,17 +136,3 @@ def _gpu_compute(field: str):
         return mat
 
     return local_ntt, twiddle
-
-
-def combine_partials_host(curve: str, partials: np.ndarray):
-    """Host-side definition of the combine step (used by the gloo CPU tests): sum of projective
-    partials via the pure-Python oracle. partials: [world, 3*L] uint32."""
-    from oracle import pyref
-
-    C = pyref.CURVES[curve]
-    L = C.limbs_q
-    acc = pyref.INF
-    for row in partials:
-        x, y, z = (sum(int(v) << (32 * k) for k, v in enumerate(row[i * L:(i + 1) * L])) for i in range(3))
-        acc = pyref.ec_add(C, acc, pyref.proj_to_affine(C, x, y, z))
-    return acc

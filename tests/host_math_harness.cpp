@@ -52,15 +52,12 @@ namespace {
     using E = EC<C>;
     using F = typename E::F;
     constexpr int N32 = E::N32;
+    // Montgomery-form affine point (cold kernels: precompute, generator, complete adds)
     auto load = [&](const uint32_t* w) {
       typename E::Aff a;
       a.x = F::from_canonical(w);
       a.y = F::from_canonical(w + N32);
-      // mimic the packed-Montgomery HBM copy: reduce + pack + unpack
-      uint32_t tmp[2 * N32];
-      F::pack(tmp, F::reduce(a.x));
-      F::pack(tmp + N32, F::reduce(a.y));
-      return E::load_mont(tmp);
+      return a;
     };
     switch (op) {
     case 0: { // XYZZ accumulate all points (aux[i]&1 = negate), output projective canonical
@@ -69,7 +66,8 @@ namespace {
       for (int i = 0; i < n; i++) {
         const uint32_t* w = pts + (size_t)i * 2 * N32;
         if (E::words_are_zero(w)) continue;
-        auto a = E::cneg(load(w), aux && (aux[i] & 1));
+        // the hot loop consumes the canonical words exactly as they lie in HBM (ec.cuh scaling convention)
+        auto a = E::cneg(E::load_plain(w), aux && (aux[i] & 1));
         E::madd(acc, empty, a);
       }
       E::store_proj_canonical(out, E::to_proj(acc, empty));

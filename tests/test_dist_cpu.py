@@ -31,7 +31,7 @@ def _worker(rank, world, port, q):
     from icicle_amd import dist as D
     from oracle import pyref
     from tests import oracle_c as oc
-    from tests.util import cached_points, points_to_array, rand_scalars, to_words
+    from tests.util import cached_points, combine_partials_host, points_to_array, rand_scalars, to_words
 
     C = pyref.BN254
     n = 101  # not divisible by world: exercises the remainder logic
@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
     part = oc.msm("bn254", to_words(sc[lo:hi], 8), points_to_array(C, pts[lo:hi]), c=6)
     partial = torch.from_numpy(part.view(np.int32).copy())
     gathered = D.allgather_partials(partial, world, dist)
-    full = D.combine_partials_host("bn254", gathered.numpy().view(np.uint32))
+    full = combine_partials_host("bn254", gathered.numpy().view(np.uint32))
     exp = pyref.msm_naive(C, sc, pts)
     # batch sharding of the NTT: rows are disjoint and cover the batch
     rows = D.ntt_batch_shard(7, rank, world)

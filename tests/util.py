@@ -50,3 +50,15 @@ def cached_points(curve: pyref.Curve, n, k0=987654321):
         have = pyref.gen_points(curve, n, k0)
         _POINT_CACHE[key] = have
     return have[:n]
+
+
+def combine_partials_host(curve: str, partials: np.ndarray):
+    """Host-side DEFINITION of the multi-GPU combine step (sum of projective partial results) with the
+    pure-Python oracle; the product does this with k_proj_sum on the GPU. partials: [world, 3*L] uint32."""
+    C = pyref.CURVES[curve]
+    L = C.limbs_q
+    acc = pyref.INF
+    for row in partials:
+        x, y, z = (sum(int(v) << (32 * k) for k, v in enumerate(row[i * L:(i + 1) * L])) for i in range(3))
+        acc = pyref.ec_add(C, acc, pyref.proj_to_affine(C, x, y, z))
+    return acc
