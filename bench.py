@@ -10,10 +10,13 @@ one 2^26-term BN254 MSM per rank (weak scaling: the N shards form one 2^26*N-ter
 results are all-gathered over RCCL and summed on every rank). Timed region: barrier + synchronize on
 both sides, max over ranks. One JSON line on rank 0.
 
+--scaling strong cuts ONE 2^26 MSM over the N GPUs instead (2^26/N pairs per rank, same exchange).
+
 Extra objects: "roofline" (dominant kernel = MSM bucket accumulation, duration from hipEvents on the
-launch stream, algorithmic bytes per SURVEY.md 8(d)), "cpu_baseline" (the reference CPU backend from
-oracle/_ref timed on this box's host cores on a bounded sample), "ntt" (secondary metric with its
-own roofline/cpu_baseline).  --size-log2 / --ntt-log2 shrink the workload for quick checks; the
+launch stream, algorithmic bytes per SURVEY.md 8(d); its ALU and gather roofs are measured in the same
+run), "cpu_baseline" (the reference CPU backend from oracle/_ref timed on this box's host cores -- on
+the full workload when the host has >= 64 cores), "ntt" (secondary metric with its own
+roofline/cpu_baseline).  --size-log2 / --ntt-log2 shrink the workload for quick checks; the
 JSON then names the reduced workload (never reported as the headline config).
 """
 import argparse
@@ -44,8 +47,10 @@ def parse():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--msm-c", type=int, default=0, help="force the MSM window size (0 = backend default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-msm-log2", type=int, default=20)
-    ap.add_argument("--cpu-ntt-log2", type=int, default=20)
+    ap.add_argument("--cpu-msm-log2", type=int, default=0, help="CPU baseline MSM size; 0 = the full workload when the host has >= 64 cores, else 2^20")
+    ap.add_argument("--cpu-ntt-log2", type=int, default=0, help="CPU baseline NTT size; 0 = the full size when the host has >= 64 cores, else 2^20")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: one 2^size MSM per GPU (the N shards form one 2^size*N MSM); strong: ONE 2^size MSM cut over the N GPUs")
     return ap.parse_args()
 
 
@@ -95,10 +100,15 @@ def main():
         return float(t.item())
 
     # ---------------- MSM: synthetic inputs resident in HBM ----------------
-    n = 1 << args.size_log2
+    strong = args.scaling == "strong"
+    if strong:  # ONE 2^size_log2 MSM; rank r holds pairs [lo, hi) of it (north_star: "large MSMs shard bases across the GPUs")
+        lo, hi = D.shard_range(1 << args.size_log2, rank, world)
+        n, k0 = hi - lo, 1 + lo
+    else:
+        n, k0 = 1 << args.size_log2, 1 + rank * (1 << 40)
     bases = torch.empty((n, 16), dtype=torch.int32, device=dev)
     # distinct points (k0 + i)G, a different range per rank; generated on the GPU
-    check(lib.bn254_hip_generate_affine_points(bases.data_ptr(), n, 1 + rank * (1 << 40), True, None), "generate")
+    check(lib.bn254_hip_generate_affine_points(bases.data_ptr(), n, k0, True, None), "generate")
     scalars = synth_scalars(n, dev, 1234 + rank)
     torch.cuda.synchronize()
 
@@ -123,7 +133,8 @@ def main():
     msm_ms = dt / args.steps * 1e3
     acc_ms = tot.value / max(1, cnt.value)
     msm_bytes = n * (32 + 64) + 96  # N*sizeof(scalar) + N*sizeof(affine) + sizeof(projective)
-    units_per_step = world * (n / float(1 << 26))  # in 2^26-term MSMs
+    total_terms = (1 << args.size_log2) if strong else world * n
+    units_per_step = total_terms / float(1 << 26)  # in 2^26-term MSMs
     value = units_per_step * args.steps / dt
     roofline = {
         "bound": "hbm", "kernel": "k_accumulate<bn254_g1>", "achieved": msm_bytes / (acc_ms * 1e-3) / 1e9,
@@ -132,36 +143,49 @@ def main():
         "note": "MSM is integer-ALU bound (v_mad_u64_u32), not HBM bound; see DESIGN.md and 'alu'",
     }
     # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (bench.py cannot
-    # run rocprofv3 on itself); only attached when the workload matches the profiled one
+    # run rocprofv3 on itself); only attached when the workload matches the profiled one. FETCH_SIZE is calibrated on
+    # a kernel with the same access pattern and a known byte count (icicle_hip_ubench_gather under the same counter).
     pmc = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-    except Exception:
-        pmc = {}
-    if args.size_log2 == 26 and args.msm_c == 0 and "msm_bn254_2^26" in pmc:
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc = json.load(f)
+            pmc["_file"] = name
+            break
+        except Exception:
+            pmc = {}
+    if args.size_log2 == 26 and args.msm_c == 0 and not strong and "msm_bn254_2^26" in pmc:
         m = pmc["msm_bn254_2^26"]
         roofline["traffic"] = (m["fetch_size_kb_raw"] * m["fetch_correction"] + m["write_size_kb"]) * 1024 / 1e9
-        roofline["traffic_unit"] = "GB per launch (FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)"
-    # secondary: integer-ALU view. mixed adds per MSM = n * windows; 8M + 2S field operations each
+        roofline["traffic_unit"] = f"GB per launch (FETCH_SIZE x calibration + WRITE_SIZE, profiles/{pmc['_file']})"
+    # secondary: integer-ALU view. mixed adds per MSM = n * windows; 8M + 2S field operations each. The roof is
+    # measured in this run: the same ec.cuh mixed add with every operand in registers (no memory traffic at all).
     pc, pw = ctypes.c_int(), ctypes.c_int()
     pcfg = MSMConfig.default()
     pcfg.c = args.msm_c
     check(lib.icicle_hip_msm_plan(n, 254, ctypes.byref(pcfg), ctypes.byref(pc), ctypes.byref(pw)), "msm_plan")
     madds = n * pw.value
+    rate = ctypes.c_double()
+    check(lib.icicle_hip_ubench_mixed_add(0, ctypes.byref(rate)), "ubench_mixed_add")
     roofline["alu"] = {"window_bits": pc.value, "windows": pw.value, "mixed_adds": madds,
-                       "mixed_adds_per_s": madds / (acc_ms * 1e-3)}
-    # every mixed add gathers one 64-byte point at a random address; a pure random-64-byte-gather microbenchmark
-    # reaches 1.49e10 gathers/s on this chip (profiles/r01_alu_ubench.txt), the second roof this kernel sits under
-    roofline["gather"] = {"gathers_per_s": madds / (acc_ms * 1e-3), "measured_ceiling": 1.49e10,
-                          "frac": madds / (acc_ms * 1e-3) / 1.49e10, "unit": "random 64-byte gathers/s"}
+                       "mixed_adds_per_s": madds / (acc_ms * 1e-3), "roof": rate.value,
+                       "frac": madds / (acc_ms * 1e-3) / rate.value,
+                       "roof_is": "XYZZ mixed adds/s, operands in registers, measured in this run (icicle_hip_ubench_mixed_add)"}
+    # every mixed add gathers one 64-byte point at a random address of the bases array: ceiling of that access pattern
+    # over a region of the same size, measured in this run
+    check(lib.icicle_hip_ubench_gather(max(64, n * 64), 1 << 27, ctypes.byref(rate)), "ubench_gather")
+    roofline["gather"] = {"gathers_per_s": madds / (acc_ms * 1e-3), "measured_ceiling": rate.value,
+                          "frac": madds / (acc_ms * 1e-3) / rate.value,
+                          "unit": f"random 64-byte gathers/s over {n * 64 / 2**30:.2f} GiB, measured in this run"}
+    check(lib.icicle_hip_release_workspace(), "release_workspace")
 
     out = {
         "metric": "bn254_msm_2^26_per_sec", "value": value, "unit": "MSM/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": msm_ms, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": msm_ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u32x8 (254-bit integer field, 29-bit-limb Montgomery)", "data": "synthetic",
-        "config": {"workload": f"BN254 G1 MSM, 2^{args.size_log2} uniform scalars x 2^{args.size_log2} distinct affine "
-                               f"bases per GPU, batch 1, inputs resident in HBM, precompute_factor 1",
+        "config": {"workload": (f"BN254 G1 MSM, ONE 2^{args.size_log2}-term MSM cut over {world} GPU(s), " if strong else
+                                f"BN254 G1 MSM, 2^{args.size_log2} uniform scalars x 2^{args.size_log2} distinct affine bases per GPU, ")
+                               + "batch 1, inputs resident in HBM, precompute_factor 1",
                    "sharding": "bases/scalars sharded per rank; RCCL all_gather of partial sums + projective add"},
         "roofline": roofline,
     }
@@ -265,48 +289,64 @@ def main():
             watchdog.cancel()
 
     # ---------------- CPU baseline: the reference CPU backend on this box's host cores ----------------
+    # On a host with >= 64 cores (the GPU boxes have 256) the baseline is timed on the REAL workload: the full 2^26 MSM
+    # (about half a minute) and full-size NTT rows; on small hosts a 2^20 sample is timed and the JSON says so.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import ref
 
             cores = os.cpu_count()
+            big_host = cores >= 64
             refc = ref.RefCurve("bn254")
-            cn = 1 << args.cpu_msm_log2
-            hb = bases[:cn].cpu().numpy().view(np.uint32)
-            hs = scalars[:cn].cpu().numpy().view(np.uint32)
+            clog = args.cpu_msm_log2 or (args.size_log2 if big_host else min(20, args.size_log2))
+            cn = min(n, 1 << clog)
+            hb = np.ascontiguousarray(bases[:cn].cpu().numpy().view(np.uint32))
+            hs = np.ascontiguousarray(scalars[:cn].cpu().numpy().view(np.uint32))
             t0 = time.perf_counter()
-            exp = refc.msm(np.ascontiguousarray(hs), np.ascontiguousarray(hb))
+            exp = refc.msm(hs, hb)
             tc = time.perf_counter() - t0
-            # parity of the sample on the GPU path too
-            got = M.msm("bn254", np.ascontiguousarray(hs), np.ascontiguousarray(hb))
+            # parity on the very inputs the CPU was timed on (the full bench inputs when cn == n)
+            got = res.cpu().numpy().view(np.uint32).reshape(1, -1) if cn == n else M.msm("bn254", hs, hb)
             parity = bool(np.array_equal(refc.to_affine(got), refc.to_affine(exp)))
+            full = cn == n and args.size_log2 == 26
             out["cpu_baseline"] = {
                 "value": (cn / float(1 << 26)) / tc, "unit": "MSM/s", "cores": cores, "kind": "reference",
-                "sample": f"one BN254 MSM of 2^{args.cpu_msm_log2} terms (first 2^{args.cpu_msm_log2} of the bench inputs) "
-                          f"took {tc:.2f} s on the reference CPU backend (oracle/_ref, Taskflow shim); value = that rate "
-                          f"expressed in 2^26-term MSMs/s assuming linear scaling",
-                "parity_with_gpu_on_sample": parity,
+                "sample": (f"the bench workload itself: one BN254 MSM of 2^{args.size_log2} terms took {tc:.2f} s on the reference CPU backend "
+                           f"(oracle/_ref, Taskflow shim, {cores} threads)" if cn == n else
+                           f"one BN254 MSM of 2^{clog} terms (a prefix of the bench inputs) took {tc:.2f} s on the reference CPU backend; value = "
+                           f"that rate in 2^26-term MSMs/s assuming linear scaling (Pippenger is sub-linear per point, so this UNDERSTATES the CPU)"),
+                "timed_on_full_workload": full, "parity_with_gpu_on_sample": parity,
             }
+            del hb, hs
             if not args.no_ntt:
                 rf = ref.RefNttField("babybear")
-                cl = args.cpu_ntt_log2
+                cl = args.cpu_ntt_log2 or (args.ntt_log2 if big_host else min(20, args.ntt_log2))
                 rf.init_domain(rf.get_root_of_unity(1 << cl))
-                hx = np.ascontiguousarray(x[0, : 1 << cl].cpu().numpy().view(np.uint32))
-                hx4 = np.tile(hx, 4)
-                rf.ntt(hx4, 1 << cl, 0, batch=4)
+                crow = min(rows, 4)
+                hx = np.ascontiguousarray(x[:crow, : 1 << cl].cpu().numpy().view(np.uint32)).reshape(-1)
                 t0 = time.perf_counter()
-                rf.ntt(hx4, 1 << cl, 0, batch=4)
+                cy = rf.ntt(hx, 1 << cl, 0, batch=crow)
                 tn = time.perf_counter() - t0
+                if tn * rows / crow < 40.0 and crow < rows and cl == args.ntt_log2:  # affordable: time the whole batch
+                    crow = rows
+                    hx = np.ascontiguousarray(x.cpu().numpy().view(np.uint32)).reshape(-1)
+                    t0 = time.perf_counter()
+                    cy = rf.ntt(hx, 1 << cl, 0, batch=crow)
+                    tn = time.perf_counter() - t0
+                scale = 1.0 if cl == args.ntt_log2 else ((1 << cl) * cl) / ((1 << args.ntt_log2) * args.ntt_log2)
+                ntt_parity = None
+                if cl == args.ntt_log2:
+                    ntt_parity = bool(np.array_equal(cy.reshape(crow, -1), y[:crow].cpu().numpy().view(np.uint32)))
                 out["ntt"]["cpu_baseline"] = {
-                    "value": 4 / tn * ((1 << cl) * cl) / ((1 << args.ntt_log2) * args.ntt_log2), "unit": "NTT/s",
-                    "cores": cores, "kind": "reference",
-                    "sample": f"4 forward BabyBear NTTs of 2^{cl} took {tn * 1e3:.1f} ms on the reference CPU backend; "
-                              f"scaled by N log N to 2^{args.ntt_log2}",
+                    "value": crow / tn * scale, "unit": "NTT/s", "cores": cores, "kind": "reference",
+                    "sample": (f"{crow} forward BabyBear NTTs of 2^{cl} (rows of the bench input) took {tn:.2f} s on the reference CPU backend"
+                               + ("" if cl == args.ntt_log2 else f"; scaled by N log N to 2^{args.ntt_log2}")),
+                    "timed_on_full_size": cl == args.ntt_log2, "parity_with_gpu_on_sample": ntt_parity,
                 }
                 rf.release_domain()
         except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
-            out["cpu_baseline"] = {"value": None, "unit": "MSM/s", "cores": os.cpu_count(), "kind": "reference",
-                                   "sample": f"failed: {e!r}"}
+            out.setdefault("cpu_baseline", {"value": None, "unit": "MSM/s", "cores": os.cpu_count(), "kind": "reference",
+                                            "sample": f"failed: {e!r}"})
 
     if rank == 0:
         print(json.dumps(out))

@@ -172,7 +172,8 @@ API_SYMBOLS = (
     + [f"{pre}{c}_ecntt" for pre in ("", "icicle_hip_") for c in CURVES]
     + [f"{pre}{f}_{op}" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + SCALAR_NTT_FIELDS
        for op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "bit_reverse")]
-    + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device"]
+    + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
+       "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes"]
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
                                                           "get_root_of_unity_from_domain")]
@@ -250,3 +251,6 @@ for _n in API_SYMBOLS:
 lib.icicle_hip_kernel_timing.argtypes = [ctypes.c_int, ctypes.c_bool, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
 lib.icicle_hip_enable_kernel_timing.argtypes = [ctypes.c_bool]
 lib.icicle_hip_msm_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+lib.icicle_hip_ubench_mixed_add.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+lib.icicle_hip_ubench_gather.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double)]
+lib.icicle_hip_workspace_bytes.argtypes = [ctypes.POINTER(ctypes.c_size_t)]

@@ -103,7 +103,8 @@ namespace icicle_hip {
   };
   Arena* arena_acquire(size_t bytes, hipStream_t st); // nullptr on allocation failure
   void arena_release(Arena* a, hipStream_t st);
-  void arena_trim(int device); // frees all idle arenas of a device (tests / release_domain)
+  void arena_trim(int device); // frees all idle arenas of a device (icicle_hip_release_workspace, release_domain)
+  size_t arena_cached_bytes(int device);
 
   // One temporary = one arena lease (released, i.e. made reusable in stream order, on destruction).
   class TempBuf

@@ -1,0 +1,148 @@
+// Diagnostics exported next to the product entry points so that bench.py can measure the roofs of the dominant MSM
+// kernel IN THE SAME RUN as the kernel itself (no hard-coded ceilings):
+//   icicle_hip_ubench_mixed_add  XYZZ mixed adds per second with every operand in registers -- the integer-ALU roof
+//                                of k_accumulate (same ec.cuh code, same launch bounds, no memory traffic)
+//   icicle_hip_ubench_gather     random 64-byte gathers per second (4 x 16 B loads per lane, the access pattern of
+//                                k_accumulate's base fetch) over a region of the given size; also the known-byte-count
+//                                kernel the FETCH_SIZE counter is calibrated on (tools/pmc_traffic.sh)
+// Neither touches user data. tools/ubench/msm_ubench.hip holds the wider design-decision sweeps.
+#include "common.h"
+#include "ec.cuh"
+
+namespace icicle_hip {
+
+  __device__ __forceinline__ uint32_t diag_mix(uint32_t x)
+  {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+  }
+
+  template <class C>
+  __global__ __launch_bounds__(128, (EC<C>::F::N <= 9 ? 3 : 2)) void k_diag_madd(uint32_t* __restrict__ out, int iters, uint32_t seed)
+  {
+    using E = EC<C>;
+    using F = typename E::F;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    auto seed_fe = [&](uint32_t s) {
+      typename F::fe r;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) {
+        s = diag_mix(s + i);
+        r.l[i] = s & RB_MASK;
+      }
+      r.l[F::N - 1] &= 0xfffff; // well below p
+      BF_SET_BOUND(r, 1);
+      return r;
+    };
+    typename E::XYZZ acc;
+    acc.x = seed_fe(t + seed), acc.y = seed_fe(t * 3 + seed), acc.zz = seed_fe(t + 5), acc.zzz = seed_fe(t + 9);
+    bool empty = false;
+    typename E::Aff p;
+    p.x = seed_fe(t + 11), p.y = seed_fe(t + 13);
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+      p.x.l[0] = (p.x.l[0] + 0x1234567u) & RB_MASK; // a different operand every step
+      p.y.l[1] ^= (uint32_t)it;
+      E::madd(acc, empty, E::cneg(p, (it & 1) != 0));
+    }
+    uint32_t r = empty;
+#pragma unroll
+    for (int i = 0; i < F::N; i++)
+      r ^= acc.x.l[i] ^ acc.y.l[i] ^ acc.zz.l[i] ^ acc.zzz.l[i];
+    out[t] = r;
+  }
+
+  __global__ __launch_bounds__(256) void k_diag_gather(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t region_pts, uint32_t per_thread, uint32_t seed)
+  {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 acc = {0, 0, 0, 0};
+    uint32_t s = diag_mix(t * 2654435761u + seed);
+    for (uint32_t i = 0; i < per_thread; i++) {
+      s = diag_mix(s + 0x9e3779b9u);
+      const uint4* p = in + (size_t)(((uint64_t)s * region_pts) >> 32) * 4;
+      const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+      acc.x ^= a.x ^ b.y ^ c.z ^ d.w;
+      acc.y += a.y + b.x;
+      acc.z ^= c.x;
+      acc.w += d.x;
+    }
+    out[t] = acc;
+  }
+
+  template <class C>
+  static icicle_error_t madd_bench(double* rate)
+  {
+    ICICLE_TRY(bind_current_device());
+    const int blocks = 256 * 24, iters = 256;
+    TempBuf o;
+    HIP_TRY(o.alloc((size_t)blocks * 128 * 4, nullptr), ICICLE_ALLOCATION_FAILED);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipEventCreate(&e1), ICICLE_INVALID_ARGUMENT);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+      (void)hipEventRecord(e0, nullptr);
+      k_diag_madd<C><<<blocks, 128>>>(o.as<uint32_t>(), iters, 7 + rep);
+      (void)hipEventRecord(e1, nullptr);
+      HIP_TRY(hipEventSynchronize(e1), ICICLE_SYNCHRONIZATION_FAILED);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *rate = (double)blocks * 128 * iters / (best * 1e-3);
+    return ICICLE_SUCCESS;
+  }
+
+} // namespace icicle_hip
+
+using namespace icicle_hip;
+
+extern "C" icicle_error_t icicle_hip_ubench_mixed_add(int curve, double* adds_per_second)
+{
+  if (!adds_per_second) return ICICLE_INVALID_POINTER;
+  try {
+    if (curve == 0) return madd_bench<bn254_g1>(adds_per_second);
+    if (curve == 1) return madd_bench<bls12_381_g1>(adds_per_second);
+  } catch (...) {
+  }
+  return ICICLE_INVALID_ARGUMENT;
+}
+
+extern "C" icicle_error_t icicle_hip_ubench_gather(uint64_t region_bytes, uint64_t gathers, double* gathers_per_second)
+{
+  if (!gathers_per_second || region_bytes < 64 || gathers == 0) return ICICLE_INVALID_ARGUMENT;
+  try {
+    ICICLE_TRY(bind_current_device());
+    const int blocks = 256 * 8;
+    const uint32_t per_thread = (uint32_t)std::max<uint64_t>(1, gathers / ((uint64_t)blocks * 256));
+    TempBuf region, o;
+    HIP_TRY(region.alloc(region_bytes, nullptr), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(o.alloc((size_t)blocks * 256 * 16, nullptr), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMemsetAsync(region.ptr(), 1, region_bytes, nullptr), ICICLE_COPY_FAILED);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipEventCreate(&e1), ICICLE_INVALID_ARGUMENT);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+      (void)hipEventRecord(e0, nullptr);
+      k_diag_gather<<<blocks, 256>>>(region.as<uint4>(), o.as<uint4>(), (uint32_t)(region_bytes / 64), per_thread, 3 + rep);
+      (void)hipEventRecord(e1, nullptr);
+      HIP_TRY(hipEventSynchronize(e1), ICICLE_SYNCHRONIZATION_FAILED);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gathers_per_second = (double)blocks * 256 * per_thread / (best * 1e-3);
+    return ICICLE_SUCCESS;
+  } catch (...) {
+    return ICICLE_INVALID_ARGUMENT;
+  }
+}

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "smallfield.cuh"
 #include "ntt_plan.h"
+#include <thread>
 #include <algorithm>
 #include <cmath>
 
@@ -672,7 +673,9 @@ namespace icicle_hip {
     k_gen_twiddles<PR><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(tw, S::to_mont(r), n);
     LAUNCH_CHECK("k_gen_twiddles", st);
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
-    if (!cfg->is_async) HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    // always synchronous: the table is published to every stream of this device the moment init returns (an ntt()
+    // on another stream must never read it half-written); domain init is a one-time operation
+    HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
     dom.tw = tw;
     dom.log_max = log_max;
     dom.root = r;
@@ -690,6 +693,7 @@ namespace icicle_hip {
       if (it->second.tw) {
         (void)hipDeviceSynchronize();
         (void)hipFree(it->second.tw);
+        arena_trim(dev); // the NTT work buffers cached for this domain's sizes go with it
       }
       DomainStore<PR>::map().erase(it);
     }
@@ -766,10 +770,112 @@ namespace icicle_hip {
   }
 
   template <class PR>
+  static icicle_error_t ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, uint32_t lanes);
+
+  // Batched NTT over several devices behind the unchanged <field>_ntt symbol: config.ext {"hip_num_devices": G} cuts
+  // the batch into G contiguous row shards (rows are independent transforms: no collective) and runs
+  // them on min(G, visible GPUs) devices, one host thread + stream per device; the twiddle domain is brought up on a
+  // device the first time it is used (same root as the calling device's). Row-major batches only; synchronous.
+  template <class PR>
+  static icicle_error_t ntt_multi_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, uint32_t lanes, int G)
+  {
+    if (size <= 0 || !input || !output) return ICICLE_INVALID_ARGUMENT;
+    const int batch = std::max(1, cfg->batch_size);
+    ICICLE_TRY(bind_current_device());
+    const int home = current_device_id();
+    HIP_TRY(hipStreamSynchronize((hipStream_t)cfg->stream), ICICLE_SYNCHRONIZATION_FAILED);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev), ICICLE_INVALID_DEVICE);
+    const int P = std::max(1, std::min(G, ndev));
+    uint32_t root = 0;
+    {
+      std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
+      auto it = DomainStore<PR>::map().find(home);
+      if (it == DomainStore<PR>::map().end() || !it->second.tw) return ICICLE_INVALID_ARGUMENT; // domain not initialised
+      root = it->second.root;
+    }
+    const size_t row_words = (size_t)size * lanes;
+    icicle_ntt_config_u32_t sub = *cfg;
+    sub.ext = nullptr;
+    sub.are_inputs_on_device = sub.are_outputs_on_device = true;
+    sub.is_async = true;
+    std::vector<icicle_error_t> rcs(P, ICICLE_SUCCESS);
+    auto worker = [&](int p) -> icicle_error_t {
+      const int dev = (home + p) % ndev;
+      ICICLE_TRY(icicle_hip_set_device(dev));
+      hipStream_t st = nullptr;
+      HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
+      icicle_error_t rc = [&]() -> icicle_error_t {
+        if (dev != home) { // silent success if this device already has the domain
+          icicle_ntt_init_domain_config_t ic{st, false, nullptr};
+          ICICLE_TRY(ntt_init_domain_run<PR>(&root, &ic));
+        }
+        icicle_ntt_config_u32_t c2 = sub;
+        c2.stream = st;
+        for (int g = p; g < G; g += P) {
+          const int base = batch / G, rem = batch % G;
+          const int lo = g * base + std::min(g, rem), rows = base + (g < rem ? 1 : 0);
+          if (rows == 0) continue;
+          const size_t words = (size_t)rows * row_words, off = (size_t)lo * row_words;
+          TempBuf d_in, d_out;
+          const uint32_t* src = input + off;
+          uint32_t* dst = output + off;
+          const bool in_direct = cfg->are_inputs_on_device && dev == home, out_direct = cfg->are_outputs_on_device && dev == home;
+          if (!in_direct) {
+            HIP_TRY(d_in.alloc(words * 4, st), ICICLE_ALLOCATION_FAILED);
+            HIP_TRY(hipMemcpyAsync(d_in.ptr(), src, words * 4, hipMemcpyDefault, st), ICICLE_COPY_FAILED);
+            src = d_in.as<uint32_t>();
+          }
+          uint32_t* o = dst;
+          if (!out_direct) {
+            if (!in_direct) {
+              o = d_in.as<uint32_t>(); // in place on the staged copy
+            } else {
+              HIP_TRY(d_out.alloc(words * 4, st), ICICLE_ALLOCATION_FAILED);
+              o = d_out.as<uint32_t>();
+            }
+          }
+          c2.batch_size = rows;
+          ICICLE_TRY(ntt_run<PR>(src, size, dir, &c2, o, lanes));
+          if (!out_direct) HIP_TRY(hipMemcpyAsync(dst, o, words * 4, hipMemcpyDefault, st), ICICLE_COPY_FAILED);
+          HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+        }
+        return ICICLE_SUCCESS;
+      }();
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+      return rc;
+    };
+    if (P == 1) {
+      rcs[0] = worker(0);
+    } else {
+      std::vector<std::thread> th;
+      for (int p = 0; p < P; p++)
+        th.emplace_back([&, p]() {
+          try {
+            rcs[p] = worker(p);
+          } catch (...) {
+            rcs[p] = ICICLE_INVALID_ARGUMENT;
+          }
+        });
+      for (auto& t : th)
+        t.join();
+    }
+    ICICLE_TRY(icicle_hip_set_device(home));
+    for (int p = 0; p < P; p++)
+      if (rcs[p] != ICICLE_SUCCESS) return rcs[p];
+    return ICICLE_SUCCESS;
+  }
+
+  template <class PR>
   static icicle_error_t ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, uint32_t lanes)
   {
     using S = SmallField<PR>;
     if (!cfg) return ICICLE_INVALID_POINTER;
+    if (cfg->ext && !cfg->columns_batch) {
+      const int G = reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_num_devices", 0);
+      if (G >= 1) return ntt_multi_run<PR>(input, size, dir, cfg, output, lanes, G);
+    }
     if (size <= 0 || (size & (size - 1)) != 0) return ICICLE_INVALID_ARGUMENT; // cpu_ntt_main.h:38-41
     if (!input || !output) return ICICLE_INVALID_POINTER;
     if (dir != ICICLE_NTT_FORWARD && dir != ICICLE_NTT_INVERSE) return ICICLE_INVALID_ARGUMENT;

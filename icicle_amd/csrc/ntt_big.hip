@@ -187,7 +187,7 @@ namespace icicle_hip {
     k_big_gen_twiddles<PR><<<(unsigned)((n / 64 + 256) / 256), 256, 0, st>>>(tw, mont_words<PR>(r), n);
     LAUNCH_CHECK("k_big_gen_twiddles", st);
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
-    if (!cfg->is_async) HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+    HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED); // see ntt.hip: published to every stream at once
     dom.tw = tw;
     dom.log_max = log_max;
     memcpy(dom.root, root, 32);
@@ -205,6 +205,7 @@ namespace icicle_hip {
       if (it->second.tw) {
         (void)hipDeviceSynchronize();
         (void)hipFree(it->second.tw);
+        arena_trim(dev); // the NTT work buffers cached for this domain's sizes go with it
       }
       BigDomainStore<PR>::map().erase(it);
     }

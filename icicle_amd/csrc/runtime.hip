@@ -92,29 +92,40 @@ namespace icicle_hip {
     static std::vector<Arena*> v;
     return v;
   }
+  // frees every idle arena of `device` (waiting for its last user first); g_arena_mtx held by the caller
+  static size_t arena_trim_locked(int device)
+  {
+    size_t freed = 0;
+    for (Arena* a : arenas()) {
+      if (a->busy || a->device != device || !a->base) continue;
+      if (a->last_use) (void)hipEventSynchronize(a->last_use);
+      (void)hipFree(a->base);
+      freed += a->cap;
+      a->base = nullptr;
+      a->cap = 0;
+    }
+    return freed;
+  }
   Arena* arena_acquire(size_t bytes, hipStream_t st)
   {
     const int dev = current_device_id();
     std::lock_guard<std::mutex> g(g_arena_mtx);
     Arena* best = nullptr;
-    Arena* small = nullptr;
+    Arena* empty = nullptr;
     for (Arena* a : arenas()) {
       if (a->busy || a->device != dev) continue;
-      if (a->cap >= bytes) {
-        if (!best || a->cap < best->cap) best = a;
-      } else if (!small || a->cap > small->cap) {
-        small = a;
+      if (!a->base) {
+        empty = a;
+      } else if (a->cap >= bytes && (!best || a->cap < best->cap)) {
+        best = a;
       }
     }
     if (!best) {
-      // grow: drop the largest idle-but-too-small arena (after its last user finished) and allocate
-      if (small) {
-        if (small->last_use) (void)hipEventSynchronize(small->last_use);
-        (void)hipFree(small->base);
-        small->base = nullptr;
-        small->cap = 0;
-        best = small;
-      } else {
+      // grow: a NEW allocation. Nothing is freed or waited for on this path, so an is_async call stays asynchronous;
+      // idle arenas that are too small stay cached for smaller requests. Only when the device is out of memory are
+      // the idle arenas given back (after their last users finished) and the allocation retried once.
+      best = empty;
+      if (!best) {
         best = new Arena();
         best->device = dev;
         if (hipEventCreateWithFlags(&best->last_use, hipEventDisableTiming) != hipSuccess) {
@@ -128,8 +139,12 @@ namespace icicle_hip {
       if (hipMalloc(&best->base, want) != hipSuccess) {
         (void)hipGetLastError();
         best->base = nullptr;
-        best->cap = 0;
-        return nullptr;
+        if (arena_trim_locked(dev) == 0 || hipMalloc(&best->base, want) != hipSuccess) {
+          (void)hipGetLastError();
+          best->base = nullptr;
+          best->cap = 0;
+          return nullptr;
+        }
       }
       best->cap = want;
       best->last_stream = st;
@@ -150,13 +165,58 @@ namespace icicle_hip {
   void arena_trim(int device)
   {
     std::lock_guard<std::mutex> g(g_arena_mtx);
-    for (Arena* a : arenas()) {
-      if (a->busy || a->device != device || !a->base) continue;
-      if (a->last_use) (void)hipEventSynchronize(a->last_use);
-      (void)hipFree(a->base);
-      a->base = nullptr;
-      a->cap = 0;
+    (void)arena_trim_locked(device);
+  }
+  size_t arena_cached_bytes(int device)
+  {
+    std::lock_guard<std::mutex> g(g_arena_mtx);
+    size_t tot = 0;
+    for (Arena* a : arenas())
+      if (a->device == device && a->base) tot += a->cap;
+    return tot;
+  }
+
+  // ---- stream-ordered free without the hipMallocAsync pool (which lost data on this stack, profiles/r01_notes.md):
+  // icicle_free_async records an event on the stream and parks the pointer; it is hipFree'd by a later runtime call
+  // once the event has completed (or by a synchronising call), so the caller never blocks.
+  struct DeferredFree {
+    void* ptr;
+    hipEvent_t done;
+    int device;
+  };
+  static std::mutex g_defer_mtx;
+  static std::vector<DeferredFree>& deferred()
+  {
+    static std::vector<DeferredFree> v;
+    return v;
+  }
+  static void reap_deferred(bool wait)
+  {
+    std::vector<DeferredFree> ready;
+    {
+      std::lock_guard<std::mutex> g(g_defer_mtx);
+      auto& v = deferred();
+      for (size_t i = 0; i < v.size();) {
+        if (wait || hipEventQuery(v[i].done) == hipSuccess) {
+          ready.push_back(v[i]);
+          v[i] = v.back();
+          v.pop_back();
+        } else {
+          (void)hipGetLastError();
+          i++;
+        }
+      }
     }
+    if (ready.empty()) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& d : ready) {
+      (void)hipSetDevice(d.device);
+      if (wait) (void)hipEventSynchronize(d.done);
+      (void)hipFree(d.ptr);
+      (void)hipEventDestroy(d.done);
+    }
+    (void)hipSetDevice(cur);
   }
 
   // ---- RCCL loader ------------------------------------------------------------------------------
@@ -338,26 +398,37 @@ icicle_error_t icicle_get_device_count(int* device_count)
   return ICICLE_SUCCESS;
 }
 
+// hipMalloc with one retry after giving cached workspace (idle arenas, parked frees) back to the device
+static hipError_t device_alloc(void** ptr, size_t size)
+{
+  reap_deferred(false);
+  hipError_t e = hipMalloc(ptr, size);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    reap_deferred(true);
+    arena_trim(current_device_id());
+    e = hipMalloc(ptr, size);
+  }
+  return e;
+}
+
 icicle_error_t icicle_malloc(void** ptr, size_t size)
 {
   if (!ptr) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(bind_current_device());
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size > total_b) return ICICLE_OUT_OF_MEMORY;
-  HIP_TRY(hipMalloc(ptr, size ? size : 1), ICICLE_ALLOCATION_FAILED);
+  HIP_TRY(device_alloc(ptr, size ? size : 1), ICICLE_ALLOCATION_FAILED);
   track_add(*ptr, size ? size : 1, current_device_id());
   return ICICLE_SUCCESS;
 }
 
+// Stream-ordered allocation (runtime.h:97): the block exists when the call returns, which satisfies any stream order.
+// NOT hipMallocAsync: that pool handed out ranges whose contents were lost on this ROCm stack (profiles/r01_notes.md).
 icicle_error_t icicle_malloc_async(void** ptr, size_t size, icicleStreamHandle stream)
 {
-  if (!ptr) return ICICLE_INVALID_POINTER;
-  ICICLE_TRY(bind_current_device());
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size > total_b) return ICICLE_OUT_OF_MEMORY;
-  HIP_TRY(hipMallocAsync(ptr, size ? size : 1, (hipStream_t)stream), ICICLE_ALLOCATION_FAILED);
-  track_add(*ptr, size ? size : 1, current_device_id());
-  return ICICLE_SUCCESS;
+  (void)stream;
+  return icicle_malloc(ptr, size);
 }
 
 icicle_error_t icicle_free(void* ptr)
@@ -374,17 +445,27 @@ icicle_error_t icicle_free(void* ptr)
     return ICICLE_DEALLOCATION_FAILED;
   }
   track_remove(ptr);
+  reap_deferred(false);
   return ICICLE_SUCCESS;
 }
 
+// Stream-ordered free (runtime.h:114): the memory is released after everything queued on `stream` so far; the host
+// does not wait (event-deferred hipFree, see reap_deferred).
 icicle_error_t icicle_free_async(void* ptr, icicleStreamHandle stream)
 {
   auto a = track_identify(ptr);
   if (!a) return ICICLE_INVALID_DEVICE;
   if (a->device != current_device_id()) return ICICLE_INVALID_DEVICE; // src/runtime.cpp:107-113
   ICICLE_TRY(bind_current_device());
-  HIP_TRY(hipFreeAsync(ptr, (hipStream_t)stream), ICICLE_DEALLOCATION_FAILED);
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming), ICICLE_DEALLOCATION_FAILED);
+  HIP_TRY(hipEventRecord(ev, (hipStream_t)stream), ICICLE_DEALLOCATION_FAILED);
   track_remove(ptr);
+  {
+    std::lock_guard<std::mutex> g(g_defer_mtx);
+    deferred().push_back({ptr, ev, a->device});
+  }
+  reap_deferred(false);
   return ICICLE_SUCCESS;
 }
 
@@ -392,6 +473,7 @@ icicle_error_t icicle_get_available_memory(size_t* total, size_t* free)
 {
   if (!total || !free) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(bind_current_device());
+  reap_deferred(false);
   HIP_TRY(hipMemGetInfo(free, total), ICICLE_INVALID_DEVICE);
   return ICICLE_SUCCESS;
 }
@@ -498,6 +580,24 @@ icicle_error_t icicle_device_synchronize(void)
 {
   ICICLE_TRY(bind_current_device());
   HIP_TRY(hipDeviceSynchronize(), ICICLE_SYNCHRONIZATION_FAILED);
+  reap_deferred(false);
+  return ICICLE_SUCCESS;
+}
+
+// Gives the cached temporary workspace of the active device (idle arenas, parked stream-ordered frees) back to the
+// device. msm()/ntt() keep their temporaries cached between calls -- ~12 GiB after a 2^26 MSM -- so a caller that
+// wants the memory for something else calls this (also done by <field>_ntt_release_domain).
+icicle_error_t icicle_hip_release_workspace(void)
+{
+  ICICLE_TRY(bind_current_device());
+  reap_deferred(true);
+  arena_trim(current_device_id());
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_hip_workspace_bytes(size_t* bytes)
+{
+  if (!bytes) return ICICLE_INVALID_POINTER;
+  *bytes = arena_cached_bytes(current_device_id());
   return ICICLE_SUCCESS;
 }
 

@@ -89,8 +89,16 @@ icicle_error_t icicle_is_device_available(const icicle_device_t* dev);   /* runt
 icicle_error_t icicle_get_registered_devices(char* output, size_t output_size); /* runtime.h:281 */
 
 /* ---- ConfigExtension: src/config_extension.cpp:7-37 (string-keyed int/bool bag, opaque handle) ----
- * Keys understood by this backend: "hip_msm_chunk_log2" (int), "hip_ntt_force_radix2" (bool).
- * Foreign keys (the CUDA backend's "large_bucket_factor", "fast_twiddles", ...) are tolerated and ignored. */
+ * The reference hands backend-specific knobs to a backend through MSMConfig.ext / NTTConfig.ext
+ * (include/icicle/backend/msm_config.h:4-16, ntt_config.h:9-18). Keys read by this backend:
+ *   "hip_num_devices"          (int,  msm + ntt)  G >= 1: run the call on G shards over min(G, visible GPUs) devices
+ *                                                 starting at the active one (MSM: contiguous (scalar, base) shards,
+ *                                                 partial results all-gathered over RCCL and summed; batched NTT:
+ *                                                 rows per device, no collective). icicle_amd/csrc/msm_multi.cuh.
+ *   "hip_msm_exchange_buckets" (bool, msm)        with hip_num_devices: exchange bucket slices (all-to-all) instead of
+ *                                                 final partial sums, so that the bucket reduction is sharded too.
+ * Foreign keys (the CUDA backend's "large_bucket_factor", "fast_twiddles", the CPU backend's "n_threads", ...) are
+ * tolerated and ignored. */
 typedef struct icicle_config_extension icicle_config_extension_t;
 icicle_config_extension_t* create_config_extension(void);
 void destroy_config_extension(icicle_config_extension_t* ext);
@@ -277,6 +285,17 @@ icicle_error_t koalabear_hip_twiddle_rows(uint32_t* data, uint64_t rows, uint64_
  * accumulation, 1 = NTT pass kernels. */
 icicle_error_t icicle_hip_kernel_timing(int which, bool reset, double* total_ms, int* launches);
 icicle_error_t icicle_hip_enable_kernel_timing(bool enable);
+/* Roofs of the dominant MSM kernel, measured on the spot (bench.py reports them next to the kernel's own rate):
+ * XYZZ mixed additions per second with all operands in registers (curve 0 = bn254, 1 = bls12_381) -- the integer-ALU
+ * roof of bucket accumulation -- and random 64-byte gathers per second over a region of `region_bytes` (the access
+ * pattern of its base fetch; also the known-byte-count kernel the FETCH_SIZE counter is calibrated on). */
+icicle_error_t icicle_hip_ubench_mixed_add(int curve, double* adds_per_second);
+icicle_error_t icicle_hip_ubench_gather(uint64_t region_bytes, uint64_t gathers, double* gathers_per_second);
+/* msm()/ntt() keep their temporaries cached between calls (about 8 GiB after a 2^26-term MSM). release_workspace gives
+ * the idle part back to the device (it is also given back automatically when an allocation would otherwise fail, and by
+ * <field>_ntt_release_domain); workspace_bytes reports what is cached for the active device. */
+icicle_error_t icicle_hip_release_workspace(void);
+icicle_error_t icicle_hip_workspace_bytes(size_t* bytes);
 
 /* ---- collision-free aliases used by the reference-runtime plugin (plugin/):
  * same functions as the un-prefixed names above, for processes that also load the reference's own

@@ -75,11 +75,11 @@ def test_config_extension_roundtrip():
     from icicle_amd._lib import lib
 
     e = lib.create_config_extension()
-    lib.config_extension_set_int(e, b"hip_msm_chunk_log2", 21)
+    lib.config_extension_set_int(e, b"hip_num_devices", 21)
     lib.config_extension_set_bool(e, b"fast_twiddles", True)  # foreign (CUDA) key: tolerated
-    assert lib.config_extension_get_int(e, b"hip_msm_chunk_log2") == 21
+    assert lib.config_extension_get_int(e, b"hip_num_devices") == 21
     assert lib.config_extension_get_bool(e, b"fast_twiddles") is True
     c = lib.clone_config_extension(e)
-    assert lib.config_extension_get_int(c, b"hip_msm_chunk_log2") == 21
+    assert lib.config_extension_get_int(c, b"hip_num_devices") == 21
     lib.destroy_config_extension(e)
     lib.destroy_config_extension(c)

@@ -180,3 +180,98 @@ def test_ntt_many_tiny_transforms(env, hip):
         got = N.ntt(fname, x, N.FORWARD, cfg)
         exp = rf.ntt(x, n, 0, batch=batch, ordering=ordering, coset_gen=coset)
         assert np.array_equal(got, exp), (logn, ordering, coset)
+
+
+@pytest.mark.parametrize("G", [1, 2, 8])
+def test_ntt_multi_device_through_c_abi(env, hip, G):
+    """config.ext {"hip_num_devices": G}: the batch cut into G row shards behind the unchanged <field>_ntt symbol
+    (logical shards share GPU 0 here; rows are independent transforms, no collective). Host and device-resident
+    operands, in place, forward with coset / inverse kNR -- memcmp against the reference CPU backend."""
+    import ctypes
+    from icicle_amd._lib import lib
+    from icicle_amd.runtime import DeviceVec
+
+    fname, F, rf, N = env
+    rng = np.random.default_rng(77 + G)
+    ext = lib.create_config_extension()
+    try:
+        lib.config_extension_set_int(ext, b"hip_num_devices", G)
+        for logn, batch, direction, ordering, coset in ((12, 5, 0, 0, 1), (9, 11, 1, 1, 1), (14, 3, 0, 0, 13), (6, 1, 0, 0, 1)):
+            n = 1 << logn
+            x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+            cfg = hip.NTTConfigU32.default()
+            cfg.batch_size, cfg.ordering, cfg.coset_gen, cfg.ext = batch, ordering, coset, ext
+            exp = rf.ntt(x, n, direction, batch=batch, ordering=ordering, coset_gen=coset)
+            assert np.array_equal(N.ntt(fname, x, direction, cfg), exp), (G, logn, batch, "host")
+            d = DeviceVec.from_host(x)
+            N.ntt(fname, d, direction, cfg, out=d, size=n)  # device resident, in place
+            assert np.array_equal(d.to_host(), exp), (G, logn, batch, "device in place")
+    finally:
+        lib.destroy_config_extension(ext)
+
+
+def test_stream_ordered_alloc_and_workspace(env, hip):
+    """operands from icicle_malloc_async / icicle_free_async (icicle/tests/test_device_api.cpp:98-118 pattern) through an
+    NTT and an MSM on a created stream; then the cached workspace is reported and given back."""
+    import ctypes
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib, check
+    from icicle_amd.runtime import Stream
+    from tests.util import cached_points, points_to_array, rand_scalars, to_words
+
+    fname, F, rf, N = env
+    rng = np.random.default_rng(88)
+    st = Stream()
+    n = 1 << 13
+    x = rng.integers(0, F.p, size=n, dtype=np.uint32)
+    p_in, p_out = ctypes.c_void_p(), ctypes.c_void_p()
+    check(lib.icicle_malloc_async(ctypes.byref(p_in), x.nbytes, st.handle))
+    check(lib.icicle_malloc_async(ctypes.byref(p_out), x.nbytes, st.handle))
+    assert lib.icicle_is_active_device_memory(p_in) == 0 and lib.icicle_is_host_memory(p_in) != 0
+    check(lib.icicle_copy_to_device_async(p_in, x.ctypes.data, x.nbytes, st.handle))
+    cfg = hip.NTTConfigU32.default()
+    cfg.stream, cfg.is_async = st.handle, True
+    N.ntt(fname, p_in.value, N.FORWARD, cfg, out=p_out.value, size=n)
+    y = np.empty_like(x)
+    check(lib.icicle_copy_to_host_async(y.ctypes.data, p_out, x.nbytes, st.handle))
+    check(lib.icicle_free_async(p_in, st.handle))
+    check(lib.icicle_free_async(p_out, st.handle))
+    st.synchronize()
+    assert np.array_equal(y, rf.ntt(x, n, 0))
+    assert lib.icicle_is_host_memory(p_in) == 0  # no longer tracked as device memory
+    # MSM on malloc_async'd operands
+    C = pyref.BN254
+    refc = ref.RefCurve("bn254")
+    m = 3000
+    bases = points_to_array(C, cached_points(C, m))
+    sc = to_words(rand_scalars(rng, m, C.r), 8)
+    ps, pb, pr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    for ptr, nb in ((ps, sc.nbytes), (pb, bases.nbytes), (pr, 96)):
+        check(lib.icicle_malloc_async(ctypes.byref(ptr), nb, st.handle))
+    check(lib.icicle_copy_to_device_async(ps, sc.ctypes.data, sc.nbytes, st.handle))
+    check(lib.icicle_copy_to_device_async(pb, bases.ctypes.data, bases.nbytes, st.handle))
+    mc = hip.MSMConfig.default()
+    mc.stream, mc.is_async = st.handle, True
+    M.msm("bn254", ps.value, pb.value, mc, results=pr.value, msm_size=m)
+    out = np.zeros((1, 24), dtype=np.uint32)
+    check(lib.icicle_copy_to_host_async(out.ctypes.data, pr, 96, st.handle))
+    for ptr in (ps, pb, pr):
+        check(lib.icicle_free_async(ptr, st.handle))
+    st.synchronize()
+    assert np.array_equal(refc.to_affine(out), refc.to_affine(refc.msm(sc, bases)))
+    # 200 live allocations, then all released (test_device_api.cpp:191-254 counts live allocations the same way)
+    ptrs = []
+    for i in range(200):
+        q = ctypes.c_void_p()
+        check(lib.icicle_malloc(ctypes.byref(q), 1024 + i))
+        ptrs.append(q)
+    assert len({q.value for q in ptrs}) == 200
+    for q in ptrs:
+        check(lib.icicle_free(q))
+    cached = ctypes.c_size_t()
+    check(lib.icicle_hip_workspace_bytes(ctypes.byref(cached)))
+    assert cached.value > 0
+    check(lib.icicle_hip_release_workspace())
+    check(lib.icicle_hip_workspace_bytes(ctypes.byref(cached)))
+    assert cached.value == 0
+    st.destroy()
