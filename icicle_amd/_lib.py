@@ -171,9 +171,11 @@ API_SYMBOLS = (
                                                                  "get_root_of_unity_from_domain")]
     + [f"{pre}{c}_ecntt" for pre in ("", "icicle_hip_") for c in CURVES]
     + [f"{pre}{f}_{op}" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + SCALAR_NTT_FIELDS
-       for op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "bit_reverse")]
+       for op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "scalar_add_vec", "scalar_sub_vec", "bit_reverse")]
     + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
-       "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes"]
+       "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
+       "icicle_hip_create_config_extension", "icicle_hip_destroy_config_extension", "icicle_hip_config_extension_set_int",
+       "icicle_hip_config_extension_set_bool"]
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
                                                           "get_root_of_unity_from_domain")]
@@ -242,7 +244,7 @@ for _f in SCALAR_NTT_FIELDS:
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
     getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
 for _f in NTT_FIELDS + SCALAR_NTT_FIELDS:
-    for _op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec"):
+    for _op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "scalar_add_vec", "scalar_sub_vec"):
         getattr(lib, f"{_f}_{_op}").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
     getattr(lib, f"{_f}_bit_reverse").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
 for _n in API_SYMBOLS:

@@ -150,8 +150,11 @@ namespace icicle_hip {
     }
   };
 
+  // `bits`: scalar bits the MSM considers (MSMConfig.bitsize). The reference reads ONLY those bits of a scalar
+  // (cpu_msm.hpp:288 coeff_width = min(c, bitsize - offset)), i.e. it computes sum (s_i mod 2^bitsize) P_i even when a
+  // scalar is wider than the caller promised (icicle/tests/test_curve_api.cpp:82-123 msm_bitsize does exactly that).
   template <class C>
-  __device__ __forceinline__ void load_scalar(DigitIter& it, const uint32_t* __restrict__ scalars, size_t i, bool scalars_refmont)
+  __device__ __forceinline__ void load_scalar(DigitIter& it, const uint32_t* __restrict__ scalars, size_t i, bool scalars_refmont, int bits)
   {
     using FR = FieldOps<typename C::fr>;
     static_assert(FR::N32 == 8, "scalar fields here are 8 x u32");
@@ -167,20 +170,30 @@ namespace icicle_hip {
       BF_SET_BOUND(cst, 1);
       FR::pack(it.w, FR::reduce(FR::mul(FR::unpack(it.w), cst)));
     }
+    if (bits < 256) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int lo = 32 * k;
+        if (bits <= lo)
+          it.w[k] = 0;
+        else if (bits < lo + 32)
+          it.w[k] &= (1u << (bits - lo)) - 1u;
+      }
+    }
     it.w[8] = 0;
     it.carry = 0;
   }
 
   // digits of all windows, dig[wi*n + i] (coalesced 4-byte writes; read back window by window)
   template <class C>
-  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, size_t nscal, int c, int nwin, bool scalars_refmont)
+  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, size_t nscal, int c, int nwin, bool scalars_refmont, int bits)
   {
     // nscal = (MSMs in this launch) * n scalars; row (b*nwin + wi) of `dig` holds window wi of MSM b
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nscal) return;
     const size_t b = t / n, i = t - b * n;
     DigitIter it;
-    load_scalar<C>(it, scalars, t, scalars_refmont);
+    load_scalar<C>(it, scalars, t, scalars_refmont, bits);
     for (int wi = 0; wi < nwin; wi++)
       dig[(b * nwin + wi) * n + i] = it.next(c);
   }
@@ -189,7 +202,7 @@ namespace icicle_hip {
   // and counts, per target window, how many fall into each of the 2^hb partitions -- the counts come from registers
   // instead of a second read of the 13 x 4 B per scalar digit array. Dynamic LDS: wpf * 2^hb counters.
   template <class C>
-  __global__ __launch_bounds__(1024) void k_digits_count(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int c, int nwin, int wpf, SortPlan sp, bool scalars_refmont)
+  __global__ __launch_bounds__(1024) void k_digits_count(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int c, int nwin, int wpf, SortPlan sp, bool scalars_refmont, int bits)
   {
     extern __shared__ uint32_t lds[];
     const int b = blockIdx.x, mb = blockIdx.y;
@@ -200,7 +213,7 @@ namespace icicle_hip {
     const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
       DigitIter it;
-      load_scalar<C>(it, scalars, (size_t)mb * n + i, scalars_refmont);
+      load_scalar<C>(it, scalars, (size_t)mb * n + i, scalars_refmont, bits);
       int wp = 0;
       for (int wi = 0; wi < nwin; wi++) {
         const uint32_t d = it.next(c);
@@ -1217,10 +1230,10 @@ namespace icicle_hip {
       // digits + pass-A histogram in one pass over the scalars, when there are enough chunks to fill the chip
       // (a block walks a whole chunk; with few chunks the thread-per-scalar k_digits + k_a_count pair is faster)
       if (lds_dc <= 64 * 1024 && bb <= 65535 && (size_t)sp.nblk * bb >= 512) {
-        k_digits_count<C><<<dim3(sp.nblk, (unsigned)bb), 1024, lds_dc, st>>>(sc, dig, cntA, n, pl.c, pl.nwin, wpf, sp, cfg->are_scalars_montgomery_form);
+        k_digits_count<C><<<dim3(sp.nblk, (unsigned)bb), 1024, lds_dc, st>>>(sc, dig, cntA, n, pl.c, pl.nwin, wpf, sp, cfg->are_scalars_montgomery_form, pl.bits);
         LAUNCH_CHECK("k_digits_count", st);
       } else {
-        k_digits<C><<<(unsigned)((nscal + 255) / 256), 256, 0, st>>>(sc, dig, n, nscal, pl.c, pl.nwin, cfg->are_scalars_montgomery_form);
+        k_digits<C><<<(unsigned)((nscal + 255) / 256), 256, 0, st>>>(sc, dig, n, nscal, pl.c, pl.nwin, cfg->are_scalars_montgomery_form, pl.bits);
         LAUNCH_CHECK("k_digits", st);
         k_a_count<<<dim3(sp.nblk, (unsigned)tw), 1024, ((size_t)4 << sp.hb), st>>>(dig, cntA, n, pl.nwin, wpf, pf, sp);
         LAUNCH_CHECK("k_a_count", st);

@@ -645,5 +645,11 @@ icicle_config_extension_t* clone_config_extension(const icicle_config_extension_
 {
   return ext ? (icicle_config_extension_t*)new ConfigExt(*(const ConfigExt*)ext) : nullptr;
 }
+// collision-free aliases for the reference-runtime plugin: it translates the keys it knows out of the reference's own
+// ConfigExtension object (a different C++ class living in libicicle_device.so) into one of ours
+icicle_config_extension_t* icicle_hip_create_config_extension(void) { return create_config_extension(); }
+void icicle_hip_destroy_config_extension(icicle_config_extension_t* ext) { destroy_config_extension(ext); }
+void icicle_hip_config_extension_set_int(icicle_config_extension_t* ext, const char* key, int value) { config_extension_set_int(ext, key, value); }
+void icicle_hip_config_extension_set_bool(icicle_config_extension_t* ext, const char* key, bool value) { config_extension_set_bool(ext, key, value); }
 
 } // extern "C"

@@ -4,7 +4,8 @@
 // product -> inverse NTT) or around the kNR / kRN orderings, so that such a pipeline stays on the device.
 //
 // Reference semantics: icicle/src/vec_ops.cpp:71-84 (vector_add), :136-149 (vector_sub), :169-182
-// (vector_mul), :362-366 (scalar_mul_vec), :440-444 (bit_reverse); CPU backend
+// (vector_mul), :362-366 (scalar_mul_vec; scalar_add_vec / scalar_sub_vec = scalar op vector next to it), :440-444
+// (bit_reverse); CPU backend
 // icicle/backend/cpu/src/field/cpu_vec_ops.cpp:325-342 (one scalar per batch entry, stride = batch for
 // columns_batch), :536-560 (bit reverse per batch entry). Values are plain (non-Montgomery) residues and
 // stay so: products are computed as montmul(montmul(a, b), R^2).
@@ -196,6 +197,10 @@ using namespace icicle_hip;
   extern "C" icicle_error_t NAME##_vector_sub(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_SUB, false))); } \
   extern "C" icicle_error_t NAME##_vector_mul(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_MUL, false))); } \
   extern "C" icicle_error_t NAME##_scalar_mul_vec(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_MUL, true))); } \
+  extern "C" icicle_error_t NAME##_scalar_add_vec(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_ADD, true))); } \
+  extern "C" icicle_error_t NAME##_scalar_sub_vec(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_SUB, true))); } \
+  extern "C" icicle_error_t icicle_hip_##NAME##_scalar_add_vec(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_ADD, true))); } \
+  extern "C" icicle_error_t icicle_hip_##NAME##_scalar_sub_vec(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_SUB, true))); } \
   extern "C" icicle_error_t NAME##_bit_reverse(const void* i, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((bitrev_run<W>(i, n, c, o))); } \
   extern "C" icicle_error_t icicle_hip_##NAME##_vector_add(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_ADD, false))); } \
   extern "C" icicle_error_t icicle_hip_##NAME##_vector_sub(const void* a, const void* b, uint64_t n, const icicle_vec_ops_config_t* c, void* o) { GUARDED((vec2_run<EL>(a, b, n, c, o, VOP_SUB, false))); } \

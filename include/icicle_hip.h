@@ -248,6 +248,10 @@ icicle_error_t bls12_381_g2_projective_convert_montgomery(const void* input, uin
   icicle_error_t F##_vector_sub(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
   icicle_error_t F##_vector_mul(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
   icicle_error_t F##_scalar_mul_vec(const void* scalar_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t F##_scalar_add_vec(const void* scalar_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t F##_scalar_sub_vec(const void* scalar_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t icicle_hip_##F##_scalar_add_vec(const void* scalar_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
+  icicle_error_t icicle_hip_##F##_scalar_sub_vec(const void* scalar_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
   icicle_error_t F##_bit_reverse(const void* input, uint64_t size, const icicle_vec_ops_config_t* config, void* output); \
   icicle_error_t icicle_hip_##F##_vector_add(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
   icicle_error_t icicle_hip_##F##_vector_sub(const void* vec_a, const void* vec_b, uint64_t size, const icicle_vec_ops_config_t* config, void* result); \
@@ -301,6 +305,10 @@ icicle_error_t icicle_hip_workspace_bytes(size_t* bytes);
  * same functions as the un-prefixed names above, for processes that also load the reference's own
  * libicicle_device / libicicle_curve_<c> / libicicle_field_<f>, which define those names. ---- */
 icicle_error_t icicle_hip_set_device(int device_id);
+icicle_config_extension_t* icicle_hip_create_config_extension(void);
+void icicle_hip_destroy_config_extension(icicle_config_extension_t* ext);
+void icicle_hip_config_extension_set_int(icicle_config_extension_t* ext, const char* key, int value);
+void icicle_hip_config_extension_set_bool(icicle_config_extension_t* ext, const char* key, bool value);
 icicle_error_t icicle_hip_bn254_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);
 icicle_error_t icicle_hip_bn254_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases);
 icicle_error_t icicle_hip_bls12_381_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);

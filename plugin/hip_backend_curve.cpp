@@ -3,7 +3,8 @@
 // Registers functions with exactly the MsmImpl / MsmPreComputeImpl signatures
 // (icicle/include/icicle/backend/msm_backend.h:11-44) under device type "HIP"; each forwards to the
 // collision-free C entry points of libicicle_hip.so (include/icicle_hip.h). MSMConfig is passed
-// through byte-for-byte (same 40-byte layout) except `ext`, whose C++ object belongs to the reference.
+// through byte-for-byte (same 40-byte layout) except `ext`: the reference's ConfigExtension object is
+// translated key by key (HipExt, hip_c_api.h).
 #include <cstring>
 #include "icicle/backend/msm_backend.h"
 #include "icicle/backend/ecntt_backend.h"
@@ -30,7 +31,9 @@ static hip_msm_config_t translate(const MSMConfig& c)
 static eIcicleError hip_msm(const Device& device, const scalar_t* scalars, const affine_t* bases, int msm_size, const MSMConfig& config, projective_t* results)
 {
   if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
-  const hip_msm_config_t c = translate(config);
+  hip_msm_config_t c = translate(config);
+  HipExt ext(config.ext); // "hip_num_devices" / "hip_msm_exchange_buckets" reach the backend, foreign keys do not
+  c.ext = ext.h;
   return (eIcicleError)HIP_FN(msm)(scalars, bases, msm_size, &c, results);
 }
 
@@ -75,7 +78,9 @@ REGISTER_MSM_PRE_COMPUTE_BASES_BACKEND("HIP", hip_msm_precompute);
 static eIcicleError hip_g2_msm(const Device& device, const scalar_t* scalars, const g2_affine_t* bases, int msm_size, const MSMConfig& config, g2_projective_t* results)
 {
   if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
-  const hip_msm_config_t c = translate(config);
+  hip_msm_config_t c = translate(config);
+  HipExt ext(config.ext);
+  c.ext = ext.h;
   return (eIcicleError)HIP_G2_FN(msm)(scalars, bases, msm_size, &c, results);
 }
 static eIcicleError hip_g2_msm_precompute(const Device& device, const g2_affine_t* input_bases, int nof_bases, const MSMConfig& config, g2_affine_t* output_bases)

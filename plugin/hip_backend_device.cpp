@@ -10,6 +10,8 @@
 // Structural model: the reference's only in-tree GPU DeviceAPI,
 // icicle/backend/cuda_pqc/src/cuda_pqc_device_api.cu:11-121 (not copied; different API, same contract).
 #include <hip/hip_runtime_api.h>
+#include <mutex>
+#include <vector>
 #include "icicle/device_api.h"
 #include "icicle/errors.h"
 
@@ -40,6 +42,44 @@ namespace {
 
 class HipDeviceAPI : public DeviceAPI
 {
+  struct Parked {
+    void* ptr;
+    hipEvent_t done;
+  };
+  static std::mutex& mtx()
+  {
+    static std::mutex m;
+    return m;
+  }
+  static std::vector<Parked>& parked()
+  {
+    static std::vector<Parked> v;
+    return v;
+  }
+  static void reap(bool wait)
+  {
+    std::vector<Parked> ready;
+    {
+      std::lock_guard<std::mutex> g(mtx());
+      auto& v = parked();
+      for (size_t i = 0; i < v.size();) {
+        if (wait || hipEventQuery(v[i].done) == hipSuccess) {
+          ready.push_back(v[i]);
+          v[i] = v.back();
+          v.pop_back();
+        } else {
+          (void)hipGetLastError();
+          i++;
+        }
+      }
+    }
+    for (auto& p : ready) {
+      if (wait) (void)hipEventSynchronize(p.done);
+      (void)hipFree(p.ptr);
+      (void)hipEventDestroy(p.done);
+    }
+  }
+
 public:
   eIcicleError set_device(const Device& device) override
   {
@@ -61,14 +101,28 @@ public:
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size > total_b) return eIcicleError::OUT_OF_MEMORY;
     return tr(hipMalloc(ptr, size ? size : 1), eIcicleError::ALLOCATION_FAILED);
   }
-  eIcicleError allocate_memory_async(void** ptr, size_t size, icicleStreamHandle stream) const override
+  // Stream-ordered allocation without the hipMallocAsync pool (it lost data on this ROCm stack, profiles/r01_notes.md):
+  // the block exists when the call returns, which satisfies any stream order; the free is deferred behind an event
+  // recorded on the stream and carried out by a later call, so the host never waits.
+  eIcicleError allocate_memory_async(void** ptr, size_t size, icicleStreamHandle) const override { return allocate_memory(ptr, size); }
+  eIcicleError free_memory(void* ptr) const override
   {
-    return tr(hipMallocAsync(ptr, size ? size : 1, (hipStream_t)stream), eIcicleError::ALLOCATION_FAILED);
+    reap(false);
+    return tr(hipFree(ptr), eIcicleError::DEALLOCATION_FAILED);
   }
-  eIcicleError free_memory(void* ptr) const override { return tr(hipFree(ptr), eIcicleError::DEALLOCATION_FAILED); }
   eIcicleError free_memory_async(void* ptr, icicleStreamHandle stream) const override
   {
-    return tr(hipFreeAsync(ptr, (hipStream_t)stream), eIcicleError::DEALLOCATION_FAILED);
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, (hipStream_t)stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return eIcicleError::DEALLOCATION_FAILED;
+    }
+    {
+      std::lock_guard<std::mutex> g(mtx());
+      parked().push_back({ptr, ev});
+    }
+    reap(false);
+    return eIcicleError::SUCCESS;
   }
   eIcicleError get_available_memory(size_t& total, size_t& free) const override
   {
@@ -92,7 +146,9 @@ public:
   }
   eIcicleError synchronize(icicleStreamHandle stream = nullptr) const override
   {
-    return tr(stream ? hipStreamSynchronize((hipStream_t)stream) : hipDeviceSynchronize(), eIcicleError::SYNCHRONIZATION_FAILED);
+    const eIcicleError e = tr(stream ? hipStreamSynchronize((hipStream_t)stream) : hipDeviceSynchronize(), eIcicleError::SYNCHRONIZATION_FAILED);
+    reap(false);
+    return e;
   }
   eIcicleError create_stream(icicleStreamHandle* stream) const override
   {

@@ -43,6 +43,8 @@ HIP_VEC2(vector_add)
 HIP_VEC2(vector_sub)
 HIP_VEC2(vector_mul)
 HIP_VEC2(scalar_mul_vec)
+HIP_VEC2(scalar_add_vec)
+HIP_VEC2(scalar_sub_vec)
 static eIcicleError hip_bit_reverse(const Device& device, const scalar_t* input, uint64_t size, const VecOpsConfig& config, scalar_t* output)
 {
   if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
@@ -51,10 +53,20 @@ static eIcicleError hip_bit_reverse(const Device& device, const scalar_t* input,
   c.ext = nullptr;
   return (eIcicleError)HIP_FN(bit_reverse)(input, size, &c, output);
 }
+// vector_accumulate(a, b): a[i] += b[i] in place (include/icicle/backend/vec_ops_backend.h) = vector_add with output = a
+static eIcicleError hip_vector_accumulate(const Device& device, scalar_t* a, const scalar_t* b, uint64_t size, const VecOpsConfig& config)
+{
+  VecOpsConfig c = config;
+  c.is_result_on_device = c.is_a_on_device;
+  return hip_vector_add(device, a, b, size, c, a);
+}
+REGISTER_VECTOR_ACCUMULATE_BACKEND("HIP", hip_vector_accumulate);
 REGISTER_VECTOR_ADD_BACKEND("HIP", hip_vector_add);
 REGISTER_VECTOR_SUB_BACKEND("HIP", hip_vector_sub);
 REGISTER_VECTOR_MUL_BACKEND("HIP", hip_vector_mul);
 REGISTER_SCALAR_MUL_VEC_BACKEND("HIP", hip_scalar_mul_vec);
+REGISTER_SCALAR_ADD_VEC_BACKEND("HIP", hip_scalar_add_vec);
+REGISTER_SCALAR_SUB_VEC_BACKEND("HIP", hip_scalar_sub_vec);
 REGISTER_BIT_REVERSE_BACKEND("HIP", hip_bit_reverse);
 
 #ifdef HIP_PLUGIN_SCALAR_FIELD_256
@@ -78,7 +90,9 @@ static hip_ntt_config_t translate(const NTTConfig<scalar_t>& c)
 static eIcicleError hip_ntt(const Device& device, const scalar_t* input, int size, NTTDir dir, const NTTConfig<scalar_t>& config, scalar_t* output)
 {
   if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
-  const hip_ntt_config_t c = translate(config);
+  hip_ntt_config_t c = translate(config);
+  HipExt ext(config.ext); // "hip_num_devices": batch rows over devices
+  c.ext = ext.h;
   return (eIcicleError)HIP_FN(ntt)((const uint32_t*)input, size, (int)dir, &c, (uint32_t*)output);
 }
 

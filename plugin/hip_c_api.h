@@ -48,6 +48,10 @@ typedef struct {
 } hip_vec_ops_config_t; // == icicle_vec_ops_config_t == icicle::VecOpsConfig (32 bytes)
 
 int icicle_hip_set_device(int device_id);
+void* icicle_hip_create_config_extension(void);
+void icicle_hip_destroy_config_extension(void* ext);
+void icicle_hip_config_extension_set_int(void* ext, const char* key, int value);
+void icicle_hip_config_extension_set_bool(void* ext, const char* key, bool value);
 #define HIP_DECLARE_CONVERT(P)                                                                                         \
   int icicle_hip_##P##_scalar_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
 HIP_DECLARE_CONVERT(bn254)
@@ -90,6 +94,8 @@ HIP_DECLARE_SCALAR_FIELD(bls12_381)
   int icicle_hip_##F##_vector_sub(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);              \
   int icicle_hip_##F##_vector_mul(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);              \
   int icicle_hip_##F##_scalar_mul_vec(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);          \
+  int icicle_hip_##F##_scalar_add_vec(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);          \
+  int icicle_hip_##F##_scalar_sub_vec(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);          \
   int icicle_hip_##F##_bit_reverse(const void*, uint64_t, const hip_vec_ops_config_t*, void*);
 HIP_DECLARE_VEC_ARITH(babybear)
 HIP_DECLARE_VEC_ARITH(koalabear)
@@ -98,3 +104,27 @@ HIP_DECLARE_VEC_ARITH(bls12_381)
 int icicle_hip_bn254_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 int icicle_hip_bls12_381_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 }
+
+#ifdef __cplusplus
+  #include "icicle/config_extension.h"
+// The reference's ConfigExtension (a C++ object of libicicle_device.so) -> this backend's own key bag, for the keys
+// this backend reads (include/icicle_hip.h "ConfigExtension"); everything else stays behind, tolerated and ignored.
+struct HipExt {
+  void* h = nullptr;
+  explicit HipExt(const icicle::ConfigExtension* e)
+  {
+    if (!e) return;
+    const bool nd = e->has("hip_num_devices"), xb = e->has("hip_msm_exchange_buckets");
+    if (!nd && !xb) return;
+    h = icicle_hip_create_config_extension();
+    if (nd) icicle_hip_config_extension_set_int(h, "hip_num_devices", e->get<int>("hip_num_devices"));
+    if (xb) icicle_hip_config_extension_set_bool(h, "hip_msm_exchange_buckets", e->get<bool>("hip_msm_exchange_buckets"));
+  }
+  ~HipExt()
+  {
+    if (h) icicle_hip_destroy_config_extension(h);
+  }
+  HipExt(const HipExt&) = delete;
+  HipExt& operator=(const HipExt&) = delete;
+};
+#endif

@@ -129,6 +129,11 @@ def test_msm_skewed_and_bitsize(hip, cname):
     for bits in (2, 7, 31, 32, 33, 64, 129, 200, C.r.bit_length() - 1):
         sc = rand_scalars(rng, 300, C.r, bits=bits)
         _check(hip, cname, to_words(sc, 8), bases[:300], refc, bitsize=bits)
+    # scalars WIDER than bitsize: only the low bitsize bits count (cpu_msm.hpp:288; test_curve_api.cpp:82-123 feeds
+    # full-width scalars to every bitsize from 1 to NBITS)
+    full = to_words(rand_scalars(rng, 300, C.r), 8)
+    for bits in (1, 2, 5, 19, 20, 21, 31, 32, 33, 63, 64, 65, 127, 200, C.r.bit_length() - 1, C.r.bit_length()):
+        _check(hip, cname, full, bases[:300], refc, bitsize=bits)
 
 
 @pytest.mark.parametrize("cname", CURVES)
