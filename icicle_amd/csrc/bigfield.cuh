@@ -19,6 +19,7 @@
 #pragma once
 #include <cstdint>
 #include "field_consts.h"
+#include "mont_asm.cuh" // device builds: the products below as single inline-asm blocks (-DBIGFIELD_NO_ASM turns them off)
 
 #if defined(__HIPCC__)
   #include <hip/hip_runtime.h>
@@ -134,6 +135,15 @@ namespace icicle_hip {
     {
       BF_ASSERT(a.bnd <= max_bound() && b.bnd <= max_bound(), "mul input bound");
       fe r;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BIGFIELD_NO_ASM)
+      if constexpr (N == 9) {
+        mont_mul_asm9<PR>(r.l, a.l, b.l);
+        return r;
+      } else if constexpr (N == 14) {
+        mont_mul_asm14<PR>(r.l, a.l, b.l);
+        return r;
+      }
+#endif
       uint32_t m[N];
       uint64_t acc = 0;
 #pragma unroll
@@ -163,6 +173,22 @@ namespace icicle_hip {
       return r;
     }
 
+    // a <- a*b/R (same value and bound as mul). On the device the result is produced in a's own registers, so a
+    // loop-carried accumulator coordinate needs no copies at the back edge (mont_asm.cuh).
+    static HD void mul_inplace(fe& a, const fe& b)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BIGFIELD_NO_ASM)
+      if constexpr (N == 9) {
+        mont_mul_inplace_asm9<PR>(a.l, b.l);
+        return;
+      } else if constexpr (N == 14) {
+        mont_mul_inplace_asm14<PR>(a.l, b.l);
+        return;
+      }
+#endif
+      a = mul(a, b);
+    }
+
     // r = (a*b + c*d)/R mod p with ONE interleaved reduction: both products share the column
     // accumulators (3N products of < 2^58 per column: < 2^64 for N <= 21).
     static HD fe mul_add(const fe& a, const fe& b, const fe& c, const fe& d)
@@ -170,6 +196,15 @@ namespace icicle_hip {
       BF_ASSERT(a.bnd <= max_bound() && b.bnd <= max_bound() && c.bnd <= max_bound() && d.bnd <= max_bound(), "mul_add input bound");
       static_assert(N <= 21, "column accumulator would overflow");
       fe r;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BIGFIELD_NO_ASM)
+      if constexpr (N == 9) {
+        mont_mul_add_asm9<PR>(r.l, a.l, b.l, c.l, d.l);
+        return r;
+      } else if constexpr (N == 14) {
+        mont_mul_add_asm14<PR>(r.l, a.l, b.l, c.l, d.l);
+        return r;
+      }
+#endif
       uint32_t m[N];
       uint64_t acc = 0;
 #pragma unroll
@@ -202,6 +237,21 @@ namespace icicle_hip {
       return r;
     }
 
+    // c <- (a*b + c*d)/R, result in c's own registers on the device (see mul_inplace)
+    static HD void mul_add_inplace_c(fe& c, const fe& a, const fe& b, const fe& d)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BIGFIELD_NO_ASM)
+      if constexpr (N == 9) {
+        mont_mul_add_inplace_c_asm9<PR>(c.l, a.l, b.l, d.l);
+        return;
+      } else if constexpr (N == 14) {
+        mont_mul_add_inplace_c_asm14<PR>(c.l, a.l, b.l, d.l);
+        return;
+      }
+#endif
+      c = mul_add(a, b, c, d);
+    }
+
     // Squaring: the a_i*a_j cross terms are computed once and doubled (N(N+1)/2 instead of N^2
     // products for the a*a half; the m*p half is unchanged).
     static HD fe sqr(const fe& a)
@@ -213,6 +263,15 @@ namespace icicle_hip {
 #pragma unroll
       for (int i = 0; i < N; i++)
         a2[i] = a.l[i] << 1;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BIGFIELD_NO_ASM)
+      if constexpr (N == 9) {
+        mont_sqr_asm9<PR>(r.l, a.l, a2);
+        return r;
+      } else if constexpr (N == 14) {
+        mont_sqr_asm14<PR>(r.l, a.l, a2);
+        return r;
+      }
+#endif
       uint64_t acc = 0;
 #pragma unroll
       for (int k = 0; k < 2 * N - 1; k++) {

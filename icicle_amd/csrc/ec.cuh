@@ -122,7 +122,7 @@ namespace icicle_hip {
     // madd-2008-s: 8M + 2S. Scaling: see the file header.
     static HD void madd(XYZZ& acc, bool& empty, const Aff& b)
     {
-      if (empty) {
+      if (__builtin_expect(empty, 0)) {
         acc.x = F::mul_base(b.x, F::base_r2());
         acc.y = F::mul_base(b.y, F::base_r2());
         acc.zz = F::r2();
@@ -136,7 +136,7 @@ namespace icicle_hip {
       fe P = F::template sub<(F::TIGHT ? 4 : 8)>(U2, acc.x); // <= 9.1
       fe R = F::template sub<4>(S2, acc.y);                  // <= 5.1
       fe PP = F::sqr(P);                    // <= 1.7
-      if (F::maybe_zero_mulout(PP)) {
+      if (__builtin_expect(F::maybe_zero_mulout(PP), 0)) {
         if (F::is_zero(P)) { // same x: either b == acc (double) or b == -acc (cancel)
           if (F::is_zero(R)) {
             acc = dbl_affine(b);
@@ -152,12 +152,21 @@ namespace icicle_hip {
       fe X3 = F::template sub<(F::TIGHT ? 8 : 4)>(F::sqr(R), t); // <= 5.3
       if constexpr (F::TIGHT) X3 = F::below4(X3);
       fe d = F::template sub<(F::TIGHT ? 4 : 8)>(Q, X3);         // <= 9.2
-      // Y3 = R*d - Y1*PPP = R*d + (4p - Y1)*PPP with one shared reduction (lazy, mul_add)
-      fe Y3 = F::mul_add(R, d, F::template neg<4>(acc.y), PPP); // <= 1.5
+      // Y3 = R*d - Y1*PPP = R*d + (4p - Y1)*PPP with one shared reduction (lazy, mul_add), produced in Y's own
+      // registers; ZZ, ZZZ likewise (no copies of the accumulator at the loop's back edge)
+#ifndef EC_NO_INPLACE
+      acc.y = F::template neg<4>(acc.y);
+      F::mul_add_inplace_c(acc.y, R, d, PPP); // <= 1.5
+      F::mul_inplace(acc.zz, PP);
+      F::mul_inplace(acc.zzz, PPP);
+      acc.x = X3;
+#else // A/B switch for tools/ab_lib.sh
+      fe Y3 = F::mul_add(R, d, F::template neg<4>(acc.y), PPP);
       acc.zz = F::mul(acc.zz, PP);
       acc.zzz = F::mul(acc.zzz, PPP);
       acc.x = X3;
       acc.y = Y3;
+#endif
     }
 
     // ---- complete projective arithmetic (identity = (0:1:0)) -----------------------------------

@@ -90,6 +90,8 @@ namespace icicle_hip {
       tighten(r.c1);
       return r;
     }
+    static HD void mul_inplace(fe& a, const fe& b) { a = mul(a, b); }
+    static HD void mul_add_inplace_c(fe& c, const fe& a, const fe& b, const fe& d) { c = mul_add(a, b, c, d); }
     static HD fe sqr(const fe& a)
     {
       fe r;

@@ -773,8 +773,12 @@ namespace icicle_hip {
     const uint32_t* src = sorted + wp * cap + offs[bucket] + start;
     typename E::XYZZ acc;
     bool empty = true;
+    // (Prefetching the next point's words into registers during the add was measured in round 2 and bought nothing:
+    // with 3 waves per SIMD the gather latency is already covered and the kernel sits at the VALU issue roof; the
+    // extra register moves it needed cost what it saved -- profiles/r02_notes.md. Only the index runs one ahead.)
+    uint32_t e_nxt = cnt ? src[0] : 0u;
     for (uint32_t j = 0; j < cnt; j++) {
-      const uint32_t e = src[j];
+      const uint32_t e = e_nxt;
       const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)(e & 0x7fffffffu) * PW);
       uint32_t w[PW];
 #pragma unroll
@@ -785,7 +789,8 @@ namespace icicle_hip {
         w[4 * q + 2] = v.z;
         w[4 * q + 3] = v.w;
       }
-      if (E::words_are_zero(w)) continue; // identity base: contributes nothing (cpu_msm.hpp:282)
+      e_nxt = src[min(j + 1, cnt - 1)];
+      if (__builtin_expect(E::words_are_zero(w), 0)) continue; // identity base: contributes nothing (cpu_msm.hpp:282)
       typename E::Aff a = E::cneg(E::load_plain(w), (e >> 31) != 0);
       E::madd(acc, empty, a);
     }

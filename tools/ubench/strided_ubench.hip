@@ -40,6 +40,32 @@ __global__ __launch_bounds__(512) void k_tile_copy(uint32_t* __restrict__ buf, u
   }
 }
 
+// the same tile with 16 bytes per lane: a lane owns 4 adjacent columns of a row (T/4 lanes per row)
+template <int RPT>
+__global__ __launch_bounds__(512) void k_tile_copy_v4(uint32_t* __restrict__ buf, uint64_t stride, uint32_t T, uint32_t rows, uint32_t tiles_per_a, int write)
+{
+  const uint32_t a = blockIdx.x / tiles_per_a, ct = blockIdx.x % tiles_per_a;
+  uint32_t* base = buf + (uint64_t)a * rows * stride + (uint64_t)ct * T;
+  const uint32_t T4 = T / 4, t = threadIdx.x % T4, g = threadIdx.x / T4; // g in [0, rows / RPT)
+  uint4 v[RPT];
+#pragma unroll
+  for (int m = 0; m < RPT; m++)
+    v[m] = *reinterpret_cast<const uint4*>(base + (uint64_t)(g + m * (rows / RPT)) * stride + 4 * t);
+  if (write) {
+#pragma unroll
+    for (int m = 0; m < RPT; m++) {
+      v[m].x += 1;
+      *reinterpret_cast<uint4*>(base + (uint64_t)(g + m * (rows / RPT)) * stride + 4 * t) = v[m];
+    }
+  } else {
+    uint32_t s = 0;
+#pragma unroll
+    for (int m = 0; m < RPT; m++)
+      s ^= v[m].x ^ v[m].y ^ v[m].z ^ v[m].w;
+    if (s == 0x12345678u) base[t] = s;
+  }
+}
+
 int main()
 {
   const uint64_t n = 1ull << 30; // 4 GiB
@@ -57,7 +83,8 @@ int main()
   };
   const Case cases[] = {{65536, 32, "pass 0 (stride 256 KiB, 128 B runs)"}, {256, 32, "pass 1 (stride 1 KiB, 128 B runs)"},
                         {65536, 64, "stride 256 KiB, 256 B runs"},          {256, 64, "stride 1 KiB, 256 B runs"},
-                        {32, 32, "contiguous (stride = run)"}};
+                        {32, 32, "contiguous (stride = run)"},
+                        {65536, 128, "stride 256 KiB, 512 B runs"},         {256, 128, "stride 1 KiB, 512 B runs"}};
   for (int write = 1; write >= 0; write--)
     for (const Case& c : cases) {
       const uint32_t tiles_per_a = (uint32_t)(c.stride / c.T);
@@ -75,7 +102,24 @@ int main()
         if (ms < best) best = ms;
       }
       const double bytes = (double)n * 4 * (write ? 2 : 1);
-      printf("%-44s %s  %8.3f ms  %7.0f GB/s\n", c.what, write ? "read+write" : "read only ", best, bytes / best / 1e6);
+      printf("%-44s %s  4 B/lane  %8.3f ms  %7.0f GB/s\n", c.what, write ? "read+write" : "read only ", best, bytes / best / 1e6);
+      // 16 B per lane, same tile; RPT = 16 rows per thread -> threads = (T/4) * rows/16 (>= 64), and RPT = 4 (4x the threads)
+      for (int rpt : {16, 4}) {
+        const unsigned th4 = (c.T / 4) * (rows / rpt);
+        if (th4 < 64 || th4 > 512) continue;
+        best = 1e9;
+        for (int it = 0; it < 4; it++) {
+          CK(hipEventRecord(e0));
+          if (rpt == 16) k_tile_copy_v4<16><<<ntiles, th4>>>(d, c.stride, c.T, rows, tiles_per_a, write);
+          else k_tile_copy_v4<4><<<ntiles, th4>>>(d, c.stride, c.T, rows, tiles_per_a, write);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (ms < best) best = ms;
+        }
+        printf("%-44s %s 16 B/lane x%-2d rows/thread %8.3f ms  %7.0f GB/s\n", c.what, write ? "read+write" : "read only ", rpt, best, bytes / best / 1e6);
+      }
     }
   return 0;
 }
