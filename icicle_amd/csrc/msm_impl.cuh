@@ -775,21 +775,38 @@ namespace icicle_hip {
     bool empty = true;
     // (Prefetching the next point's words into registers during the add was measured in round 2 and bought nothing:
     // with 3 waves per SIMD the gather latency is already covered and the kernel sits at the VALU issue roof; the
-    // extra register moves it needed cost what it saved -- profiles/r02_notes.md. Only the index runs one ahead.)
-    uint32_t e_nxt = cnt ? src[0] : 0u;
+    // extra register moves it needed cost what it saved -- profiles/r02_notes.md.)
+    // The list is read FOUR entries at a time, one group ahead: a lane's list is contiguous but no other lane shares
+    // its 64-byte lines, and by the time a lane came back for the next 4-byte entry (one mixed add = ~4.5 us later)
+    // the line had usually left the L2 -- each entry then cost a 64-byte fetch (PMC: 77 GB per 2^26 MSM against
+    // 59 GB of gathers + entries, profiles/r02_notes.md). The reads may run up to 7 entries past the end of the
+    // bucket's list (never used): `sorted` is allocated with that slack.
+    auto load4 = [&](uint32_t j) {
+      uint4 v;
+      __builtin_memcpy(&v, src + j, 16); // 4-byte aligned
+      return v;
+    };
+    uint4 cur = load4(0), nxt = cur;
     for (uint32_t j = 0; j < cnt; j++) {
-      const uint32_t e = e_nxt;
+      if ((j & 3u) == 0) nxt = load4(j + 4);
+      const uint32_t e = cur.x;
+      cur.x = cur.y, cur.y = cur.z, cur.z = cur.w;
+      if ((j & 3u) == 3u) cur = nxt;
       const uint4* p = reinterpret_cast<const uint4*>(bases + (size_t)(e & 0x7fffffffu) * PW);
       uint32_t w[PW];
 #pragma unroll
       for (int q = 0; q < PW / 4; q++) {
+#ifdef MSM_NT_GATHER // A/B: keep the once-used base points out of the L2 (tools/ab_lib.sh)
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p) + q);
+#else
         const uint4 v = p[q];
+#endif
         w[4 * q] = v.x;
         w[4 * q + 1] = v.y;
         w[4 * q + 2] = v.z;
         w[4 * q + 3] = v.w;
       }
-      e_nxt = src[min(j + 1, cnt - 1)];
       if (__builtin_expect(E::words_are_zero(w), 0)) continue; // identity base: contributes nothing (cpu_msm.hpp:282)
       typename E::Aff a = E::cneg(E::load_plain(w), (e >> 31) != 0);
       E::madd(acc, empty, a);
@@ -1179,7 +1196,7 @@ namespace icicle_hip {
     if (stage_bases) HIP_TRY(d_mont.alloc((shared ? 1 : (size_t)BB) * npts_one * PW * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_dig.alloc((size_t)BB * pl.nwin * n * 4, st), ICICLE_ALLOCATION_FAILED);
     if (!single_level) HIP_TRY(d_partA.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_sorted.alloc(TW * cap * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_sorted.alloc(TW * cap * 4 + 64, st), ICICLE_ALLOCATION_FAILED); // + slack: k_accumulate reads lists in groups of 4
     HIP_TRY(d_cntA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_offA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_bstart.alloc((nparts + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
