@@ -66,6 +66,44 @@ __global__ __launch_bounds__(512) void k_tile_copy_v4(uint32_t* __restrict__ buf
   }
 }
 
+// the same tile moved the way an LDS-DMA column pass would: global_load_lds_dwordx4 into LDS (no VGPR staging), the next
+// batch row's tile in flight while the current one is "processed" (read back from LDS 16 B per lane) and stored
+// 16 B per lane. 512 threads, 2 x 32 KiB LDS per block (2 blocks per CU), block = one tile position x `nrows` batch rows.
+__global__ __launch_bounds__(512, 4) void k_tile_dma(uint32_t* __restrict__ buf, uint64_t stride, uint32_t tiles_per_a, uint64_t row_elems, uint32_t nrows)
+{
+  constexpr uint32_t T = 32, ROWS = 256;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][ROWS * T];
+  const uint32_t a = blockIdx.x / tiles_per_a, ct = blockIdx.x % tiles_per_a;
+  uint32_t* base = buf + (uint64_t)a * ROWS * stride + (uint64_t)ct * T;
+  const uint32_t c4 = threadIdx.x % 8, r0 = threadIdx.x / 8; // 8 lanes per 128-B row, 64 rows per sweep
+  const uint32_t wave = threadIdx.x / 64;
+  auto issue = [&](uint32_t brow, uint32_t which) {
+    const uint32_t* src = base + (uint64_t)brow * row_elems;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const uint32_t row = r0 + 64 * m;
+      // LDS destination of a wave-instruction: wave-uniform base + lane * 16: rows (8 * wave + 64 * m) .. + 7
+      __builtin_amdgcn_global_load_lds(src + (uint64_t)row * stride + 4 * c4, &lds[which][(8 * wave + 64 * m) * T], 16, 0, 0);
+    }
+  };
+  issue(0, 0);
+  for (uint32_t b = 0; b < nrows; b++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (b + 1 < nrows) issue(b + 1, (b + 1) & 1);
+    uint32_t* dst = base + (uint64_t)b * row_elems;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      const uint32_t row = r0 + 64 * m;
+      uint4 v = *reinterpret_cast<const uint4*>(&lds[b & 1][row * T + 4 * c4]);
+      v.x += 1;
+      *reinterpret_cast<uint4*>(dst + (uint64_t)row * stride + 4 * c4) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
 int main()
 {
   const uint64_t n = 1ull << 30; // 4 GiB
@@ -121,5 +159,25 @@ int main()
         printf("%-44s %s 16 B/lane x%-2d rows/thread %8.3f ms  %7.0f GB/s\n", c.what, write ? "read+write" : "read only ", rpt, best, bytes / best / 1e6);
       }
     }
+  { // LDS-DMA variant: 64 batch rows of 2^24 elements, pass-0 and pass-1 patterns, 32 batch rows per block
+    const uint64_t row_elems = 1ull << 24;
+    const uint32_t batch = (uint32_t)(n / row_elems), rpb = 32;
+    for (uint64_t stride : {65536ull, 256ull}) {
+      const uint32_t tiles_per_a = (uint32_t)(stride / 32);
+      const uint32_t ntiles = (uint32_t)(row_elems / (256 * stride)) * tiles_per_a;
+      float best = 1e9;
+      for (int it = 0; it < 4; it++) {
+        CK(hipEventRecord(e0));
+        for (uint32_t g = 0; g < batch / rpb; g++)
+          k_tile_dma<<<ntiles, 512>>>(d + (uint64_t)g * rpb * row_elems, stride, tiles_per_a, row_elems, rpb);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+      }
+      printf("LDS-DMA in, 16 B/lane out, stride %6llu elements, 128 B runs, 32 rows per block   read+write %8.3f ms  %7.0f GB/s\n", (unsigned long long)stride, best, (double)n * 8 / best / 1e6);
+    }
+  }
   return 0;
 }
