@@ -15,6 +15,7 @@
 //                                    all-to-all over xGMI), adds the slices and reduces only its own slice; the
 //                                    per-slice results then take the E1 exchange. E2 strong-scales the bucket
 //                                    reduction at the price of moving W*2^(c-1)*sizeof(projective)/G bytes per peer.
+//   "hip_force_rccl"           bool  use the RCCL exchange even with one physical device (size-1 communicator): test hook.
 //
 // One host thread and one stream per physical device (the reference's own model, applied inside the call). The
 // call is synchronous with respect to the host whatever is_async says. Inputs may live on the host or on the
@@ -92,7 +93,7 @@ namespace icicle_hip {
   };
 
   template <class C>
-  static icicle_error_t msm_multi_run(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v, int G, bool exchange_buckets)
+  static icicle_error_t msm_multi_run(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v, int G, bool exchange_buckets, bool force_rccl)
   {
     using E = EC<C>;
     constexpr int PW = 2 * E::N32, RW = 3 * E::N32, SW = 8;
@@ -124,8 +125,11 @@ namespace icicle_hip {
     sub.are_scalars_on_device = sub.are_points_on_device = sub.are_results_on_device = true;
     sub.is_async = true;
 
+    // "hip_force_rccl": take the RCCL exchange even with ONE physical device (communicator of size 1), so that the
+    // loader, ncclCommInitAll and ncclAllGather bindings are exercised on a single-GPU box (tests)
+    const bool use_rccl = P > 1 || force_rccl;
     std::vector<void*> comms(P, nullptr);
-    if (P > 1) {
+    if (use_rccl) {
       if (!rccl_api()) {
         fprintf(stderr, "[icicle_hip] hip_num_devices > 1 needs librccl.so (not loadable)\n");
         return ICICLE_API_NOT_IMPLEMENTED;
@@ -185,7 +189,7 @@ namespace icicle_hip {
           LAUNCH_CHECK("k_proj_sum(shards)", st);
         }
         const uint32_t* result = devpart.as<uint32_t>();
-        if (P > 1) { // "all-reduce" of partial sums: EC addition is not an RCCL reduce op -> all-gather + local projective sum
+        if (use_rccl) { // "all-reduce" of partial sums: EC addition is not an RCCL reduce op -> all-gather + local projective sum
           const RcclApi* api = rccl_api();
           HIP_TRY(gathered.alloc((size_t)P * batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
           HIP_TRY(fin.alloc((size_t)batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
@@ -233,7 +237,7 @@ namespace icicle_hip {
     if (cfg->ext) {
       const ConfigExt* e = reinterpret_cast<const ConfigExt*>(cfg->ext);
       const int G = e->get_int("hip_num_devices", 0);
-      if (G >= 1) return msm_multi_run<C>(scalars_v, bases_v, n, cfg, results_v, G, e->get_bool("hip_msm_exchange_buckets", false));
+      if (G >= 1) return msm_multi_run<C>(scalars_v, bases_v, n, cfg, results_v, G, e->get_bool("hip_msm_exchange_buckets", false), e->get_bool("hip_force_rccl", false));
     }
     return msm_run_single<C>(scalars_v, bases_v, n, cfg, results_v);
   }

@@ -186,3 +186,30 @@ def test_msm_multi_device_through_c_abi(hip, cname, G, mode):
         assert np.array_equal(refc.to_affine(got2), exp2), (cname, G, mode, "device batch")
     finally:
         lib.destroy_config_extension(ext)
+
+
+def test_rccl_binding_with_size_one_communicator(hip):
+    """"hip_force_rccl": the RCCL leg of the in-library multi-device MSM (dlopen of librccl, ncclCommInitAll,
+    ncclAllGather on the call's stream, k_proj_sum over the gathered partials) run with a communicator of size 1 --
+    everything of the P > 1 exchange that a single-GPU box can execute."""
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib
+
+    C = pyref.BN254
+    refc = ref.RefCurve("bn254")
+    rng = np.random.default_rng(123)
+    n = 4099
+    bases = points_to_array(C, cached_points(C, n))
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    ext = lib.create_config_extension()
+    try:
+        lib.config_extension_set_int(ext, b"hip_num_devices", 3)  # 3 logical shards on the one device
+        lib.config_extension_set_bool(ext, b"hip_force_rccl", True)
+        for xb in (False, True):
+            lib.config_extension_set_bool(ext, b"hip_msm_exchange_buckets", xb)
+            cfg = hip.MSMConfig.default()
+            cfg.ext = ext
+            got = M.msm("bn254", sc, bases, cfg)
+            assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(sc, bases))), xb
+    finally:
+        lib.destroy_config_extension(ext)
