@@ -46,6 +46,11 @@ namespace icicle_hip {
     p.bits = (cfg.bitsize > 0 && cfg.bitsize < scalar_bits) ? cfg.bitsize : scalar_bits;
     p.pf = std::max(1, cfg.precompute_factor);
     int c = cfg.c;
+    // A precomputed base table fixes the doubling shift c * wpf, so msm_precompute_bases(nof_bases) and msm(msm_size)
+    // must agree on c. The reference derives it from the size on both sides (cpu_msm.hpp:466 vs :207), which only
+    // agrees when nof_bases == msm_size; here an unspecified c is size-independent whenever precompute_factor > 1,
+    // so shared and per-MSM base tables of any batch shape work (pass config.c on both calls to tune it).
+    if (c <= 0 && p.pf > 1) c = 16;
     if (c <= 0) {
       // minimise  (#mixed adds) + (bucket-reduction adds, weighted for their poor parallelism)
       double best = 1e300;

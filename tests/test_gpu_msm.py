@@ -225,6 +225,33 @@ def test_msm_precompute(hip, cname):
         assert np.array_equal(refc.to_affine(got), exp), pf
 
 
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_precompute_non_shared_batch(hip, cname):
+    """per-MSM base tables: msm_precompute_bases over batch * n bases, msm with are_points_shared_in_batch = false
+    (nof_bases != msm_size: the window size must not depend on either), plus a different msm_size on the same table"""
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(33)
+    n, batch, pf = 300, 3, 4
+    bases = points_to_array(C, cached_points(C, n * batch))
+    sc = to_words(rand_scalars(rng, n * batch, C.r), 8)
+    exp = refc.to_affine(refc.msm(sc, bases, batch=batch, shared=False))
+    cfg = hip.MSMConfig.default()
+    cfg.precompute_factor = pf
+    pre = M.precompute_bases(cname, bases, cfg)  # nof_bases = batch * n
+    cfg.batch_size = batch
+    cfg.are_points_shared_in_batch = False
+    got = M.msm(cname, sc, pre, cfg)
+    assert np.array_equal(refc.to_affine(got), exp)
+    # the first 100 bases of the same table, as a single MSM of a different size
+    cfg1 = hip.MSMConfig.default()
+    cfg1.precompute_factor = pf
+    got1 = M.msm(cname, np.ascontiguousarray(sc[:100]), np.ascontiguousarray(pre[: 100 * pf]), cfg1)
+    assert np.array_equal(refc.to_affine(got1), refc.to_affine(refc.msm(np.ascontiguousarray(sc[:100]), np.ascontiguousarray(bases[:100]))))
+
+
 def test_generated_points_are_distinct_multiples_of_g(hip):
     from icicle_amd import msm as M
 
