@@ -16,7 +16,7 @@
 //      point and does an XYZZ mixed add entirely in registers -- ~77 % of the time at 2^26,
 //      integer-ALU bound (v_mad_u64_u32), see DESIGN.md. Buckets longer than `seg` points are
 //      split (k_plan_overflow) and their partial sums folded back in parallel (k_fold_overflow).
-//   5. bucket reduction: k_reduce_segments (running sums per segment) -> k_reduce_window (256
+//   5. bucket reduction: k_reduce_wave (wave64 suffix scans over 64*m-bucket chunks) -> k_reduce_window (256
 //      lanes per window) -> k_final (128 lanes per MSM, Horner over windows).
 // A batch of MSMs is folded into the window dimension: all of the above is launched once for up
 // to BB MSMs x wpf windows.
@@ -855,56 +855,135 @@ namespace icicle_hip {
   }
 
   // ------------------------------------------------------------------------------------------
-  // 5a. per-segment running sums. Segment = m consecutive buckets [k0, k0+m) of one window;
-  //     val = sum_{k} (k+1) * B_k  =  tri + k0 * line   (bucket index k carries weight k+1).
-  //     Only segments [seg_lo, seg_lo + nsegr) of every window are reduced (the whole window unless a multi-device
-  //     bucket exchange left this device a slice of the buckets); segval is compact: [window][nsegr].
+  // 5a/5b. bucket reduction of a window, S = sum_k (k+1) * B_k, with wave64 scans.
+  //
+  // A chunk = 64*m consecutive buckets [k0, k0 + 64m) is owned by ONE WAVE, lane l taking buckets k0 + 64 i + l,
+  // i < m -- so every step of the wave reads 64 consecutive buckets (coalesced), unlike a thread-per-segment walk.
+  // With (k+1) = (k0+1) + 64 i + l and, per lane, line_l = sum_i B (column sum) and tri0_l = sum_i i*B (zero-based
+  // running sum, two complete adds per bucket):
+  //     S_chunk = (k0+1) * T + 64 * sum_l tri0_l + sum_l l * line_l ,   T = sum_l line_l
+  // and sum_l l*line_l = sum_l X_l with X_l = sum_{l' > l} line_l' -- an exclusive SUFFIX SCAN across the lanes of the
+  // wave (6 shuffle + add steps). So a wave emits V = sum_l (64 * tri0_l + X_l) (one more 6-step wave reduction) and T;
+  // the per-window kernel repeats the same trick over chunks: S = sum_c (V_c + T_c) + 64m * sum_c c * T_c, the last
+  // sum again a suffix scan, across the block. No scalar multiplication anywhere (round 1 paid a ~19-doubling
+  // mul_small per 32-bucket segment), 2 + 13/m adds per bucket.
+  // Only chunks [seg_lo, seg_lo + nsegr) of every window are reduced (the whole window unless a multi-device bucket
+  // exchange left this device a slice); the chunk outputs are compact: [window][nsegr].
   template <class C>
-  __global__ __launch_bounds__(64) void k_reduce_segments(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ segval, uint32_t nb, uint32_t m, int wpf, uint32_t seg_lo, uint32_t nsegr)
-  {
-    using E = EC<C>;
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= (size_t)wpf * nsegr) return;
-    const size_t wp = t / nsegr;
-    const uint32_t seg = seg_lo + (uint32_t)(t % nsegr);
-    const uint32_t k0 = seg * m;
-    const typename E::Proj* b = buckets + wp * nb + k0;
-    typename E::Proj line = E::proj_identity(), tri = E::proj_identity();
-    for (int k = (int)m - 1; k >= 0; k--) {
-      line = E::add(line, b[k]);
-      tri = E::add(tri, line);
-    }
-    if (k0) tri = E::add(tri, E::mul_small(line, k0));
-    segval[t] = tri;
-  }
-
-  // 5b. one 256-thread block per window (128 where 256 projective points would not fit the 64 KiB
-  //     of static LDS, i.e. G2 over BLS12-381): each thread folds nseg/RWL segment values, then a tree
-  //     through LDS (4 waves keep the serial part short: it is latency-, not throughput-bound)
-  template <class C>
-  struct ReduceWindowLanes {
+  struct ReduceWindowLanes { // block size of the per-window kernel (its LDS holds one projective point per thread)
     static constexpr int value = (sizeof(typename EC<C>::Proj) * 256 <= 60 * 1024) ? 256 : 128;
   };
+  template <class P>
+  __device__ __forceinline__ P proj_shfl_down(const P& v, int d)
+  {
+    static_assert(sizeof(P) % 4 == 0, "projective point is a whole number of words");
+    P r;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(P) / 4; i++)
+      dst[i] = __shfl_down(src[i], d);
+    return r;
+  }
+  // inclusive suffix sum over the 64 lanes of a wave: lane l gets sum_{l' >= l} v_l'
   template <class C>
-  __global__ __launch_bounds__(ReduceWindowLanes<C>::value) void k_reduce_window(const typename EC<C>::Proj* __restrict__ segval, typename EC<C>::Proj* __restrict__ winsum, uint32_t nseg)
+  __device__ __forceinline__ typename EC<C>::Proj wave_suffix_sum(typename EC<C>::Proj v, int lane)
+  {
+    using E = EC<C>;
+    for (int d = 1; d < 64; d <<= 1) {
+      const typename E::Proj o = proj_shfl_down(v, d);
+      if (lane + d < 64) v = E::add(v, o);
+    }
+    return v;
+  }
+  // sum over the wave, valid in lane 0
+  template <class C>
+  __device__ __forceinline__ typename EC<C>::Proj wave_sum(typename EC<C>::Proj v, int lane)
+  {
+    using E = EC<C>;
+    for (int d = 32; d >= 1; d >>= 1) {
+      const typename E::Proj o = proj_shfl_down(v, d);
+      if (lane < d) v = E::add(v, o);
+    }
+    return v;
+  }
+
+  template <class C>
+  __global__ __launch_bounds__(64) void k_reduce_wave(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ chunkV, typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum_direct, uint32_t nb, uint32_t m, uint32_t seg_lo, uint32_t nsegr)
+  {
+    using E = EC<C>;
+    const int lane = threadIdx.x;
+    const size_t wp = blockIdx.x / nsegr;
+    const uint32_t ch = seg_lo + blockIdx.x % nsegr;
+    const uint32_t k0 = ch * 64u * m;
+    const typename E::Proj* b = buckets + wp * nb;
+    typename E::Proj line = E::proj_identity(), tri0 = E::proj_identity();
+    for (int i = (int)m - 1; i >= 0; i--) {
+      const uint32_t k = k0 + 64u * (uint32_t)i + (uint32_t)lane;
+      tri0 = E::add(tri0, line);
+      if (k < nb) line = E::add(line, b[k]);
+    }
+    const typename E::Proj suf = wave_suffix_sum<C>(line, lane); // lane 0: T
+    typename E::Proj x = proj_shfl_down(suf, 1);                 // exclusive suffix
+    if (lane == 63) x = E::proj_identity();
+    for (int q = 0; q < 6; q++)
+      tri0 = E::dbl(tri0); // 64 * tri0
+    const typename E::Proj v = wave_sum<C>(E::add(x, tri0), lane);
+    if (lane == 0) {
+      if (winsum_direct) { // the chunk is the whole window (small windows, batches of small MSMs): S = V + T
+        winsum_direct[blockIdx.x] = E::add(v, suf);
+      } else {
+        chunkV[blockIdx.x] = v;
+        chunkT[blockIdx.x] = suf;
+      }
+    }
+  }
+
+  // per window: S = sum_c (V_c + T_c) + chunk * sum_c c * T_c over the nsegr <= blockDim chunks of this device's slice
+  // (c = global chunk index = seg_lo + local index)
+  template <class C>
+  __global__ __launch_bounds__(ReduceWindowLanes<C>::value) void k_reduce_window(const typename EC<C>::Proj* __restrict__ chunkV, const typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum, uint32_t nsegr, uint32_t seg_lo, uint32_t log_chunk)
   {
     using E = EC<C>;
     constexpr int RWL = ReduceWindowLanes<C>::value;
     __shared__ typename E::Proj sh[RWL];
-    const int wp = blockIdx.x, lane = threadIdx.x;
-    typename E::Proj v = E::proj_identity();
-    for (uint32_t s = lane; s < nseg; s += RWL)
-      v = E::add(v, segval[(size_t)wp * nseg + s]);
-    sh[lane] = v;
+    const int NW = blockDim.x / 64; // launched with the power of two >= nsegr (64 .. RWL threads)
+    const int wp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool have = (uint32_t)tid < nsegr;
+    const typename E::Proj t = have ? chunkT[(size_t)wp * nsegr + tid] : E::proj_identity();
+    typename E::Proj u = have ? E::add(chunkV[(size_t)wp * nsegr + tid], t) : E::proj_identity();
+    // exclusive suffix sum of T over the block
+    const typename E::Proj suf = wave_suffix_sum<C>(t, lane);
+    if (lane == 0) sh[wave] = suf; // wave totals
     __syncthreads();
-    for (int s = RWL / 2; s >= 1; s >>= 1) {
-      if (lane < s) {
-        v = E::add(v, sh[lane + s]);
-        sh[lane] = v;
-      }
-      __syncthreads();
+    typename E::Proj x = proj_shfl_down(suf, 1);
+    if (lane == 63) x = E::proj_identity();
+    typename E::Proj ttot = E::proj_identity(); // sum of T over the whole block (needed for a slice that does not start at 0)
+    for (int w = NW - 1; w >= 0; w--) {
+      if (w > wave) x = E::add(x, sh[w]);
+      ttot = E::add(ttot, sh[w]);
     }
-    if (lane == 0) winsum[wp] = v;
+    __syncthreads();
+    auto block_sum = [&](typename E::Proj v) { // valid in thread 0
+      sh[tid] = v;
+      __syncthreads();
+      for (int s2 = blockDim.x / 2; s2 >= 1; s2 >>= 1) {
+        if (tid < s2) {
+          v = E::add(v, sh[tid + s2]);
+          sh[tid] = v;
+        }
+        __syncthreads();
+      }
+      return v;
+    };
+    const typename E::Proj U = block_sum(u);
+    typename E::Proj X = block_sum(x);
+    if (tid == 0) {
+      if (seg_lo) X = E::add(X, E::mul_small(ttot, seg_lo));
+      for (uint32_t q = 0; q < log_chunk; q++)
+        X = E::dbl(X);
+      winsum[wp] = E::add(U, X);
+    }
   }
 
   // 5c. window combine: result = sum_w 2^(c*w) * winsum[w], written in the reference's
@@ -1171,8 +1250,15 @@ namespace icicle_hip {
     }
     const bool single_level = (sp.lb == 0);
     const size_t nparts_w = (size_t)1 << sp.hb;
-    const uint32_t m = std::min<uint32_t>(nb, 32);
-    const uint32_t nseg = nb / m;
+    // bucket reduction geometry: a wave owns a chunk of 64*mrow buckets; at most RWL chunks per window (one thread of
+    // the per-window kernel each), at least 16 rows per lane when the window is big enough to amortise the wave scans
+    constexpr uint32_t RWL = ReduceWindowLanes<C>::value;
+    const uint32_t mrow = std::max<uint32_t>(1, std::max<uint32_t>(nb / (64 * RWL), std::min<uint32_t>(16, nb / 64)));
+    const uint32_t m = 64 * mrow;                       // buckets per chunk ("segment" of the exchange hook)
+    const uint32_t nseg = std::max<uint32_t>(1, nb / m); // chunks per window
+    uint32_t log_chunk = 0;
+    while ((1u << log_chunk) < m)
+      log_chunk++;
 
     // ---- batch folding: BB MSMs of the batch run as ONE launch sequence with BB*wpf windows
     // (wrappers/rust/icicle-core/src/msm/tests.rs:92-254 batches; small MSMs would otherwise leave the
@@ -1209,7 +1295,7 @@ namespace icicle_hip {
     HIP_TRY(d_offs.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_cursor.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_buckets.alloc(nbk * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_seg.alloc(TW * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_seg.alloc(2 * TW * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED); // chunk V | chunk T
     HIP_TRY(d_win.alloc(TW * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
@@ -1345,13 +1431,20 @@ namespace icicle_hip {
         ICICLE_TRY(hook->after_accumulate(buckets, tw, nb, nseg, m, st, &skip, &seg_lo, &nsegr));
         if (skip) continue; // another shard of this device (or the exchange step) produces the result
       }
-      const size_t nsg = tw * nsegr;
-      if (nsg) {
-        k_reduce_segments<C><<<(unsigned)((nsg + 63) / 64), 64, 0, st>>>(buckets, d_seg.as<typename E::Proj>(), nb, m, (int)tw, seg_lo, nsegr);
-        LAUNCH_CHECK("k_reduce_segments", st);
+      typename E::Proj* chunkV = d_seg.as<typename E::Proj>();
+      typename E::Proj* chunkT = chunkV + TW * nseg;
+      const bool direct = (nseg == 1 && nsegr == 1 && seg_lo == 0);
+      if (tw * nsegr) {
+        k_reduce_wave<C><<<(unsigned)(tw * nsegr), 64, 0, st>>>(buckets, chunkV, chunkT, direct ? d_win.as<typename E::Proj>() : nullptr, nb, mrow, seg_lo, nsegr);
+        LAUNCH_CHECK("k_reduce_wave", st);
       }
-      k_reduce_window<C><<<(unsigned)tw, ReduceWindowLanes<C>::value, 0, st>>>(d_seg.as<typename E::Proj>(), d_win.as<typename E::Proj>(), nsegr);
-      LAUNCH_CHECK("k_reduce_window", st);
+      if (!direct) {
+        unsigned rthreads = 64; // power of two (LDS tree), >= nsegr
+        while (rthreads < nsegr && rthreads < RWL)
+          rthreads <<= 1;
+        k_reduce_window<C><<<(unsigned)tw, rthreads, 0, st>>>(chunkV, chunkT, d_win.as<typename E::Proj>(), nsegr, seg_lo, log_chunk);
+        LAUNCH_CHECK("k_reduce_window", st);
+      }
       k_final<C><<<bb, 128, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c);
       LAUNCH_CHECK("k_final", st);
     }
