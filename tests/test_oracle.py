@@ -167,3 +167,23 @@ def test_reference_build_matches_new_row_goldens(cname):
         assert np.array_equal(r1.to_affine(r1.ecntt(s["ec_points"], 32, 0).reshape(32, 3 * L)), s["ec_fwd_NN_affine"])
     finally:
         sf.release_domain()
+
+
+def test_reference_test_binaries_host_arithmetic_suite():
+    """The reference's own test sources compiled against the GoogleTest stand-in (oracle/build_ref_tests.sh): the part
+    that needs no device under test -- CurveSanity (host curve arithmetic of the reference) -- must pass on the CPU.
+    Pins the stand-in itself (TYPED_TEST registration, ASSERT_EQ on points, filters) without a GPU."""
+    import os
+    import subprocess
+
+    import pytest
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "tests", "test_curve_api_bn254")
+    if not os.path.exists(exe):
+        pytest.skip("reference tests not built (oracle/build_ref_tests.sh needs /root/reference)")
+    r = subprocess.run([exe, "--gtest_filter=CurveSanity*"], capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "[  PASSED  ] 4 tests." in out, out[-2000:]
+    lst = subprocess.run([exe, "--gtest_list_tests"], capture_output=True, text=True, timeout=60).stdout
+    for name in ("CurveApiTest.msm", "CurveApiTest.msm_bitsize", "CurveApiTest.msmG2", "CurveApiTest.ecntt", "CurveSanity/1.ScalarMultTest"):
+        assert name in lst
