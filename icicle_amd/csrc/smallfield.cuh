@@ -36,10 +36,12 @@ namespace icicle_hip {
     // t < p * 2^32  ->  t / 2^32 mod p, in [0,p)
     static SF_HD uint32_t mont_reduce(uint64_t t)
     {
-      uint32_t m = (uint32_t)t * PR::PINV;
-      uint32_t u = (uint32_t)(((uint64_t)m * P) >> 32);
-      uint32_t r = (uint32_t)(t >> 32) - u;
-      return umin(r, r + P);
+      // t + m'*p in ONE v_mad_u64_u32 with m' = -t/p mod 2^32: the sum is divisible by 2^32 and below 2p*2^32 (no
+      // carry out of 64 bits since t, m'*p < p*2^32), so its high word is the result in [0, 2p) -- 5 instructions per
+      // product instead of 6 for the subtract-the-high-words form (64 x 2^24 BabyBear: 6.06 -> 5.98 ms, same box)
+      uint32_t m = (uint32_t)t * (0u - PR::PINV);
+      uint32_t r = (uint32_t)((t + (uint64_t)m * P) >> 32);
+      return umin(r, r - P);
     }
     static SF_HD uint32_t mul(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }
     static SF_HD uint32_t to_mont(uint32_t x) { return mul(x, PR::R2); }
