@@ -31,6 +31,16 @@ __global__ __launch_bounds__(256) void k_alu(uint32_t* out, uint32_t seed)
     for (int i = 0; i < CH; i++) {
       if constexpr (OP == 0) { // v_mad_u64_u32
         asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[i]) : "v"(a[i]), "v"(b[i]) : "vcc");
+      } else if constexpr (OP == 19) { // v_mad_u64_u32 with an SGPR multiplicand (the m*p half of a Montgomery product)
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[i]) : "v"(a[i]), "s"(seed) : "vcc");
+      } else if constexpr (OP == 20) { // dependent chain of v_mad_u64_u32 through ONE accumulator (what mont_asm.cuh issues)
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[0]) : "v"(a[i]), "v"(b[i]) : "vcc");
+      } else if constexpr (OP == 21) { // v_mov_b32
+        asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b[i]));
+      } else if constexpr (OP == 22) { // v_lshrrev_b64
+        asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(c[i]));
+      } else if constexpr (OP == 23) { // v_and_b32
+        asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(a[i]));
       } else if constexpr (OP == 1) { // v_mul_lo_u32
         asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
       } else if constexpr (OP == 2) { // v_mul_hi_u32
@@ -152,6 +162,11 @@ int main()
   uint32_t* d_out; CK(hipMalloc(&d_out, 256 * 8 * 256 * 4 * 4));
   run<0>("v_mad_u64_u32", 1, d_out);
   run<13>("v_mad_i64_i32", 1, d_out);
+  run<19>("v_mad_u64_u32 (sgpr src)", 1, d_out);
+  run<20>("v_mad_u64_u32 (1 dep chain)", 1, d_out);
+  run<21>("v_mov_b32", 1, d_out);
+  run<22>("v_lshrrev_b64", 1, d_out);
+  run<23>("v_and_b32 (literal)", 1, d_out);
   run<1>("v_mul_lo_u32", 1, d_out);
   run<2>("v_mul_hi_u32", 1, d_out);
   run<3>("v_mul_u32_u24", 1, d_out);
