@@ -305,6 +305,60 @@ namespace icicle_hip {
       return r;
     }
 
+#if defined(__HIPCC__)
+    // ---- doubling spread over the four lanes of a DPP quad (k_final's Horner chains) -----------------------------
+    // A chain of ~250 dependent doublings on ONE wave is pure latency (7 dependent products per step, ~4.4 us each on
+    // gfx950: the floor of every small MSM). The 2M + 5S of dbl_jac have depth 3: {X^2, Y^2, YZ} -> {(3X^2)^2, Y^4,
+    // (X + Y^2)^2} -> E (D - X3). All four lanes of a quad hold the same point; lane `role` computes one product of
+    // each level, the results are broadcast with quad_perm DPP moves, and the cheap linear steps run redundantly.
+    // Same operands, same bounds and the same values as dbl_jac, three product latencies per step instead of seven.
+    template <int SRC>
+    static __device__ __forceinline__ fe quad_bcast(const fe& v)
+    {
+      constexpr int NW = sizeof(fe) / 4;
+      uint32_t w[NW];
+      __builtin_memcpy(w, &v, sizeof(fe));
+#pragma unroll
+      for (int i = 0; i < NW; i++)
+        w[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)w[i], (int)w[i], SRC * 0x55, 0xF, 0xF, false); // quad_perm [SRC x 4]
+      fe r = v; // keeps the (host-checker-only) bound annotation
+      __builtin_memcpy(&r, w, sizeof(fe));
+      return r;
+    }
+    static __device__ __forceinline__ fe lane_select(bool c, const fe& a, const fe& b)
+    {
+      constexpr int NW = sizeof(fe) / 4;
+      uint32_t x[NW], y[NW];
+      __builtin_memcpy(x, &a, sizeof(fe));
+      __builtin_memcpy(y, &b, sizeof(fe));
+#pragma unroll
+      for (int i = 0; i < NW; i++)
+        x[i] = c ? x[i] : y[i];
+      fe r = a;
+      __builtin_memcpy(&r, x, sizeof(fe));
+      return r;
+    }
+    static __device__ __forceinline__ Jac dbl_jac_quad(const Jac& p, uint32_t role)
+    {
+      // level 1: role 0: X*X, role 1: Y*Y, roles 2, 3: Y*Z
+      const fe l1 = F::mul(lane_select(role == 0, p.x, p.y), lane_select(role == 0, p.x, lane_select(role == 1, p.y, p.z)));
+      const fe A = quad_bcast<0>(l1), B = quad_bcast<1>(l1), YZ = quad_bcast<2>(l1);
+      // level 2: role 0: E^2 (E = 3A), role 1: B^2, roles 2, 3: (X + B)^2
+      const fe E = F::add(F::dbl(A), A);
+      const fe l2 = F::sqr(lane_select(role == 0, E, lane_select(role == 1, B, F::add(p.x, B))));
+      const fe Fv = quad_bcast<0>(l2), CC = quad_bcast<1>(l2), t = quad_bcast<2>(l2);
+      const fe D = F::below4(F::dbl(F::template sub<4>(t, F::add(A, CC))));
+      Jac r;
+      r.x = F::below4(F::template sub<8>(Fv, F::dbl(D)));
+      // level 3 (every lane): E (D - X3)
+      const fe m = F::mul(E, F::template sub<4>(D, r.x));
+      const fe c8 = F::dbl(F::below4(F::dbl(F::dbl(CC))));
+      r.y = F::below4(F::template sub<8>(m, c8));
+      r.z = F::dbl(YZ);
+      return r;
+    }
+#endif
+
     // k * p for a small unsigned k (bucket reduction segment offsets), MSB-first double-and-add
     static HD Proj mul_small(const Proj& p, uint32_t k)
     {

@@ -17,7 +17,7 @@
 //      integer-ALU bound (v_mad_u64_u32), see DESIGN.md. Buckets longer than `seg` points are
 //      split (k_plan_overflow) and their partial sums folded back in parallel (k_fold_overflow).
 //   5. bucket reduction: k_reduce_wave (wave64 suffix scans over 64*m-bucket chunks) -> k_reduce_window (256
-//      lanes per window) -> k_final (128 lanes per MSM, Horner over windows).
+//      lanes per window) -> k_final (4 lanes per window, Horner over windows).
 // A batch of MSMs is folded into the window dimension: all of the above is launched once for up
 // to BB MSMs x wpf windows.
 //
@@ -993,34 +993,45 @@ namespace icicle_hip {
   //     LDS. <1 % of the work at 2^26, but the latency floor of a small MSM.
   //     (A <<<1,1>>> serial Horner is provably wave-uniform, so hipcc compiles ALL of its field
   //     arithmetic to SALU code, which is several times slower per multiply than the VALU path.)
+  // threads of k_final: 4 lanes per window; G1 covers the 128 possible windows at once, the Fq2 curves keep the block
+  // at 256 threads (one wave per SIMD: the complete addition over Fq2 wants the whole register file)
   template <class C>
-  __global__ __launch_bounds__(128) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c)
+  struct FinalThreads {
+    static constexpr int value = sizeof(typename EC<C>::fe) > 64 ? 256 : 512;
+  };
+  template <class C>
+  __global__ __launch_bounds__(FinalThreads<C>::value) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c)
   {
     using E = EC<C>;
     __shared__ typename E::Proj sh[128];
-    const int lane = threadIdx.x;
+    // four lanes per window: the doubling chain 2^(c*w) * S_w is the latency floor of the whole MSM, and a quad
+    // runs it with three dependent products per step instead of seven (ec.cuh dbl_jac_quad)
+    const uint32_t role = threadIdx.x & 3u;
     winsum += (size_t)blockIdx.x * wpf;
     result += (size_t)blockIdx.x * 3 * E::N32;
-    typename E::Proj v = E::proj_identity();
-    if (lane < wpf) {
-      v = winsum[lane];
-      if (lane > 0) { // 2^(c*lane) * v: Jacobian doubling chain (ec.cuh), 2M + 5S per step
-        typename E::Jac j = E::to_jac(v);
-        for (int i = 0; i < lane * c; i++)
-          j = E::dbl_jac(j);
-        v = E::from_jac(j);
+    for (int w = threadIdx.x >> 2; w < 128; w += FinalThreads<C>::value >> 2) {
+      typename E::Proj v = E::proj_identity();
+      if (w < wpf) {
+        v = winsum[w];
+        if (w > 0) { // Jacobian doubling chain (ec.cuh), 2M + 5S per step
+          typename E::Jac j = E::to_jac(v);
+          for (int i = 0; i < w * c; i++) // the same trip count in all four lanes of a quad
+            j = E::dbl_jac_quad(j, role);
+          v = E::from_jac(j);
+        }
       }
+      if (role == 0) sh[w] = v;
     }
-    sh[lane] = v;
     __syncthreads();
-    for (int s = 64; s >= 1; s >>= 1) {
-      if (lane < s) {
-        v = E::add(v, sh[lane + s]);
-        sh[lane] = v;
-      }
+    int top = 1;
+    while (top < wpf)
+      top <<= 1;
+    const int lane = threadIdx.x;
+    for (int s = top >> 1; s >= 1; s >>= 1) {
+      if (lane < s) sh[lane] = E::add(sh[lane], sh[lane + s]);
       __syncthreads();
     }
-    if (lane == 0) E::store_proj_canonical(result, v);
+    if (lane == 0) E::store_proj_canonical(result, sh[0]);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -1445,7 +1456,7 @@ namespace icicle_hip {
         k_reduce_window<C><<<(unsigned)tw, rthreads, 0, st>>>(chunkV, chunkT, d_win.as<typename E::Proj>(), nsegr, seg_lo, log_chunk);
         LAUNCH_CHECK("k_reduce_window", st);
       }
-      k_final<C><<<bb, 128, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c);
+      k_final<C><<<bb, FinalThreads<C>::value, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c);
       LAUNCH_CHECK("k_final", st);
     }
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
