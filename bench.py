@@ -159,7 +159,7 @@ def main():
         roofline["traffic"] = (m["fetch_size_kb_raw"] * m["fetch_correction"] + m["write_size_kb"]) * 1024 / 1e9
         roofline["traffic_unit"] = f"GB per launch (FETCH_SIZE x calibration + WRITE_SIZE, profiles/{pmc['_file']})"
     # secondary: integer-ALU view. mixed adds per MSM = n * windows; 8M + 2S field operations each. The roof is
-    # measured in this run: the same ec.cuh mixed add with every operand in registers (no memory traffic at all).
+    # measured in this run: the same ec.hpp mixed add with every operand in registers (no memory traffic at all).
     pc, pw = ctypes.c_int(), ctypes.c_int()
     pcfg = MSMConfig.default()
     pcfg.c = args.msm_c

@@ -12,14 +12,14 @@
 // reduced; subtraction adds a multiple of p (K*p, K in {2,4,8,16}) big enough to stay positive.
 // A normalised element has limbs 0..NL-2 in [0,2^29) and a non-negative top limb.
 // In host debug builds (-DBIGFIELD_BOUNDS) every element carries its bound (in units of p) and each
-// op asserts its precondition, so the bounds argument of ec.cuh is machine-checked by tests.
+// op asserts its precondition, so the bounds argument of ec.hpp is machine-checked by tests.
 //
 // I/O is the reference's canonical storage<N> (N x u32 little-endian, value in [0,p), NOT
 // Montgomery unless a *_montgomery_form flag says so; modular_arithmetic.h:517-521, 583-585).
 #pragma once
 #include <cstdint>
 #include "field_consts.h"
-#include "mont_asm.cuh" // device builds: the products below as single inline-asm blocks (-DBIGFIELD_NO_ASM turns them off)
+#include "mont_asm.hpp" // device builds: the products below as single inline-asm blocks (-DBIGFIELD_NO_ASM turns them off)
 
 #if defined(__HIPCC__)
   #include <hip/hip_runtime.h>
@@ -59,7 +59,7 @@ namespace icicle_hip {
     static constexpr int N = PR::NL;
     static constexpr int N32 = PR::NL32;
     static constexpr uint32_t MASK = RB_MASK;
-    static constexpr bool TIGHT = false; // see fq2.cuh
+    static constexpr bool TIGHT = false; // see fq2.hpp
     using fe = Fe<PR>;
     // R/p (lower bound) used only by the debug bound tracker
     static constexpr double r_over_p() { return (double)(1ull << (RB * N - PR::NBITS)); }
@@ -174,7 +174,7 @@ namespace icicle_hip {
     }
 
     // a <- a*b/R (same value and bound as mul). On the device the result is produced in a's own registers, so a
-    // loop-carried accumulator coordinate needs no copies at the back edge (mont_asm.cuh).
+    // loop-carried accumulator coordinate needs no copies at the back edge (mont_asm.hpp).
     static HD void mul_inplace(fe& a, const fe& b)
     {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(BIGFIELD_NO_ASM)
@@ -381,7 +381,7 @@ namespace icicle_hip {
       a.bnd = (a.bnd - (double)K > (double)K) ? a.bnd - (double)K : (a.bnd < (double)K ? a.bnd : (double)K);
 #endif
     }
-    // value < 16p -> < 4p (two conditional subtractions); used by ec.cuh in Fq2Ops' TIGHT mode only
+    // value < 16p -> < 4p (two conditional subtractions); used by ec.hpp in Fq2Ops' TIGHT mode only
     static HD fe below4(const fe& a)
     {
       BF_ASSERT(a.bnd <= 16.0, "below4 input bound");

@@ -1,13 +1,13 @@
 // Diagnostics exported next to the product entry points so that bench.py can measure the roofs of the dominant MSM
 // kernel IN THE SAME RUN as the kernel itself (no hard-coded ceilings):
 //   icicle_hip_ubench_mixed_add  XYZZ mixed adds per second with every operand in registers -- the integer-ALU roof
-//                                of k_accumulate (same ec.cuh code, same launch bounds, no memory traffic)
+//                                of k_accumulate (same ec.hpp code, same launch bounds, no memory traffic)
 //   icicle_hip_ubench_gather     random 64-byte gathers per second (4 x 16 B loads per lane, the access pattern of
 //                                k_accumulate's base fetch) over a region of the given size; also the known-byte-count
 //                                kernel the FETCH_SIZE counter is calibrated on (tools/pmc_traffic.sh)
 // Neither touches user data. tools/ubench/msm_ubench.hip holds the wider design-decision sweeps.
 #include "common.h"
-#include "ec.cuh"
+#include "ec.hpp"
 
 namespace icicle_hip {
 

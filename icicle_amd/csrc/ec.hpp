@@ -1,4 +1,4 @@
-// Short-Weierstrass (a = 0) group arithmetic over bigfield.cuh, for the MSM hot path.
+// Short-Weierstrass (a = 0) group arithmetic over bigfield.hpp, for the MSM hot path.
 //
 // The reference does every EC operation with the complete homogeneous-projective formulas of
 // Renes-Costello-Batina (icicle/include/icicle/curves/projective.h:73-188; mixed add = 11 muls +
@@ -16,15 +16,15 @@
 // (ZZ*PP)*R^2 keeps ZZ, ZZZ in their form. The only conversions are per BUCKET, not per point: the first point of
 // a bucket is multiplied by R^2 (2 products) and to_proj() removes one R from ZZ (1 product).
 //
-// Bounds (units of p, see bigfield.cuh; machine-checked under -DBIGFIELD_BOUNDS):
+// Bounds (units of p, see bigfield.hpp; machine-checked under -DBIGFIELD_BOUNDS):
 //   affine (plain words) x <= 1.2, y <= 2.2         XYZZ  X <= 8, Y <= 4, ZZ,ZZZ <= 2
 //   projective           X,Y,Z <= 4
 //
-// The same code serves G1 (coordinates in Fq, FieldOps) and G2 (coordinates in Fq2, fq2.cuh):
+// The same code serves G1 (coordinates in Fq, FieldOps) and G2 (coordinates in Fq2, fq2.hpp):
 // C::EXT_DEGREE selects the field-ops class, everything below only uses their common interface.
 #pragma once
-#include "bigfield.cuh"
-#include "fq2.cuh"
+#include "bigfield.hpp"
+#include "fq2.hpp"
 #include <type_traits>
 
 #if defined(__HIPCC__)

@@ -14,8 +14,8 @@
 // folded into the load and store kernels. The projective representative of a result differs from
 // the reference's (it depends on the order of additions); the group element is the same -- tests
 // compare to_affine() limbs, as for the MSM.
-#include "ntt_big_common.cuh"
-#include "ec.cuh"
+#include "ntt_big_common.hpp"
+#include "ec.hpp"
 #include "ntt_plan.h"
 #include <algorithm>
 

@@ -1,9 +1,9 @@
-// Quadratic extension Fq2 = Fq[u]/(u^2 + 1) over bigfield.cuh, for the G2 groups of BN254 and
+// Quadratic extension Fq2 = Fq[u]/(u^2 + 1) over bigfield.hpp, for the G2 groups of BN254 and
 // BLS12-381 (both use the non-residue -1: icicle/include/icicle/fields/snark_fields/bn254_base.h,
 // bls12_381_base.h `nonresidue = 1, nonresidue_is_negative = true`; element layout {c0 = real,
 // c1 = imaginary}, icicle/include/icicle/fields/complex_extension.h).
 //
-// Fq2Ops<PR> offers the same static interface as FieldOps<PR>, so ec.cuh and the MSM kernels are
+// Fq2Ops<PR> offers the same static interface as FieldOps<PR>, so ec.hpp and the MSM kernels are
 // instantiated over it unchanged. Lazy bounds are tracked per component (units of p).
 //   mul  : c0 = a0*b0 + (16p - a1)*b1 , c1 = a0*b1 + a1*b0  -- two mul_add, i.e. 4 limb products
 //          under 2 interleaved reductions (6 N^2 mads; 3-product Karatsuba with separate reductions
@@ -11,12 +11,12 @@
 //   sqr  : c0 = (a0 + a1)*(a0 - a1) , c1 = 2*a0*a1           -- 2 products
 // The 16p offset of the negation costs 16*B(b1)/(R/p) in the product's bound. BLS12-381 has
 // R/p = 2^25 and does not notice; BN254 has R/p = 128, where products would come out at up to ~3p
-// instead of the <= 2p the formulas in ec.cuh were laid out for. TIGHT mode (R/p < 1024) therefore
+// instead of the <= 2p the formulas in ec.hpp were laid out for. TIGHT mode (R/p < 1024) therefore
 // ends every product with one conditional subtraction of 2p per component (~6 % of a product), and
 // squares with c0 = a0*a0 + (16p - a1)*a1 so that the raw value stays below 4p. With that, Fq2
-// products have the same bound class as Fq products and ec.cuh needs no G2-specific constants.
+// products have the same bound class as Fq products and ec.hpp needs no G2-specific constants.
 #pragma once
-#include "bigfield.cuh"
+#include "bigfield.hpp"
 
 namespace icicle_hip {
 

@@ -1,6 +1,6 @@
-// G1 instantiation of the MSM (msm_impl.cuh) and its C ABI. G2 lives in msm_g2.hip so that the two
+// G1 instantiation of the MSM (msm_impl.hpp) and its C ABI. G2 lives in msm_g2.hip so that the two
 // halves compile in parallel.
-#include "msm_impl.cuh"
+#include "msm_impl.hpp"
 
 using namespace icicle_hip;
 

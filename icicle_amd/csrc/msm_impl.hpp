@@ -5,7 +5,7 @@
 // The CPU backend gives each worker private buckets and random-access RMWs into them; on MI355X
 // the same sum is reorganised so that the only random access left is a read-only gather:
 //
-//   1. (no Montgomery copy of the bases: k_accumulate gathers the caller's canonical words, see ec.cuh)
+//   1. (no Montgomery copy of the bases: k_accumulate gathers the caller's canonical words, see ec.hpp)
 //   2. k_digits          scalars -> signed c-bit digits, one u32 per (window, scalar), coalesced
 //   3. two-level counting sort of point indices by bucket, every scatter staged through an LDS
 //      tile-sort so that HBM sees runs, not 4-byte random writes:
@@ -25,7 +25,7 @@
 // host only blocks when the API contract requires it (is_async == false or results on host).
 #pragma once
 #include "common.h"
-#include "ec.cuh"
+#include "ec.hpp"
 #include <algorithm>
 
 namespace icicle_hip {
@@ -83,7 +83,7 @@ namespace icicle_hip {
 
   // ------------------------------------------------------------------------------------------
   // 1. bases staging (thread per coordinate) -- NOT on the default path: bucket accumulation gathers the caller's
-  //    canonical affine words directly (ec.cuh header). Only bases given in the reference's Montgomery form
+  //    canonical affine words directly (ec.hpp header). Only bases given in the reference's Montgomery form
   //    (are_points_montgomery_form: x*2^(32*N32) -> x) or at an address that is not 16-byte aligned are copied.
   template <class C>
   __global__ __launch_bounds__(256) void k_bases_stage(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t ncoord, bool in_refmont)
@@ -1005,7 +1005,7 @@ namespace icicle_hip {
     using E = EC<C>;
     __shared__ typename E::Proj sh[128];
     // four lanes per window: the doubling chain 2^(c*w) * S_w is the latency floor of the whole MSM, and a quad
-    // runs it with three dependent products per step instead of seven (ec.cuh dbl_jac_quad)
+    // runs it with three dependent products per step instead of seven (ec.hpp dbl_jac_quad)
     const uint32_t role = threadIdx.x & 3u;
     winsum += (size_t)blockIdx.x * wpf;
     result += (size_t)blockIdx.x * 3 * E::N32;
@@ -1013,7 +1013,7 @@ namespace icicle_hip {
       typename E::Proj v = E::proj_identity();
       if (w < wpf) {
         v = winsum[w];
-        if (w > 0) { // Jacobian doubling chain (ec.cuh), 2M + 5S per step
+        if (w > 0) { // Jacobian doubling chain (ec.hpp), 2M + 5S per step
           typename E::Jac j = E::to_jac(v);
           for (int i = 0; i < w * c; i++) // the same trip count in all four lanes of a quad
             j = E::dbl_jac_quad(j, role);
@@ -1170,7 +1170,7 @@ namespace icicle_hip {
     dst[t] = E::add(dst[t], src[t]);
   }
 
-  // Hook between bucket accumulation and bucket reduction (multi-device variant E2, msm_multi.cuh): may replace the
+  // Hook between bucket accumulation and bucket reduction (multi-device variant E2, msm_multi.hpp): may replace the
   // bucket contents with sums over shards / devices, skip this call's reduction, or restrict it to a segment range.
   template <class C>
   struct MsmBucketHook {
@@ -1471,7 +1471,7 @@ namespace icicle_hip {
   }
 
 } // namespace icicle_hip
-#include "msm_multi.cuh"
+#include "msm_multi.hpp"
 namespace icicle_hip {
 
   template <class C>

@@ -21,6 +21,8 @@
 // call is synchronous with respect to the host whatever is_async says. Inputs may live on the host or on the
 // calling device; shards for other devices are staged with hipMemcpy2DAsync (peer or host-to-device).
 #pragma once
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 namespace icicle_hip {
@@ -32,6 +34,28 @@ namespace icicle_hip {
     *hi = *lo + base + (g < rem ? 1 : 0);
   }
 
+  // Rendezvous of the per-device host threads in front of a collective: a thread that failed earlier (allocation,
+  // copy, launch) must not leave its peers blocked inside ncclSend/ncclRecv/ncclAllGather forever. Every thread
+  // arrives exactly once per gate, with its status; all of them leave with "everybody was fine" or all with "someone
+  // failed" and then skip the collective.
+  struct PhaseGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int expected = 1, arrived = 0;
+    bool failed = false;
+    bool arrive(bool ok)
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      if (!ok) failed = true;
+      if (++arrived == expected) {
+        cv.notify_all();
+      } else {
+        cv.wait(lk, [&] { return arrived == expected; });
+      }
+      return !failed;
+    }
+  };
+
   // E2 hook of one physical device: sums the bucket arrays of its logical shards, then (last shard) exchanges bucket
   // slices with the peers and leaves this device's slice, summed over all devices, in the caller's bucket array.
   template <class C>
@@ -40,6 +64,8 @@ namespace icicle_hip {
     int nshards = 1, seen = 0, P = 1, p = 0;
     TempBuf acc, recv;
     void* comm = nullptr;
+    PhaseGate* gate = nullptr; // passed (once) right before the slice exchange
+    bool gate_passed = false;
 
     icicle_error_t after_accumulate(Proj* buckets, size_t tw, uint32_t nb, uint32_t nseg, uint32_t m, hipStream_t st, bool* skip_reduce, uint32_t* seg_lo, uint32_t* nsegr) override
     {
@@ -67,7 +93,10 @@ namespace icicle_hip {
       const RcclApi* api = rccl_api();
       if (!api) return ICICLE_API_NOT_IMPLEMENTED;
       const size_t mine = (size_t)(hi - lo) * m; // buckets of my slice per window
-      HIP_TRY(recv.alloc(std::max<size_t>(1, (size_t)P * tw * mine) * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
+      const bool have_recv = recv.alloc(std::max<size_t>(1, (size_t)P * tw * mine) * sizeof(Proj), st) == hipSuccess;
+      gate_passed = true;
+      if (gate && !gate->arrive(have_recv)) return ICICLE_ALLOCATION_FAILED; // a peer (or this device) cannot take part
+      if (!have_recv) return ICICLE_ALLOCATION_FAILED;
       constexpr size_t PWORDS = sizeof(Proj) / 4;
       if (api->GroupStart() != 0) return ICICLE_COPY_FAILED;
       for (int q = 0; q < P; q++) {
@@ -138,11 +167,15 @@ namespace icicle_hip {
       ICICLE_TRY(bind_current_device());
     }
 
+    PhaseGate gate_exchange, gate_gather;
+    gate_exchange.expected = gate_gather.expected = P;
     std::vector<icicle_error_t> rcs(P, ICICLE_SUCCESS);
     auto worker = [&](int p) -> icicle_error_t {
       ICICLE_TRY(icicle_hip_set_device(devs[p]));
       hipStream_t st = nullptr;
       HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
+      BucketExchange<C> hook;
+      bool gather_gate_passed = false;
       icicle_error_t rc = [&]() -> icicle_error_t {
         std::vector<int> mine;
         for (int g = p; g < G; g += P)
@@ -151,8 +184,8 @@ namespace icicle_hip {
         TempBuf partials, devpart, gathered, fin;
         HIP_TRY(partials.alloc((size_t)ns_p * batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
         HIP_TRY(devpart.alloc((size_t)batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
-        BucketExchange<C> hook;
         hook.nshards = ns_p, hook.P = P, hook.p = p, hook.comm = comms[p];
+        hook.gate = (exchange_buckets && P > 1) ? &gate_exchange : nullptr;
         icicle_msm_config_t c2 = sub;
         c2.stream = st;
         for (int j = 0; j < ns_p; j++) {
@@ -191,8 +224,9 @@ namespace icicle_hip {
         const uint32_t* result = devpart.as<uint32_t>();
         if (use_rccl) { // "all-reduce" of partial sums: EC addition is not an RCCL reduce op -> all-gather + local projective sum
           const RcclApi* api = rccl_api();
-          HIP_TRY(gathered.alloc((size_t)P * batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
-          HIP_TRY(fin.alloc((size_t)batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
+          const bool have_bufs = gathered.alloc((size_t)P * batch * RW * 4, st) == hipSuccess && fin.alloc((size_t)batch * RW * 4, st) == hipSuccess;
+          gather_gate_passed = true;
+          if (!gate_gather.arrive(have_bufs) || !have_bufs) return ICICLE_ALLOCATION_FAILED;
           if (api->AllGather(devpart.ptr(), gathered.ptr(), (size_t)batch * RW, RCCL_UINT32, comms[p], st) != 0) return ICICLE_COPY_FAILED;
           k_proj_sum<C><<<batch, 64, 0, st>>>(gathered.as<uint32_t>(), P, (size_t)batch * RW, fin.as<uint32_t>());
           LAUNCH_CHECK("k_proj_sum(devices)", st);
@@ -203,6 +237,9 @@ namespace icicle_hip {
         HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
         return ICICLE_SUCCESS;
       }();
+      // a thread that bailed out before a collective still reports to its gate, so that the peers skip it too
+      if (exchange_buckets && P > 1 && !hook.gate_passed) (void)gate_exchange.arrive(false);
+      if (use_rccl && !gather_gate_passed) (void)gate_gather.arrive(false);
       (void)hipStreamSynchronize(st);
       (void)hipStreamDestroy(st);
       return rc;

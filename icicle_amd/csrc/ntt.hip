@@ -13,7 +13,7 @@
 // data with no separate transpose / bit-reverse pass. Data stays in canonical form throughout:
 // twiddles are stored in Montgomery form, and montmul(canonical, w*R) = canonical.
 #include "common.h"
-#include "smallfield.cuh"
+#include "smallfield.hpp"
 #include "ntt_plan.h"
 #include <thread>
 #include <algorithm>

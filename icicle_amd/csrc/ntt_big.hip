@@ -9,14 +9,14 @@
 // last pass. What changes with 32-byte elements:
 //   * a run of T = 4 elements is already a 128 B HBM transaction, so tiles are narrow and tall;
 //   * the tile lives in LDS as 9 x 29-bit limbs per element (36 B, odd word stride) so the
-//     butterflies use bigfield.cuh's lazy arithmetic without re-packing between stages;
+//     butterflies use bigfield.hpp's lazy arithmetic without re-packing between stages;
 //   * a butterfly is one 9-limb Montgomery product (~230 VALU ops), two stages per LDS round trip: the pass is ALU-bound, not
 //     HBM-bound (2^24 elements: ~1.5 GB of traffic per direction vs ~6e10 lane-ops).
 // Data stays in the caller's (canonical or Montgomery) form: twiddles are kept in Montgomery form
 // and montmul(x, w*R) = x*w. Lazy bounds (units of p): loads 1.2, 3.2 and 7.2 after the two
 // product-free stages, +2 per later stage, <= 23.2 after ten stages (limit 64, reduce() accepts
 // < 32), back to canonical on every store.
-#include "ntt_big_common.cuh"
+#include "ntt_big_common.hpp"
 #include "ntt_plan.h"
 #include <algorithm>
 #include <cstring>

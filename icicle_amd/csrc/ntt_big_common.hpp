@@ -1,9 +1,9 @@
 // Shared by ntt_big.hip (scalar-field NTT) and ecntt.hip (NTT over curve points, same twiddle domain):
-// field helpers on top of bigfield.cuh, the per-device twiddle domain of a 256-bit scalar field, and
+// field helpers on top of bigfield.hpp, the per-device twiddle domain of a 256-bit scalar field, and
 // the twiddle / coset-power generators.
 #pragma once
 #include "common.h"
-#include "bigfield.cuh"
+#include "bigfield.hpp"
 #include <cstring>
 #include <map>
 #include <mutex>

@@ -7,8 +7,8 @@
 // C ABI icicle/src/vec_ops.cpp:402-415, icicle/src/curves/montgomery_conversion.cpp:10-58).
 // One field multiplication per element: HBM-bound (read + write of the data).
 #include "common.h"
-#include "bigfield.cuh"
-#include "smallfield.cuh"
+#include "bigfield.hpp"
+#include "smallfield.hpp"
 
 namespace icicle_hip {
 

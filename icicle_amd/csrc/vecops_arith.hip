@@ -11,8 +11,8 @@
 // stay so: products are computed as montmul(montmul(a, b), R^2).
 // All of these are HBM-bound streams (2 reads + 1 write per element, or 1 + 1 for bit_reverse).
 #include "common.h"
-#include "bigfield.cuh"
-#include "smallfield.cuh"
+#include "bigfield.hpp"
+#include "smallfield.hpp"
 
 namespace icicle_hip {
 

@@ -94,7 +94,7 @@ icicle_error_t icicle_get_registered_devices(char* output, size_t output_size); 
  *   "hip_num_devices"          (int,  msm + ntt)  G >= 1: run the call on G shards over min(G, visible GPUs) devices
  *                                                 starting at the active one (MSM: contiguous (scalar, base) shards,
  *                                                 partial results all-gathered over RCCL and summed; batched NTT:
- *                                                 rows per device, no collective). icicle_amd/csrc/msm_multi.cuh.
+ *                                                 rows per device, no collective). icicle_amd/csrc/msm_multi.hpp.
  *   "hip_msm_exchange_buckets" (bool, msm)        with hip_num_devices: exchange bucket slices (all-to-all) instead of
  *                                                 final partial sums, so that the bucket reduction is sharded too.
  * Foreign keys (the CUDA backend's "large_bucket_factor", "fast_twiddles", the CPU backend's "n_threads", ...) are

@@ -1,11 +1,11 @@
-// TEST-ONLY host build of the device arithmetic headers (bigfield.cuh / ec.cuh / smallfield.cuh)
+// TEST-ONLY host build of the device arithmetic headers (bigfield.hpp / ec.hpp / smallfield.hpp)
 // with the debug bound tracker on (-DBIGFIELD_BOUNDS). Lets the CPU test-suite check the exact
 // code the kernels run against Python big-int arithmetic and the reference oracle, without a GPU.
 // Not part of the shipped library; nothing in icicle_amd/ links it.
 #include <cstdint>
 #include <cstring>
-#include "../icicle_amd/csrc/ec.cuh"
-#include "../icicle_amd/csrc/smallfield.cuh"
+#include "../icicle_amd/csrc/ec.hpp"
+#include "../icicle_amd/csrc/smallfield.hpp"
 
 using namespace icicle_hip;
 
@@ -66,7 +66,7 @@ namespace {
       for (int i = 0; i < n; i++) {
         const uint32_t* w = pts + (size_t)i * 2 * N32;
         if (E::words_are_zero(w)) continue;
-        // the hot loop consumes the canonical words exactly as they lie in HBM (ec.cuh scaling convention)
+        // the hot loop consumes the canonical words exactly as they lie in HBM (ec.hpp scaling convention)
         auto a = E::cneg(E::load_plain(w), aux && (aux[i] & 1));
         E::madd(acc, empty, a);
       }

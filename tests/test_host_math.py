@@ -1,4 +1,4 @@
-"""CPU: the exact arithmetic headers the kernels use (bigfield.cuh, ec.cuh, smallfield.cuh), compiled
+"""CPU: the exact arithmetic headers the kernels use (bigfield.hpp, ec.hpp, smallfield.hpp), compiled
 for the host with the debug bound tracker on, against Python big-int arithmetic. This pins the
 29-bit-radix Montgomery field, the XYZZ mixed add with its exceptional cases, and the complete
 projective formulas (reference: icicle/include/icicle/curves/projective.h:73-188) without a GPU."""
@@ -21,7 +21,7 @@ NL = {0: 8, 1: 8, 2: 12, 3: 8}
 @pytest.fixture(scope="module")
 def lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.cuh", "fq2.cuh", "ec.cuh", "smallfield.cuh", "field_consts.h")]
+    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.hpp", "fq2.hpp", "ec.hpp", "smallfield.hpp", "field_consts.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-DBIGFIELD_BOUNDS", "-fPIC", "-shared", SRC, "-o", SO])
     return ctypes.CDLL(SO)
@@ -119,7 +119,7 @@ def test_ec_ops(lib, ci, c):
 
 @pytest.mark.parametrize("ci,c", [(2, pyref.BN254_G2), (3, pyref.BLS12_381_G2)])
 def test_g2_ec_ops(lib, ci, c):
-    """same cases over Fq2 (fq2.cuh): XYZZ accumulation with its exceptional branches, complete add / dbl,
+    """same cases over Fq2 (fq2.hpp): XYZZ accumulation with its exceptional branches, complete add / dbl,
     small multiples; the bound tracker asserts inside the harness on every field operation."""
     n32 = c.base.limbs_q
     q = c.base.q

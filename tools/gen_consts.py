@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate icicle_amd/csrc/field_consts.h: per-field constants for the 29-bit-radix Montgomery
-big-field arithmetic (bigfield.cuh) and the 31-bit NTT fields.
+big-field arithmetic (bigfield.hpp) and the 31-bit NTT fields.
 
 Moduli / generators / roots of unity are the published curve parameters; they are cross-checked
 against the reference headers (icicle/include/icicle/fields/snark_fields/*.h, stark_fields/*.h,
@@ -47,7 +47,7 @@ def gen_big(name, p, l32):
     bits = p.bit_length()
     nl = (bits + 6 + RB - 1) // RB  # >= 7 bits of slack: values up to 64p never overflow, R/p >= 2^7... checked below
     R = 1 << (RB * nl)
-    assert R // p >= 64, (name, R // p)  # lazy-reduction slack, see bigfield.cuh bounds
+    assert R // p >= 64, (name, R // p)  # lazy-reduction slack, see bigfield.hpp bounds
     pinv = (-pow(p, -1, 1 << RB)) % (1 << RB)
     r32 = 1 << (32 * l32)
     s = []
@@ -204,8 +204,8 @@ def gen_small(name, p, rou):
 def main():
     out = []
     out.append("// GENERATED by tools/gen_consts.py -- do not edit.")
-    out.append("// Constants for the 29-bit-radix Montgomery representation used on device (bigfield.cuh)")
-    out.append("// and for the 31-bit NTT fields (smallfield.cuh).")
+    out.append("// Constants for the 29-bit-radix Montgomery representation used on device (bigfield.hpp)")
+    out.append("// and for the 31-bit NTT fields (smallfield.hpp).")
     out.append("#pragma once")
     out.append("#include <cstdint>")
     out.append("namespace icicle_hip {")

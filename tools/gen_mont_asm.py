@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates icicle_amd/csrc/mont_asm.cuh: the interleaved Montgomery product of bigfield.cuh (radix 2^29, product
+"""Generates icicle_amd/csrc/mont_asm.hpp: the interleaved Montgomery product of bigfield.hpp (radix 2^29, product
 scanning) written as ONE gfx950 inline-asm block per operation, for N = 9 (BN254) and N = 14 (BLS12-381) limbs.
 
 Why: hipcc reassociates every column sum so that the carry of the previous column is added LAST (LLVM's Reassociate

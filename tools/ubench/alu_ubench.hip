@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_alu(uint32_t* out, uint32_t seed)
         asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[i]) : "v"(a[i]), "v"(b[i]) : "vcc");
       } else if constexpr (OP == 19) { // v_mad_u64_u32 with an SGPR multiplicand (the m*p half of a Montgomery product)
         asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[i]) : "v"(a[i]), "s"(seed) : "vcc");
-      } else if constexpr (OP == 20) { // dependent chain of v_mad_u64_u32 through ONE accumulator (what mont_asm.cuh issues)
+      } else if constexpr (OP == 20) { // dependent chain of v_mad_u64_u32 through ONE accumulator (what mont_asm.hpp issues)
         asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[0]) : "v"(a[i]), "v"(b[i]) : "vcc");
       } else if constexpr (OP == 21) { // v_mov_b32
         asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b[i]));

@@ -5,18 +5,18 @@
 //   gather  random 64-byte point gathers/s as a function of the region the indices fall in (64 MiB .. 4 GiB) and of
 //           the number of points in flight per lane -- is the 14.9 G/s ceiling a TLB / line / latency limit, and would
 //           slicing the base array so that a slice lives in the 256 MiB Infinity Cache lift it?
-//   alu     BN254 Fq rates from the PRODUCT code (bigfield.cuh / ec.cuh), operands in registers: modmul, modsqr, the
+//   alu     BN254 Fq rates from the PRODUCT code (bigfield.hpp / ec.hpp), operands in registers: modmul, modsqr, the
 //           XYZZ mixed add (= the ALU roof of k_accumulate), Fermat inversion, and the per-add work of a batched-affine
 //           add (forward product + backward: 5M + 1S), from which the break-even batch size per inversion follows.
 //   dfma    the 254-bit integer product as 5x52-bit limbs on v_fma_f64 (hi/lo split, Emmart-style instruction mix)
-//           against the 9x29-bit v_mad_u64_u32 column product used by bigfield.cuh.
+//           against the 9x29-bit v_mad_u64_u32 column product used by bigfield.hpp.
 //   mfma    issue rate of v_mfma_i32_16x16x64_i8 (the "m*p is a constant-matrix product" idea).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
 #include <vector>
-#include "ec.cuh"
+#include "ec.hpp"
 
 using namespace icicle_hip;
 
@@ -240,7 +240,7 @@ static void bench_alu()
 }
 
 // ------------------------------------------------------------------------------------------- dfma
-// Full 254x254 -> 508-bit product, no reduction. (a) 9 x 29-bit limbs, column sums in one u64 (bigfield.cuh's scheme);
+// Full 254x254 -> 508-bit product, no reduction. (a) 9 x 29-bit limbs, column sums in one u64 (bigfield.hpp's scheme);
 // (b) 5 x 52-bit limbs held in doubles: per limb product  hi = fma(a,b,2^104); lo = fma(a,b,(2^104+2^52)-hi); the two
 // bit patterns are accumulated as 64-bit integers (exponent constants removed at the end). Exactness needs RZ mode;
 // the instruction mix and cost are the same under the default mode used here.
