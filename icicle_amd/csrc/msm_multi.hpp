@@ -171,12 +171,19 @@ namespace icicle_hip {
     gate_exchange.expected = gate_gather.expected = P;
     std::vector<icicle_error_t> rcs(P, ICICLE_SUCCESS);
     auto worker = [&](int p) -> icicle_error_t {
-      ICICLE_TRY(icicle_hip_set_device(devs[p]));
+      auto bail = [&](icicle_error_t e) { // nothing started on this device: tell the peers at both gates
+        if (exchange_buckets && P > 1) (void)gate_exchange.arrive(false);
+        if (use_rccl) (void)gate_gather.arrive(false);
+        return e;
+      };
+      if (icicle_hip_set_device(devs[p]) != ICICLE_SUCCESS) return bail(ICICLE_INVALID_DEVICE);
       hipStream_t st = nullptr;
-      HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return bail(ICICLE_STREAM_CREATION_FAILED);
+      icicle_error_t rc;
+      { // the hook's buffers are released in stream order: it must die before the stream does
       BucketExchange<C> hook;
       bool gather_gate_passed = false;
-      icicle_error_t rc = [&]() -> icicle_error_t {
+      rc = [&]() -> icicle_error_t {
         std::vector<int> mine;
         for (int g = p; g < G; g += P)
           mine.push_back(g);
@@ -240,6 +247,7 @@ namespace icicle_hip {
       // a thread that bailed out before a collective still reports to its gate, so that the peers skip it too
       if (exchange_buckets && P > 1 && !hook.gate_passed) (void)gate_exchange.arrive(false);
       if (use_rccl && !gather_gate_passed) (void)gate_gather.arrive(false);
+      }
       (void)hipStreamSynchronize(st);
       (void)hipStreamDestroy(st);
       return rc;
