@@ -189,7 +189,29 @@ namespace icicle_hip {
   // variants (separate instantiations, so that they do not cost the plain path registers) get 2
   constexpr int ntt_fast_min_waves(int nr, bool extra) { return (nr <= 2 && !extra) ? 4 : 2; }
 
-  template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV>
+  // 4x4 transpose across the four 16-lane rows of a wave: lanes {l, l+16, l+32, l+48} form a group, in: the lane of
+  // row r holds v[c] = M[r][c]; out: v[c] = M[c][r]. gfx950's v_permlane16_swap (odd rows of the first operand <->
+  // even rows of the second) and v_permlane32_swap (upper half of the first <-> lower half of the second) are exactly
+  // the two exchange steps of the transpose: four instructions, no selects.
+  typedef uint32_t ntt_u2 __attribute__((ext_vector_type(2)));
+  __device__ __forceinline__ void rows_transpose(uint32_t* v)
+  {
+    const ntt_u2 a01 = __builtin_amdgcn_permlane16_swap(v[0], v[1], false, false);
+    const ntt_u2 a23 = __builtin_amdgcn_permlane16_swap(v[2], v[3], false, false);
+    const ntt_u2 w02 = __builtin_amdgcn_permlane32_swap(a01.x, a23.x, false, false);
+    const ntt_u2 w13 = __builtin_amdgcn_permlane32_swap(a01.y, a23.y, false, false);
+    v[0] = w02.x, v[1] = w13.x, v[2] = w02.y, v[3] = w13.y;
+  }
+
+  // V4 (16-byte lanes): with unit element stride, 32-column tiles and radix-16 rounds a thread's 16 operands sit in
+  // 16 different rows of ONE column. Lane l of a wave then works for column 4*(l & 7) + (l >> 4) of sub-transform
+  // group 2*wave + ((l >> 3) & 1): the four lanes {l, l+16, l+32, l+48} own four ADJACENT columns of the same rows.
+  // The lane in wave-row r moves the rows {4g + r} as uint4 (its group's four columns), eight consecutive lanes cover
+  // one 128-byte line, and rows_transpose() hands every word to its owner: a quarter of the memory instructions, 16
+  // bytes per lane (the access shape profiles/r02_strided_ubench.txt measured at 1.73 instead of 1.93 ms per pass) for
+  // 4 extra VALU instructions per 4 words. The host picks it when every base is 16-byte aligned; results are
+  // identical word for word.
+  template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV, bool V4 = false>
   __global__ __launch_bounds__(512, ntt_fast_min_waves(NR, COSET && DIF)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
   {
     using S = SmallField<PR>;
@@ -212,8 +234,15 @@ namespace icicle_hip {
     const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
     const uint32_t lstride_log = nl.log_max - SS;
     // mapping B (lanes along t) everywhere except the first executed round of a DIF pass (mapping A)
-    const uint32_t tB = threadIdx.x % T, gB = threadIdx.x / T;
-    const uint32_t gA = threadIdx.x % NG16, tA = threadIdx.x / NG16;
+    static_assert(!V4 || (NQ0 == 4 && NR >= 2 && !OUTREV), "16-byte lanes: radix-16 rounds only");
+    // V4 (T == 32): lane l -> column 4*(l & 7) + (l >> 4), group 2*wave + ((l >> 3) & 1); mapping A (NG16 % 16 == 0):
+    // row 4*(l & 3) + (l >> 4) of its 16-row block, column 4*wave + ((l >> 2) & 3) -- see the V4 note above
+    const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t wrow = ln >> 4, wrev = ((wrow & 1u) << 1) | (wrow >> 1); // wave-row of this lane, 2-bit reversed
+    const uint32_t tB = V4 ? 4u * (ln & 7u) + wrow : threadIdx.x % T;
+    const uint32_t gB = V4 ? 2u * wv + ((ln >> 3) & 1u) : threadIdx.x / T;
+    const uint32_t gA = V4 ? (threadIdx.x % NG16 & ~15u) + 4u * (ln & 3u) + wrow : threadIdx.x % NG16;
+    const uint32_t tA = V4 ? (threadIdx.x / NG16 & ~3u) + ((ln >> 2) & 3u) : threadIdx.x / NG16;
 
     auto tw_load = [&](uint64_t idx) -> uint32_t {
       idx &= max_mask;
@@ -314,7 +343,23 @@ namespace icicle_hip {
     // (SQ_WAIT_ANY 0.52-0.57 on the column passes, profiles/r01_notes.md).
     auto load_row = [&](uint32_t rloc, uint32_t* x) {
       const uint32_t* __restrict__ pin = in + row_offset(rloc, nl.src_rel != 0);
-      if (!DIF) {
+      if (V4 && !DIF) { // NQ0 == 4, G0 == 1: slot 4g+c of the lane in wave-row r <- word c of source row brev4(4g+r) (before the transpose)
+        const uint32_t kb = (KB_BITS == 0) ? 0u : (__brev(gB) >> (32 - (KB_BITS > 0 ? KB_BITS : 1)));
+        const uint32_t* p = pin + (in_base + (uint64_t)kb * pd.in_sk + (uint64_t)(tB - wrow));
+        const uint64_t step = pd.in_sk << KB_BITS;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const uint4 v = *reinterpret_cast<const uint4*>(p + (uint64_t)((wrev << 2) | brev_c<2>(g)) * step);
+          x[4 * g] = v.x, x[4 * g + 1] = v.y, x[4 * g + 2] = v.z, x[4 * g + 3] = v.w;
+        }
+      } else if (V4) { // top round of the row pass: slot 4g+c of the lane in wave-row r <- word c of row 4g+r
+        const uint32_t* p = pin + (in_base + (uint64_t)(gA - wrow) + (uint64_t)tA * pd.in_st);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const uint4 v = *reinterpret_cast<const uint4*>(p + ((uint64_t)(4 * g + wrow) << QT));
+          x[4 * g] = v.x, x[4 * g + 1] = v.y, x[4 * g + 2] = v.z, x[4 * g + 3] = v.w;
+        }
+      } else if (!DIF) {
 #pragma unroll
         for (int u = 0; u < G0; u++) {
           const uint32_t gi = gB * G0 + u;
@@ -362,6 +407,11 @@ namespace icicle_hip {
 #pragma unroll
           for (int m = 0; m < (1 << NQ0); m++)
             x[m] = xin[u * (1 << NQ0) + m];
+          if (V4) {
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+              rows_transpose(x + 4 * g);
+          }
           if (coset_in) { // row part of g^j (the column part sits in wip)
 #pragma unroll
             for (int m = 0; m < (1 << NQ0); m++)
@@ -390,7 +440,18 @@ namespace icicle_hip {
             for (int m = 0; m < 16; m++)
               x[m] = tile[(base + ((uint32_t)m << q0)) * TP + tB];
             ntt_stages<S, 4, false, false>(x, wr[r - 1]);
-            if (r == NR - 1) {
+            if (r == NR - 1 && V4) { // the lane in wave-row r stores rows 4g+r, four adjacent columns each
+              uint32_t* q = pout + (in_base + (uint64_t)base * pd.in_sk + (uint64_t)(tB - wrow));
+              const uint64_t step = pd.in_sk << q0;
+#pragma unroll
+              for (int m = 0; m < 16; m++)
+                x[m] = S::mul(x[m], wip[m]);
+#pragma unroll
+              for (int g = 0; g < 4; g++) {
+                rows_transpose(x + 4 * g);
+                *reinterpret_cast<uint4*>(q + (uint64_t)(4 * g + wrow) * step) = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+              }
+            } else if (r == NR - 1) {
               uint32_t* q = pout + (in_base + (uint64_t)base * pd.in_sk + (uint64_t)tB * pd.in_st) * es;
               const uint64_t step = (pd.in_sk << q0) * es;
 #pragma unroll
@@ -441,6 +502,11 @@ namespace icicle_hip {
 #pragma unroll
             for (int m = 0; m < 16; m++)
               x[m] = xin[m];
+            if (V4) {
+#pragma unroll
+              for (int g = 0; g < 4; g++)
+                rows_transpose(x + 4 * g);
+            }
             if (coset_in) { // single-pass transform: rows k = gA + m * L/16 of column tA
               const uint64_t j0 = in_base + (uint64_t)gA + (uint64_t)tA * pd.in_st;
 #pragma unroll
@@ -489,6 +555,14 @@ namespace icicle_hip {
 #pragma unroll
               for (int m = 0; m < (1 << NQ0); m++)
                 tile[((gi << NQ0) + m) * TP + tB] = x[m];
+            } else if (V4) { // the lane in wave-row r stores slots 4g+r (rows brev4(4g+r)), four adjacent output columns each
+              uint32_t* q = pout + ((K0 - wrow) + (uint64_t)kb * pd.out_sk);
+              const uint64_t step = pd.out_sk << KB_BITS;
+#pragma unroll
+              for (int g = 0; g < 4; g++) {
+                rows_transpose(x + 4 * g);
+                *reinterpret_cast<uint4*>(q + (uint64_t)((wrev << 2) | brev_c<2>(g)) * step) = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+              }
             } else {
               uint32_t* q = pout + (K0 + (uint64_t)kb * pd.out_sk) * es;
               const uint64_t step = (pd.out_sk << KB_BITS) * es;
@@ -749,9 +823,17 @@ namespace icicle_hip {
   {
     return coset ? pick_variant2<PR, NQ0, NR, true>(dif, inv, outrev) : pick_variant2<PR, NQ0, NR, false>(dif, inv, outrev);
   }
-  template <class PR>
-  static pass_fn_t<PR> pick_pass(int s, bool dif, bool inv, bool coset, bool outrev)
+  template <class PR, int NR>
+  static pass_fn_t<PR> pick_v4(bool dif, bool inv)
   {
+    if (!dif) return (pass_fn_t<PR>)k_ntt_fast<PR, 4, NR, false, false, false, false, true>;
+    return inv ? (pass_fn_t<PR>)k_ntt_fast<PR, 4, NR, true, true, false, false, true> : (pass_fn_t<PR>)k_ntt_fast<PR, 4, NR, true, false, false, false, true>;
+  }
+
+  template <class PR>
+  static pass_fn_t<PR> pick_pass(int s, bool dif, bool inv, bool coset, bool outrev, bool v4)
+  {
+    if (v4 && !coset && !outrev && s == 8) return pick_v4<PR, 2>(dif, inv); // 16-byte lanes: 2^8 sub-transforms, 32-column tiles
     switch (s) {
     case 1: return pick_variant<PR, 1, 1>(dif, inv, coset, outrev);
     case 2: return pick_variant<PR, 2, 1>(dif, inv, coset, outrev);
@@ -1037,7 +1119,10 @@ namespace icicle_hip {
         const uint32_t gy = (nl.nrows_launch + rpb - 1) / rpb;
         // the coset factors touch the first pass (forward) or the last one (inverse) only
         const bool cvar = nl.coset && (nl.inverse ? pd.is_last != 0 : p == 0);
-        pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, nl.out_rev != 0 && pd.is_last != 0);
+        // 16-byte lanes need unit element stride, rows and bases on 16-byte boundaries and full 32-column tiles
+        static const bool v4_on = !(getenv("ICICLE_HIP_NTT_V4") && atoi(getenv("ICICLE_HIP_NTT_V4")) == 0);
+        const bool v4 = v4_on && lanes == 1 && nl.es == 1 && nl.bs % 4 == 0 && pd.T == 32 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+        pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, nl.out_rev != 0 && pd.is_last != 0, v4);
         if (!fn) return ICICLE_INVALID_ARGUMENT;
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
         fn<<<dim3(pd.ntiles, gy), threads, lds_bytes, st>>>(src, dst, dom.tw, d_ctab.as<uint32_t>(), pd, nl, rpb);
