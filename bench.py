@@ -241,7 +241,7 @@ def main():
         if logn == 24 and rows == 64 and "ntt_babybear_2^24x64_one_direction" in pmc:
             m = pmc["ntt_babybear_2^24x64_one_direction"]
             out["ntt"]["roofline"]["traffic"] = m["passes"] * (m["fetch_size_kb_raw_per_pass"] * m["fetch_correction"] + m["write_size_kb_per_pass"]) * 1024 / 1e9
-            out["ntt"]["roofline"]["traffic_unit"] = "GB per direction (3 pass launches; FETCH_SIZE calibrated on the 4 GiB each pass provably reads, WRITE_SIZE exact; profiles/r01_pmc_traffic.json)"
+            out["ntt"]["roofline"]["traffic_unit"] = f"GB per direction (3 pass launches; FETCH_SIZE calibrated on the 4 GiB each pass provably reads, WRITE_SIZE exact; profiles/{pmc['_file']})"
         N.release_domain("babybear")
 
     # ---------------- N > 1 only: ONE large NTT split over the ranks (4-step, all-to-all over RCCL/xGMI) -----

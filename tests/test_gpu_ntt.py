@@ -88,6 +88,34 @@ def test_ntt_device_inplace_async(env, hip, logn):
     st.destroy()
 
 
+def test_ntt_16_byte_lane_passes_and_unaligned_fallback(env, hip):
+    """2^16 = two 2^8 passes with 32-column tiles: on 16-byte-aligned device buffers k_ntt_fast runs its uint4 load /
+    store paths (V4), on buffers that start 4 bytes off a 16-byte boundary the 4-byte-lane passes. Both must equal
+    the reference CPU backend word for word (test_mod_arithmetic_api.h:694 memcmp)."""
+    import torch
+
+    fname, F, rf, N = env
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4242)
+    n, batch = 1 << 16, 5
+    x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+    cfg = hip.NTTConfigU32.default()
+    cfg.batch_size = batch
+    for direction, ordering in ((N.FORWARD, N.kNN), (N.INVERSE, N.kNN), (N.FORWARD, N.kNR)):
+        cfg.ordering = ordering
+        exp = rf.ntt(x, n, 0 if direction == N.FORWARD else 1, batch=batch, ordering=ordering)
+        for shift in (0, 1):  # element offset of both buffers inside 16-byte-aligned allocations
+            src = torch.zeros(n * batch + 4, dtype=torch.int32, device=dev)
+            dst = torch.zeros(n * batch + 4, dtype=torch.int32, device=dev)
+            src[shift:shift + n * batch] = torch.from_numpy(x.view(np.int32)).to(dev)
+            assert (src.data_ptr() + 4 * shift) % 16 == 4 * shift
+            N.ntt(fname, src.data_ptr() + 4 * shift, direction, cfg, out=dst.data_ptr() + 4 * shift, size=n)
+            torch.cuda.synchronize()
+            got = dst[shift:shift + n * batch].cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, exp), (direction, ordering, shift)
+            assert int(dst[:shift].abs().sum()) == 0 and int(dst[shift + n * batch:].abs().sum()) == 0  # nothing outside
+
+
 def test_ntt_extension_field(env, hip):
     fname, F, rf, N = env
     rng = np.random.default_rng(5)
