@@ -203,14 +203,15 @@ namespace icicle_hip {
     v[0] = w02.x, v[1] = w13.x, v[2] = w02.y, v[3] = w13.y;
   }
 
-  // V4 (16-byte lanes): with unit element stride, 32-column tiles and radix-16 rounds a thread's 16 operands sit in
-  // 16 different rows of ONE column. Lane l of a wave then works for column 4*(l & 7) + (l >> 4) of sub-transform
-  // group 2*wave + ((l >> 3) & 1): the four lanes {l, l+16, l+32, l+48} own four ADJACENT columns of the same rows.
-  // The lane in wave-row r moves the rows {4g + r} as uint4 (its group's four columns), eight consecutive lanes cover
-  // one 128-byte line, and rows_transpose() hands every word to its owner: a quarter of the memory instructions, 16
-  // bytes per lane (the access shape profiles/r02_strided_ubench.txt measured at 1.73 instead of 1.93 ms per pass) for
-  // 4 extra VALU instructions per 4 words. The host picks it when every base is 16-byte aligned; results are
-  // identical word for word.
+  // V4 (16-byte lanes, row pass): with unit element stride, 32-column tiles and radix-16 rounds a thread's 16
+  // operands / results sit in 16 different rows of ONE column. Lane l of a wave works for output column
+  // 4*(l & 7) + (l >> 4) of group 2*wave + ((l >> 3) & 1) (and for input row 4*(l & 3) + (l >> 4) of its 16-row block):
+  // the four lanes {l, l+16, l+32, l+48} own four ADJACENT columns of the same rows. The lane in wave-row r moves the
+  // rows {4g + r} as uint4, eight consecutive lanes cover one 128-byte line, and rows_transpose() hands every word to
+  // its owner: a quarter of the memory instructions for 4 extra VALU instructions per 4 words. Measured (same box,
+  // profiles/r02_notes.md section 6): the row pass of 2^24 x 64 1.90 -> 1.83 ms, 2^16 x 1024 transforms -7 %. The same
+  // paths on the column passes were built and measured neutral (+-1 %), so they are not in the tree. The host picks
+  // V4 when every base is 16-byte aligned; results are identical word for word.
   template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV, bool V4 = false>
   __global__ __launch_bounds__(512, ntt_fast_min_waves(NR, COSET && DIF)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
   {
@@ -234,7 +235,7 @@ namespace icicle_hip {
     const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
     const uint32_t lstride_log = nl.log_max - SS;
     // mapping B (lanes along t) everywhere except the first executed round of a DIF pass (mapping A)
-    static_assert(!V4 || (NQ0 == 4 && NR >= 2 && !OUTREV), "16-byte lanes: radix-16 rounds only");
+    static_assert(!V4 || (DIF && NQ0 == 4 && NR >= 2 && !OUTREV), "16-byte lanes: row pass with radix-16 rounds only");
     // V4 (T == 32): lane l -> column 4*(l & 7) + (l >> 4), group 2*wave + ((l >> 3) & 1); mapping A (NG16 % 16 == 0):
     // row 4*(l & 3) + (l >> 4) of its 16-row block, column 4*wave + ((l >> 2) & 3) -- see the V4 note above
     const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -343,16 +344,7 @@ namespace icicle_hip {
     // (SQ_WAIT_ANY 0.52-0.57 on the column passes, profiles/r01_notes.md).
     auto load_row = [&](uint32_t rloc, uint32_t* x) {
       const uint32_t* __restrict__ pin = in + row_offset(rloc, nl.src_rel != 0);
-      if (V4 && !DIF) { // NQ0 == 4, G0 == 1: slot 4g+c of the lane in wave-row r <- word c of source row brev4(4g+r) (before the transpose)
-        const uint32_t kb = (KB_BITS == 0) ? 0u : (__brev(gB) >> (32 - (KB_BITS > 0 ? KB_BITS : 1)));
-        const uint32_t* p = pin + (in_base + (uint64_t)kb * pd.in_sk + (uint64_t)(tB - wrow));
-        const uint64_t step = pd.in_sk << KB_BITS;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const uint4 v = *reinterpret_cast<const uint4*>(p + (uint64_t)((wrev << 2) | brev_c<2>(g)) * step);
-          x[4 * g] = v.x, x[4 * g + 1] = v.y, x[4 * g + 2] = v.z, x[4 * g + 3] = v.w;
-        }
-      } else if (V4) { // top round of the row pass: slot 4g+c of the lane in wave-row r <- word c of row 4g+r
+      if (V4) { // top round of the row pass: slot 4g+c of the lane in wave-row r <- word c of row 4g+r
         const uint32_t* p = pin + (in_base + (uint64_t)(gA - wrow) + (uint64_t)tA * pd.in_st);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -382,22 +374,14 @@ namespace icicle_hip {
           x[m] = p[((uint64_t)m << QT) * es];
       }
     };
-    // (three-round variants, s >= 9, are already at 110-150 VGPRs: they load each row when it is needed)
     constexpr bool PREFETCH = NR <= 2;
-    uint32_t xin[E];
-    if (PREFETCH && rloc0 < nl.nrows_launch) load_row(rloc0, xin);
-    for (uint32_t rr = 0; rr < rows_per_block && rloc0 + rr < nl.nrows_launch; rr++) {
+    const uint32_t nrows = (rloc0 < nl.nrows_launch) ? std::min<uint32_t>(rows_per_block, nl.nrows_launch - rloc0) : 0u;
+    // one batch row: rounds, LDS exchanges, stores. `xin` = the E operands of the first round (already in registers).
+    // Row rr uses LDS buffer rr & 1; the barrier inside the next row's processing orders the reuse after that.
+    auto process_row = [&](uint32_t rr, const uint32_t* xin) {
       const uint32_t rloc = rloc0 + rr;
       uint32_t* __restrict__ pout = out + row_offset(rloc, nl.dst_rel != 0);
       uint32_t* tile = lds + (size_t)(rr & 1) * L * TP;
-      uint32_t xnext[PREFETCH ? E : 1];
-      const bool has_next = PREFETCH && rr + 1 < rows_per_block && rloc + 1 < nl.nrows_launch;
-      if (PREFETCH) {
-        if (has_next) load_row(rloc + 1, xnext);
-      } else {
-        load_row(rloc, xin);
-      }
-
       if (!DIF) {
         // ================= column pass, DIT =================
 #pragma unroll
@@ -407,11 +391,6 @@ namespace icicle_hip {
 #pragma unroll
           for (int m = 0; m < (1 << NQ0); m++)
             x[m] = xin[u * (1 << NQ0) + m];
-          if (V4) {
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-              rows_transpose(x + 4 * g);
-          }
           if (coset_in) { // row part of g^j (the column part sits in wip)
 #pragma unroll
             for (int m = 0; m < (1 << NQ0); m++)
@@ -440,18 +419,7 @@ namespace icicle_hip {
             for (int m = 0; m < 16; m++)
               x[m] = tile[(base + ((uint32_t)m << q0)) * TP + tB];
             ntt_stages<S, 4, false, false>(x, wr[r - 1]);
-            if (r == NR - 1 && V4) { // the lane in wave-row r stores rows 4g+r, four adjacent columns each
-              uint32_t* q = pout + (in_base + (uint64_t)base * pd.in_sk + (uint64_t)(tB - wrow));
-              const uint64_t step = pd.in_sk << q0;
-#pragma unroll
-              for (int m = 0; m < 16; m++)
-                x[m] = S::mul(x[m], wip[m]);
-#pragma unroll
-              for (int g = 0; g < 4; g++) {
-                rows_transpose(x + 4 * g);
-                *reinterpret_cast<uint4*>(q + (uint64_t)(4 * g + wrow) * step) = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
-              }
-            } else if (r == NR - 1) {
+            if (r == NR - 1) {
               uint32_t* q = pout + (in_base + (uint64_t)base * pd.in_sk + (uint64_t)tB * pd.in_st) * es;
               const uint64_t step = (pd.in_sk << q0) * es;
 #pragma unroll
@@ -599,11 +567,38 @@ namespace icicle_hip {
           }
         }
       }
-      // the next row uses the other LDS buffer; the barrier inside its processing orders the reuse after that
-      if (PREFETCH && has_next) {
+    };
+    if (PREFETCH) {
+      // Software prefetch: the next row's E operands are fetched into xnext while this row is processed (without it a
+      // block alternates between a load phase and a compute / LDS / store phase and the waves sit parked on s_waitcnt
+      // for more than half of their cycles, profiles/r01_notes.md). Two details keep it a prefetch in the ISA:
+      //  * the first row must have LANDED before the loop is entered. With "xin pending" on the entry edge and "xin
+      //    copied from xnext" on the back edge the waitcnt pass merges the two states conservatively and guards the
+      //    first butterflies of EVERY iteration with vmcnt(6..0) right after the next row's loads were issued: it waits
+      //    for those very loads (that is what rounds 1-2 shipped, profiles/r02_notes.md);
+      //  * the copy xin <- xnext stays behind the stores (sched_barrier): hoisted into the second round it needs the
+      //    loads half an iteration early.
+      uint32_t xin[E], xnext[E];
+      if (nrows) {
+        load_row(rloc0, xin);
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
+      }
+      for (uint32_t rr = 0; rr < nrows; rr++) {
+        const bool has_next = rr + 1 < nrows;
+        if (has_next) load_row(rloc0 + rr + 1, xnext);
+        process_row(rr, xin);
+        if (has_next) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < E; m++)
-          xin[m] = xnext[m];
+          for (int m = 0; m < E; m++)
+            xin[m] = xnext[m];
+        }
+      }
+    } else { // (three-round variants, s >= 9, are already at 110-150 VGPRs: they load each row when it is needed)
+      for (uint32_t rr = 0; rr < nrows; rr++) {
+        uint32_t xin[E];
+        load_row(rloc0 + rr, xin);
+        process_row(rr, xin);
       }
     }
   }
@@ -824,16 +819,15 @@ namespace icicle_hip {
     return coset ? pick_variant2<PR, NQ0, NR, true>(dif, inv, outrev) : pick_variant2<PR, NQ0, NR, false>(dif, inv, outrev);
   }
   template <class PR, int NR>
-  static pass_fn_t<PR> pick_v4(bool dif, bool inv)
+  static pass_fn_t<PR> pick_v4(bool inv)
   {
-    if (!dif) return (pass_fn_t<PR>)k_ntt_fast<PR, 4, NR, false, false, false, false, true>;
     return inv ? (pass_fn_t<PR>)k_ntt_fast<PR, 4, NR, true, true, false, false, true> : (pass_fn_t<PR>)k_ntt_fast<PR, 4, NR, true, false, false, false, true>;
   }
 
   template <class PR>
   static pass_fn_t<PR> pick_pass(int s, bool dif, bool inv, bool coset, bool outrev, bool v4)
   {
-    if (v4 && !coset && !outrev && s == 8) return pick_v4<PR, 2>(dif, inv); // 16-byte lanes: 2^8 sub-transforms, 32-column tiles
+    if (v4 && dif && !coset && !outrev && s == 8) return pick_v4<PR, 2>(inv); // 16-byte lanes: row pass of 2^8 sub-transforms, 32-column tiles
     switch (s) {
     case 1: return pick_variant<PR, 1, 1>(dif, inv, coset, outrev);
     case 2: return pick_variant<PR, 2, 1>(dif, inv, coset, outrev);
@@ -1121,7 +1115,7 @@ namespace icicle_hip {
         const bool cvar = nl.coset && (nl.inverse ? pd.is_last != 0 : p == 0);
         // 16-byte lanes need unit element stride, rows and bases on 16-byte boundaries and full 32-column tiles
         static const bool v4_on = !(getenv("ICICLE_HIP_NTT_V4") && atoi(getenv("ICICLE_HIP_NTT_V4")) == 0);
-        const bool v4 = v4_on && lanes == 1 && nl.es == 1 && nl.bs % 4 == 0 && pd.T == 32 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+        const bool v4 = v4_on && pd.is_last && lanes == 1 && nl.es == 1 && nl.bs % 4 == 0 && pd.T == 32 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
         pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, nl.out_rev != 0 && pd.is_last != 0, v4);
         if (!fn) return ICICLE_INVALID_ARGUMENT;
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
