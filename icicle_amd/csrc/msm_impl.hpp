@@ -778,9 +778,11 @@ namespace icicle_hip {
     const uint32_t* src = sorted + wp * cap + offs[bucket] + start;
     typename E::XYZZ acc;
     bool empty = true;
-    // (Prefetching the next point's words into registers during the add was measured in round 2 and bought nothing:
-    // with 3 waves per SIMD the gather latency is already covered and the kernel sits at the VALU issue roof; the
-    // extra register moves it needed cost what it saved -- profiles/r02_notes.md.)
+    // (Prefetching the next point was measured twice in round 2 and bought nothing. In registers it costs 16 VGPRs that
+    // 3 waves per SIMD do not have: spills, and every scratch reload's vmcnt(0) then waits for the prefetch. Through
+    // LDS (global_load_lds_dwordx4 into a per-wave double buffer, no VGPRs, waits verified in the ISA) it is a real
+    // one-iteration-ahead prefetch and still changes nothing: 60.0 vs 60.5 ms. The other two waves of the SIMD already
+    // cover the gather latency; the kernel sits at the VALU issue roof -- profiles/r02_notes.md section 1.)
     // The list is read FOUR entries at a time, one group ahead: a lane's list is contiguous but no other lane shares
     // its 64-byte lines, and by the time a lane came back for the next 4-byte entry (one mixed add = ~4.5 us later)
     // the line had usually left the L2 -- each entry then cost a 64-byte fetch (PMC: 77 GB per 2^26 MSM against
