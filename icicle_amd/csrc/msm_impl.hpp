@@ -355,10 +355,10 @@ namespace icicle_hip {
       };
       uint32_t cur[SORT_EPT];
       fetch(lo, cur);
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first tile lands before the loop (see k_ntt_fast: a pending entry edge makes the waitcnt pass guard every iteration conservatively)
       for (int tile0 = lo; tile0 < hi; tile0 += SORT_TS) {
         uint32_t nxt[SORT_EPT];
-        const bool more = tile0 + (int)SORT_TS < hi;
-        if (more) fetch(tile0 + (int)SORT_TS, nxt);
+        fetch(tile0 + (int)SORT_TS, nxt); // past the end of the chunk every lane is predicated off (zeros)
         if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
         __syncthreads();
         uint32_t el[SORT_EPT], dr[SORT_EPT]; // element, (dest << 16 | rank)
@@ -394,17 +394,22 @@ namespace icicle_hip {
             t.sdest[pos] = (uint16_t)h;
           }
         __syncthreads();
+        // the next tile's words move into `cur` BEFORE this tile's stores are issued: a wait for them at the top of
+        // the next iteration would be a vmcnt(0) behind a data-dependent number of stores, i.e. it would also wait
+        // for every store of this tile (one exposed store latency per tile with a single 1024-thread block per CU)
+        // (the empty asm pins the point where the loaded value must exist: a plain copy is a PHI and its moves -- with
+        // their vmcnt(0) -- are materialised in the loop latch, after the stores)
+#pragma unroll
+        for (int it = 0; it < SORT_EPT; it++) {
+          cur[it] = nxt[it];
+          asm volatile("" : "+v"(cur[it]));
+        }
         const uint32_t ntile = t.cnt[D - 1] + (cursor[D - 1] - t.gbase[D - 1]);
         for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += blockDim.x) {
           const uint32_t h = t.sdest[sidx];
           dst[t.gbase[h] + (sidx - t.cnt[h])] = t.stage[sidx];
         }
         __syncthreads();
-        if (more) {
-#pragma unroll
-          for (int it = 0; it < SORT_EPT; it++)
-            cur[it] = nxt[it];
-        }
       }
     }
   }
@@ -597,10 +602,10 @@ namespace icicle_hip {
     };
     uint32_t cur[SORT_EPT];
     fetch(r0, cur);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), see k_a_scatter
     for (uint32_t tile0 = r0; tile0 < r1; tile0 += SORT_TS) {
       uint32_t nxt[SORT_EPT];
-      const bool more = tile0 + SORT_TS < r1;
-      if (more) fetch(tile0 + SORT_TS, nxt);
+      fetch(tile0 + SORT_TS, nxt); // past the end of the run every lane is predicated off (zeros)
       if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
       // source block (scalar chunk) of an element = last bsrc with boffs[bsrc] <= pos. One binary search per
       // 64 consecutive positions (256 threads, once per tile); an element then starts from its group's answer
@@ -654,17 +659,17 @@ namespace icicle_hip {
           t.sdest[pos] = (uint16_t)bin;
         }
       __syncthreads();
+#pragma unroll
+      for (int it = 0; it < SORT_EPT; it++) { // before the stores, pinned: see k_a_scatter
+        cur[it] = nxt[it];
+        asm volatile("" : "+v"(cur[it]));
+      }
       const uint32_t ntile = min(r1 - tile0, SORT_TS);
       for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += blockDim.x) {
         const uint32_t bin = t.sdest[sidx];
         dst[t.gbase[bin] + (sidx - t.cnt[bin])] = t.stage[sidx];
       }
       __syncthreads();
-      if (more) {
-#pragma unroll
-        for (int it = 0; it < SORT_EPT; it++)
-          cur[it] = nxt[it];
-      }
     }
   }
 
