@@ -828,16 +828,18 @@ namespace icicle_hip {
 
   // buckets[b] += its overflow partials. A group of G lanes handles one overflowing bucket: lanes fold strided
   // partials, then a tree through LDS, so a bucket with thousands of segments -- a 1-bit top window, all-equal
-  // scalars -- costs log-depth, not a serial chain. G = 16 when no bucket has more than 16 segments (the usual
-  // case: the short top window of uniform scalars has ~15 per bucket, and a wave then folds four buckets at once
-  // instead of spending 7 wave-wide additions on each), otherwise 64.
+  // scalars -- costs log-depth, not a serial chain. G follows the largest segment count of the launch: every tree
+  // level is a wave-wide complete addition whether 2 or 64 lanes hold something, so small groups win as long as the
+  // serial part stays short. Measured at BN254 2^26 (short top window, 15-17 segments per bucket, 16 K buckets):
+  // G = 64: 0.70 ms, G = 16: 0.21 ms, G = 4: 0.12 ms (profiles/r02_notes.md section 11).
   template <class C>
   __global__ __launch_bounds__(64) void k_fold_overflow(typename EC<C>::Proj* __restrict__ buckets, const typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ firsts, const uint32_t* __restrict__ ovf_count, uint32_t ovf_cap)
   {
     using E = EC<C>;
     __shared__ typename E::Proj sh[64];
     const uint32_t n = min(ovf_count[0], ovf_cap), nfirst = ovf_count[1];
-    const uint32_t G = ovf_count[2] <= 16 ? 16u : 64u, per_block = 64 / G;
+    const uint32_t mx = ovf_count[2]; // largest number of overflow segments of one bucket
+    const uint32_t G = mx <= 2 ? 1u : (mx <= 32 ? 4u : (mx <= 256 ? 16u : 64u)), per_block = 64 / G;
     const uint32_t lane = threadIdx.x, sub = lane / G, gl = lane % G;
     for (uint32_t q0 = blockIdx.x * per_block; q0 < nfirst; q0 += gridDim.x * per_block) {
       const uint32_t q = q0 + sub;
