@@ -174,6 +174,8 @@ API_SYMBOLS = (
        for op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "scalar_add_vec", "scalar_sub_vec", "bit_reverse")]
     + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
        "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
+       "icicle_hip_msm_release_resident_bases", "icicle_hip_multi_stats", "icicle_hip_test_set_virtual_devices",
+       "icicle_hip_test_use_loopback_rccl", "icicle_hip_test_inject_failure",
        "icicle_hip_create_config_extension", "icicle_hip_destroy_config_extension", "icicle_hip_config_extension_set_int",
        "icicle_hip_config_extension_set_bool"]
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
@@ -256,3 +258,15 @@ lib.icicle_hip_msm_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(M
 lib.icicle_hip_ubench_mixed_add.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
 lib.icicle_hip_ubench_gather.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double)]
 lib.icicle_hip_workspace_bytes.argtypes = [ctypes.POINTER(ctypes.c_size_t)]
+lib.icicle_hip_msm_release_resident_bases.argtypes = [ctypes.c_void_p]
+lib.icicle_hip_multi_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_bool]
+lib.icicle_hip_test_set_virtual_devices.argtypes = [ctypes.c_int]
+lib.icicle_hip_test_use_loopback_rccl.argtypes = [ctypes.c_bool]
+lib.icicle_hip_test_inject_failure.argtypes = [ctypes.c_int, ctypes.c_int]
+
+
+def multi_stats(reset=False):
+    """dict of the multi-device / pipelined-path counters (icicle_hip_multi_stats)"""
+    out = (ctypes.c_uint64 * 5)()
+    check(lib.icicle_hip_multi_stats(out, reset), "multi_stats")
+    return dict(zip(("staged_base_bytes", "staged_scalar_bytes", "exchanged_bucket_bytes", "resident_base_hits", "threaded_calls"), [int(v) for v in out]))

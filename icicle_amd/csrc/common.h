@@ -2,6 +2,7 @@
 // stream-ordered temporaries, kernel timing.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -153,9 +154,44 @@ namespace icicle_hip {
     int (*GroupEnd)();
     const char* (*GetErrorString)(int);
   };
-  const RcclApi* rccl_api(); // nullptr when no RCCL can be loaded
-  // one communicator per device of `devs` (ncclCommInitAll), created once per device list and cached
-  icicle_error_t rccl_comms_for(const std::vector<int>& devs, std::vector<void*>& comms);
+  const RcclApi* rccl_api(); // nullptr when no RCCL can be loaded; the loopback stand-in when that was asked for
+  const RcclApi* rccl_loopback_api(); // rccl_loopback.hip: in-process rehearsal stand-in (never picked unless asked for)
+  bool rccl_is_loopback();
+  // One communicator per device slot of `devs` (ncclCommInitAll), created once per device list and cached. Collectives
+  // on one communicator set must not interleave between two host-side calls, so the set comes with a mutex that the
+  // multi-device entry points hold from their first to their last collective (two host threads calling a multi-device
+  // msm() on the same devices are serialised instead of deadlocking inside RCCL).
+  struct RcclCommSet {
+    std::vector<void*> comms;
+    std::mutex call_mtx;
+  };
+  icicle_error_t rccl_comms_for(const std::vector<int>& devs, RcclCommSet** set);
+
+  // ---- multi-device plumbing shared by msm_multi.hpp and the NTT row-shard paths ----
+  // Device slots of a multi-device call: `P` = min(G, slots) host threads, slot p on physical device devs[p]. Normally
+  // a slot IS a visible GPU. icicle_hip_test_set_virtual_devices(K) (tests only) makes K slots exist whatever the box
+  // has, mapped round-robin onto the physical GPUs -- slots then share a device, each with its own host thread, stream
+  // and (loopback) communicator rank, and slots other than 0 treat the caller's buffers as remote (staged by copy).
+  int virtual_device_slots(); // 0 = off
+  struct DeviceSlots {
+    int home = 0;          // the calling thread's device
+    int P = 1;             // slots used
+    bool is_virtual = false;
+    std::vector<int> devs; // physical device per slot
+    bool local(int p) const { return devs[p] == home && !(is_virtual && p > 0); } // may slot p use the caller's device buffers in place?
+  };
+  icicle_error_t make_device_slots(int G, DeviceSlots* out);
+  // One-shot failure injection for the rehearsal tests: returns true exactly once for the (slot, stage) armed with
+  // icicle_hip_test_inject_failure. Stages: 1 = worker set-up, 2 = right before the bucket-exchange gate,
+  // 3 = right before the result-gather gate.
+  bool test_failure_armed(int slot, int stage);
+  // per-process counters of what the multi-device / pipelined paths moved (icicle_hip_multi_stats)
+  struct MultiStats {
+    std::atomic<uint64_t> staged_base_bytes{0}, staged_scalar_bytes{0}, exchanged_bucket_bytes{0}, resident_base_hits{0}, threaded_calls{0};
+  };
+  MultiStats& multi_stats();
+  // a long-lived non-blocking side stream of the calling thread's device (operand staging runs beside the compute stream)
+  hipStream_t side_stream(int which);
 
   // ---- dominant-kernel timing with hipEvents on the launch stream (bench.py roofline figure) ----
   struct KernelTimer {

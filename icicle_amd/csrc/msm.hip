@@ -60,4 +60,14 @@ icicle_error_t icicle_hip_msm_plan(int msm_size, int scalar_bits, const icicle_m
   *nwin = pl.nwin;
   return ICICLE_SUCCESS;
 }
+// gives the per-device copies made under config.ext "hip_bases_resident" back (bases == NULL: all of them)
+icicle_error_t icicle_hip_msm_release_resident_bases(const void* bases)
+{
+  try {
+    (void)resident_release(bases);
+    return ICICLE_SUCCESS;
+  } catch (...) {
+    return ICICLE_INVALID_ARGUMENT;
+  }
+}
 }

@@ -27,6 +27,7 @@
 #include "common.h"
 #include "ec.hpp"
 #include <algorithm>
+#include <tuple>
 
 namespace icicle_hip {
 
@@ -1292,7 +1293,10 @@ namespace icicle_hip {
     }
     int BB = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / std::max<size_t>(per_msm_bytes, 1)));
     BB = std::min(BB, std::max(1, 60000 / wpf));
-    if (hook && BB < batch) return ICICLE_INVALID_ARGUMENT; // a bucket exchange needs the whole batch in one launch group
+    if (hook && BB < batch) { // a bucket exchange needs the whole batch in one launch group (msm_multi_run checked the grid limit)
+      BB = batch;
+      if ((size_t)BB * wpf > 60000) return ICICLE_INVALID_ARGUMENT;
+    }
     const size_t TW = (size_t)BB * wpf; // windows per launch
     const size_t nbk = TW * nb;
     const size_t nparts = TW << sp.hb;

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "smallfield.hpp"
 #include "ntt_plan.h"
+#include "ntt_multi.hpp"
 #include <thread>
 #include <algorithm>
 #include <cmath>
@@ -26,6 +27,7 @@ namespace icicle_hip {
     uint32_t* tw = nullptr; // tw[i] = w_max^i (Montgomery), i < max_size
     int log_max = -1;
     uint32_t root = 0; // canonical w_max
+    int owner = -1;    // >= 0: brought up by a multi-device call of device `owner`, released with that device's domain
   };
   template <class PR>
   struct DomainStore {
@@ -757,15 +759,21 @@ namespace icicle_hip {
     ICICLE_TRY(bind_current_device());
     const int dev = current_device_id();
     std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
-    auto it = DomainStore<PR>::map().find(dev);
-    if (it != DomainStore<PR>::map().end()) {
-      if (it->second.tw) {
+    auto& m = DomainStore<PR>::map();
+    // this device's domain and the copies a multi-device call of this device brought up elsewhere
+    for (auto it = m.begin(); it != m.end();) {
+      if (it->first != dev && it->second.owner != dev) {
+        ++it;
+        continue;
+      }
+      if (it->second.tw && hipSetDevice(it->first) == hipSuccess) {
         (void)hipDeviceSynchronize();
         (void)hipFree(it->second.tw);
-        arena_trim(dev); // the NTT work buffers cached for this domain's sizes go with it
+        arena_trim(it->first); // the NTT work buffers cached for this domain's sizes go with it
       }
-      DomainStore<PR>::map().erase(it);
+      it = m.erase(it);
     }
+    (void)hipSetDevice(dev);
     return ICICLE_SUCCESS;
   }
 
@@ -849,20 +857,16 @@ namespace icicle_hip {
   static icicle_error_t ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, uint32_t lanes);
 
   // Batched NTT over several devices behind the unchanged <field>_ntt symbol: config.ext {"hip_num_devices": G} cuts
-  // the batch into G contiguous row shards (rows are independent transforms: no collective) and runs
-  // them on min(G, visible GPUs) devices, one host thread + stream per device; the twiddle domain is brought up on a
-  // device the first time it is used (same root as the calling device's). Row-major batches only; synchronous.
+  // the batch into G contiguous row shards (rows are independent transforms: no collective) over
+  // min(G, visible GPUs) device slots -- ntt_multi.hpp holds the slot threads and the upload / compute / download
+  // pipeline. The twiddle domain is brought up on a device the first time it is used (same root as the calling
+  // device's) and released together with the calling device's domain. Row-major batches only.
   template <class PR>
-  static icicle_error_t ntt_multi_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, uint32_t lanes, int G)
+  static icicle_error_t ntt_multi_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, uint32_t lanes, int G, int max_slots)
   {
     if (size <= 0 || !input || !output) return ICICLE_INVALID_ARGUMENT;
-    const int batch = std::max(1, cfg->batch_size);
     ICICLE_TRY(bind_current_device());
     const int home = current_device_id();
-    HIP_TRY(hipStreamSynchronize((hipStream_t)cfg->stream), ICICLE_SYNCHRONIZATION_FAILED);
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev), ICICLE_INVALID_DEVICE);
-    const int P = std::max(1, std::min(G, ndev));
     uint32_t root = 0;
     {
       std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
@@ -870,77 +874,33 @@ namespace icicle_hip {
       if (it == DomainStore<PR>::map().end() || !it->second.tw) return ICICLE_INVALID_ARGUMENT; // domain not initialised
       root = it->second.root;
     }
-    const size_t row_words = (size_t)size * lanes;
     icicle_ntt_config_u32_t sub = *cfg;
     sub.ext = nullptr;
     sub.are_inputs_on_device = sub.are_outputs_on_device = true;
     sub.is_async = true;
-    std::vector<icicle_error_t> rcs(P, ICICLE_SUCCESS);
-    auto worker = [&](int p) -> icicle_error_t {
-      const int dev = (home + p) % ndev;
-      ICICLE_TRY(icicle_hip_set_device(dev));
-      hipStream_t st = nullptr;
-      HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
-      icicle_error_t rc = [&]() -> icicle_error_t {
-        if (dev != home) { // silent success if this device already has the domain
-          icicle_ntt_init_domain_config_t ic{st, false, nullptr};
-          ICICLE_TRY(ntt_init_domain_run<PR>(&root, &ic));
-        }
+    NttRowsJob job;
+    job.input = input, job.output = output;
+    job.row_bytes = (size_t)size * lanes * 4;
+    job.batch = std::max(1, cfg->batch_size);
+    job.G = G, job.max_slots = max_slots;
+    job.in_on_device = cfg->are_inputs_on_device, job.out_on_device = cfg->are_outputs_on_device, job.is_async = cfg->is_async;
+    job.stream = (hipStream_t)cfg->stream;
+    return ntt_rows_multi(
+      job,
+      [&](const void* src, void* dst, int rows, hipStream_t st) -> icicle_error_t {
         icicle_ntt_config_u32_t c2 = sub;
         c2.stream = st;
-        for (int g = p; g < G; g += P) {
-          const int base = batch / G, rem = batch % G;
-          const int lo = g * base + std::min(g, rem), rows = base + (g < rem ? 1 : 0);
-          if (rows == 0) continue;
-          const size_t words = (size_t)rows * row_words, off = (size_t)lo * row_words;
-          TempBuf d_in, d_out;
-          const uint32_t* src = input + off;
-          uint32_t* dst = output + off;
-          const bool in_direct = cfg->are_inputs_on_device && dev == home, out_direct = cfg->are_outputs_on_device && dev == home;
-          if (!in_direct) {
-            HIP_TRY(d_in.alloc(words * 4, st), ICICLE_ALLOCATION_FAILED);
-            HIP_TRY(hipMemcpyAsync(d_in.ptr(), src, words * 4, hipMemcpyDefault, st), ICICLE_COPY_FAILED);
-            src = d_in.as<uint32_t>();
-          }
-          uint32_t* o = dst;
-          if (!out_direct) {
-            if (!in_direct) {
-              o = d_in.as<uint32_t>(); // in place on the staged copy
-            } else {
-              HIP_TRY(d_out.alloc(words * 4, st), ICICLE_ALLOCATION_FAILED);
-              o = d_out.as<uint32_t>();
-            }
-          }
-          c2.batch_size = rows;
-          ICICLE_TRY(ntt_run<PR>(src, size, dir, &c2, o, lanes));
-          if (!out_direct) HIP_TRY(hipMemcpyAsync(dst, o, words * 4, hipMemcpyDefault, st), ICICLE_COPY_FAILED);
-          HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
-        }
+        c2.batch_size = rows;
+        return ntt_run<PR>((const uint32_t*)src, size, dir, &c2, (uint32_t*)dst, lanes);
+      },
+      [&](hipStream_t st) -> icicle_error_t { // silent success if this device already has the domain
+        icicle_ntt_init_domain_config_t ic{st, false, nullptr};
+        ICICLE_TRY(ntt_init_domain_run<PR>(&root, &ic));
+        std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
+        auto& d = DomainStore<PR>::map()[current_device_id()];
+        if (d.owner < 0) d.owner = home; // brought up on behalf of `home`: goes when home's domain goes
         return ICICLE_SUCCESS;
-      }();
-      (void)hipStreamSynchronize(st);
-      (void)hipStreamDestroy(st);
-      return rc;
-    };
-    if (P == 1) {
-      rcs[0] = worker(0);
-    } else {
-      std::vector<std::thread> th;
-      for (int p = 0; p < P; p++)
-        th.emplace_back([&, p]() {
-          try {
-            rcs[p] = worker(p);
-          } catch (...) {
-            rcs[p] = ICICLE_INVALID_ARGUMENT;
-          }
-        });
-      for (auto& t : th)
-        t.join();
-    }
-    ICICLE_TRY(icicle_hip_set_device(home));
-    for (int p = 0; p < P; p++)
-      if (rcs[p] != ICICLE_SUCCESS) return rcs[p];
-    return ICICLE_SUCCESS;
+      });
   }
 
   template <class PR>
@@ -950,7 +910,12 @@ namespace icicle_hip {
     if (!cfg) return ICICLE_INVALID_POINTER;
     if (cfg->ext && !cfg->columns_batch) {
       const int G = reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_num_devices", 0);
-      if (G >= 1) return ntt_multi_run<PR>(input, size, dir, cfg, output, lanes, G);
+      if (G >= 1) return ntt_multi_run<PR>(input, size, dir, cfg, output, lanes, G, 0);
+    }
+    // host-resident rows of a large batch on one GPU: row groups through the upload / compute / download pipeline
+    if (!cfg->columns_batch && (!cfg->are_inputs_on_device || !cfg->are_outputs_on_device) && size > 0 && input && output && virtual_device_slots() == 0) {
+      const int groups = ntt_host_row_groups((size_t)size * lanes * 4, std::max(1, cfg->batch_size));
+      if (groups > 1) return ntt_multi_run<PR>(input, size, dir, cfg, output, lanes, groups, 1);
     }
     if (size <= 0 || (size & (size - 1)) != 0) return ICICLE_INVALID_ARGUMENT; // cpu_ntt_main.h:38-41
     if (!input || !output) return ICICLE_INVALID_POINTER;

@@ -18,6 +18,7 @@
 // < 32), back to canonical on every store.
 #include "ntt_big_common.hpp"
 #include "ntt_plan.h"
+#include "ntt_multi.hpp"
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -200,15 +201,20 @@ namespace icicle_hip {
     ICICLE_TRY(bind_current_device());
     const int dev = current_device_id();
     std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
-    auto it = BigDomainStore<PR>::map().find(dev);
-    if (it != BigDomainStore<PR>::map().end()) {
-      if (it->second.tw) {
+    auto& m = BigDomainStore<PR>::map();
+    for (auto it = m.begin(); it != m.end();) { // this device's domain + the copies its multi-device calls made elsewhere
+      if (it->first != dev && it->second.owner != dev) {
+        ++it;
+        continue;
+      }
+      if (it->second.tw && hipSetDevice(it->first) == hipSuccess) {
         (void)hipDeviceSynchronize();
         (void)hipFree(it->second.tw);
-        arena_trim(dev); // the NTT work buffers cached for this domain's sizes go with it
+        arena_trim(it->first); // the NTT work buffers cached for this domain's sizes go with it
       }
-      BigDomainStore<PR>::map().erase(it);
+      it = m.erase(it);
     }
+    (void)hipSetDevice(dev);
     return ICICLE_SUCCESS;
   }
 
@@ -247,11 +253,65 @@ namespace icicle_hip {
   }
 
   template <class PR>
+  static icicle_error_t big_ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output);
+
+  // row shards over device slots / row groups of a host-resident batch: see ntt_multi.hpp (same contract as ntt.hip)
+  template <class PR>
+  static icicle_error_t big_ntt_multi_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output, int G, int max_slots)
+  {
+    if (size <= 0 || !input || !output) return ICICLE_INVALID_ARGUMENT;
+    ICICLE_TRY(bind_current_device());
+    const int home = current_device_id();
+    uint32_t root[8];
+    {
+      std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
+      auto it = BigDomainStore<PR>::map().find(home);
+      if (it == BigDomainStore<PR>::map().end() || !it->second.tw) return ICICLE_INVALID_ARGUMENT; // domain not initialised
+      memcpy(root, it->second.root, 32);
+    }
+    icicle_ntt_config_u256_t sub = *cfg;
+    sub.ext = nullptr;
+    sub.are_inputs_on_device = sub.are_outputs_on_device = true;
+    sub.is_async = true;
+    NttRowsJob job;
+    job.input = input, job.output = output;
+    job.row_bytes = (size_t)size * 32;
+    job.batch = std::max(1, cfg->batch_size);
+    job.G = G, job.max_slots = max_slots;
+    job.in_on_device = cfg->are_inputs_on_device, job.out_on_device = cfg->are_outputs_on_device, job.is_async = cfg->is_async;
+    job.stream = (hipStream_t)cfg->stream;
+    return ntt_rows_multi(
+      job,
+      [&](const void* src, void* dst, int rows, hipStream_t st) -> icicle_error_t {
+        icicle_ntt_config_u256_t c2 = sub;
+        c2.stream = st;
+        c2.batch_size = rows;
+        return big_ntt_run<PR>((const uint32_t*)src, size, dir, &c2, (uint32_t*)dst);
+      },
+      [&](hipStream_t st) -> icicle_error_t {
+        icicle_ntt_init_domain_config_t ic{st, false, nullptr};
+        ICICLE_TRY(big_init_domain_run<PR>(root, &ic));
+        std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
+        auto& d = BigDomainStore<PR>::map()[current_device_id()];
+        if (d.owner < 0) d.owner = home;
+        return ICICLE_SUCCESS;
+      });
+  }
+
+  template <class PR>
   static icicle_error_t big_ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output)
   {
     using F = FieldOps<PR>;
     using fe = typename F::fe;
     if (!cfg) return ICICLE_INVALID_POINTER;
+    if (cfg->ext && !cfg->columns_batch) {
+      const int G = reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_num_devices", 0);
+      if (G >= 1) return big_ntt_multi_run<PR>(input, size, dir, cfg, output, G, 0);
+    }
+    if (!cfg->columns_batch && (!cfg->are_inputs_on_device || !cfg->are_outputs_on_device) && size > 0 && input && output && virtual_device_slots() == 0) {
+      const int groups = ntt_host_row_groups((size_t)size * 32, std::max(1, cfg->batch_size));
+      if (groups > 1) return big_ntt_multi_run<PR>(input, size, dir, cfg, output, groups, 1);
+    }
     if (size <= 0 || (size & (size - 1)) != 0) return ICICLE_INVALID_ARGUMENT; // cpu_ntt_main.h:38-41
     if (!input || !output) return ICICLE_INVALID_POINTER;
     if (dir != ICICLE_NTT_FORWARD && dir != ICICLE_NTT_INVERSE) return ICICLE_INVALID_ARGUMENT;

@@ -50,6 +50,7 @@ namespace icicle_hip {
     uint32_t* tw = nullptr; // tw[i*8 .. i*8+7] = packed Montgomery w_max^i, i < max_size
     int log_max = -1;
     uint32_t root[8] = {0}; // canonical w_max
+    int owner = -1;         // >= 0: brought up by a multi-device call of device `owner` (released with its domain)
   };
   template <class PR>
   struct BigDomainStore {

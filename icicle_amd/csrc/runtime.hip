@@ -220,7 +220,19 @@ namespace icicle_hip {
   }
 
   // ---- RCCL loader ------------------------------------------------------------------------------
-  const RcclApi* rccl_api()
+  static std::atomic<int> g_loopback{-1}; // -1: not decided yet (environment), 0 / 1: set
+  bool rccl_is_loopback()
+  {
+    int v = g_loopback.load();
+    if (v < 0) {
+      const char* e = getenv("ICICLE_HIP_RCCL");
+      v = (e && strcmp(e, "loopback") == 0) ? 1 : 0;
+      g_loopback.store(v);
+    }
+    return v == 1;
+  }
+
+  static const RcclApi* rccl_real_api()
   {
     static RcclApi api;
     static const bool ok = []() {
@@ -250,25 +262,81 @@ namespace icicle_hip {
     return ok ? &api : nullptr;
   }
 
-  icicle_error_t rccl_comms_for(const std::vector<int>& devs, std::vector<void*>& comms)
+  const RcclApi* rccl_api() { return rccl_is_loopback() ? rccl_loopback_api() : rccl_real_api(); }
+
+  icicle_error_t rccl_comms_for(const std::vector<int>& devs, RcclCommSet** set)
   {
     static std::mutex mtx;
-    static std::map<std::vector<int>, std::vector<void*>> cache;
+    static std::map<std::pair<bool, std::vector<int>>, RcclCommSet*> cache; // sets live as long as the process
     const RcclApi* api = rccl_api();
-    if (!api) return ICICLE_API_NOT_IMPLEMENTED;
+    if (!api || !set) return ICICLE_API_NOT_IMPLEMENTED;
     std::lock_guard<std::mutex> g(mtx);
-    auto it = cache.find(devs);
+    const auto key = std::make_pair(rccl_is_loopback(), devs);
+    auto it = cache.find(key);
     if (it == cache.end()) {
-      std::vector<void*> c(devs.size(), nullptr);
-      const int rc = api->CommInitAll(c.data(), (int)devs.size(), devs.data());
+      auto* cs = new RcclCommSet;
+      cs->comms.assign(devs.size(), nullptr);
+      const int rc = api->CommInitAll(cs->comms.data(), (int)devs.size(), devs.data());
       if (rc != 0) {
         fprintf(stderr, "[icicle_hip] ncclCommInitAll failed: %s\n", api->GetErrorString ? api->GetErrorString(rc) : "?");
+        delete cs;
         return ICICLE_INVALID_DEVICE;
       }
-      it = cache.emplace(devs, std::move(c)).first;
+      it = cache.emplace(key, cs).first;
     }
-    comms = it->second;
+    *set = it->second;
     return ICICLE_SUCCESS;
+  }
+
+  // ---- multi-device plumbing -------------------------------------------------------------------
+  static std::atomic<int> g_virtual_slots{0};
+  static std::atomic<int> g_fail_slot{-1}, g_fail_stage{0};
+  int virtual_device_slots() { return g_virtual_slots.load(); }
+
+  icicle_error_t make_device_slots(int G, DeviceSlots* out)
+  {
+    if (G < 1 || !out) return ICICLE_INVALID_ARGUMENT;
+    ICICLE_TRY(bind_current_device());
+    const int ndev = device_count_cached();
+    if (ndev < 1) return ICICLE_INVALID_DEVICE;
+    const int vs = virtual_device_slots();
+    out->home = current_device_id();
+    out->is_virtual = vs > 0;
+    out->P = std::max(1, std::min(G, vs > 0 ? vs : ndev));
+    out->devs.resize(out->P);
+    for (int p = 0; p < out->P; p++)
+      out->devs[p] = (out->home + p) % ndev;
+    return ICICLE_SUCCESS;
+  }
+
+  bool test_failure_armed(int slot, int stage)
+  {
+    if (g_fail_stage.load(std::memory_order_relaxed) != stage || g_fail_slot.load(std::memory_order_relaxed) != slot) return false;
+    int expect = stage;
+    return g_fail_stage.compare_exchange_strong(expect, 0); // one shot
+  }
+
+  MultiStats& multi_stats()
+  {
+    static MultiStats s;
+    return s;
+  }
+
+  hipStream_t side_stream(int which)
+  {
+    static std::mutex mtx;
+    static std::map<std::pair<int, int>, hipStream_t> streams; // (device, which) -> stream, never destroyed
+    const int dev = current_device_id();
+    std::lock_guard<std::mutex> g(mtx);
+    auto it = streams.find({dev, which});
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    streams[{dev, which}] = s;
+    return s;
   }
 
   // ---- kernel timing ---------------------------------------------------------------------------
@@ -336,6 +404,45 @@ icicle_error_t icicle_hip_kernel_timing(int which, bool reset, double* total_ms,
       (void)hipEventDestroy(sp.b);
     }
     g_spans[which].clear();
+  }
+  return ICICLE_SUCCESS;
+}
+
+// ---- rehearsal hooks for the multi-device paths (tests; see include/icicle_hip.h) ----
+icicle_error_t icicle_hip_test_set_virtual_devices(int slots)
+{
+  if (slots < 0 || slots > 64) return ICICLE_INVALID_ARGUMENT;
+  g_virtual_slots.store(slots);
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_hip_test_use_loopback_rccl(bool on)
+{
+  g_loopback.store(on ? 1 : 0);
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_hip_test_inject_failure(int slot, int stage)
+{
+  if (stage < 0 || stage > 3) return ICICLE_INVALID_ARGUMENT;
+  g_fail_slot.store(slot);
+  g_fail_stage.store(stage);
+  return ICICLE_SUCCESS;
+}
+icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset)
+{
+  MultiStats& m = multi_stats();
+  if (out5) {
+    out5[0] = m.staged_base_bytes.load();
+    out5[1] = m.staged_scalar_bytes.load();
+    out5[2] = m.exchanged_bucket_bytes.load();
+    out5[3] = m.resident_base_hits.load();
+    out5[4] = m.threaded_calls.load();
+  }
+  if (reset) {
+    m.staged_base_bytes = 0;
+    m.staged_scalar_bytes = 0;
+    m.exchanged_bucket_bytes = 0;
+    m.resident_base_hits = 0;
+    m.threaded_calls = 0;
   }
   return ICICLE_SUCCESS;
 }

@@ -300,6 +300,27 @@ icicle_error_t icicle_hip_ubench_gather(uint64_t region_bytes, uint64_t gathers,
  * <field>_ntt_release_domain); workspace_bytes reports what is cached for the active device. */
 icicle_error_t icicle_hip_release_workspace(void);
 icicle_error_t icicle_hip_workspace_bytes(size_t* bytes);
+/* MSMConfig.ext / NTTConfig.ext keys this backend reads (include/icicle/backend/msm_config.h:4-16 is the reference's
+ * vehicle for backend knobs; the plugin copies them out of the reference's ConfigExtension key by key):
+ *   "hip_num_devices"          int   msm + ntt: cut the work into this many shards over min(G, visible GPUs) devices
+ *   "hip_msm_exchange_buckets" bool  msm: exchange bucket slices (grouped send / recv) instead of partial results
+ *   "hip_bases_resident"       bool  msm: keep the per-device copies of the base shards between calls (the caller
+ *                                    promises the bases at that pointer do not change); released by the function below
+ *   "hip_force_rccl"           bool  msm: take the RCCL exchange even with one device (test hook)
+ * icicle_hip_msm_release_resident_bases(bases) frees the resident copies made for `bases` (NULL: for every pointer). */
+icicle_error_t icicle_hip_msm_release_resident_bases(const void* bases);
+/* Counters of what the multi-device / pipelined paths moved since the last reset, out[5] = { base bytes staged to a
+ * device, scalar bytes staged, bucket bytes sent by the bucket exchange, resident-base hits (shards NOT staged again),
+ * calls that ran one host thread per device slot }. */
+icicle_error_t icicle_hip_multi_stats(uint64_t* out, bool reset);
+/* Rehearsal hooks for the multi-device code on a box with fewer GPUs than device slots (tests only; see
+ * icicle_amd/csrc/rccl_loopback.hip): K virtual device slots mapped round-robin onto the physical GPUs, an in-process
+ * stand-in for the RCCL calls (real RCCL refuses one GPU twice in a communicator; ICICLE_HIP_RCCL=loopback in the
+ * environment selects it as well), and a one-shot failure of device slot `slot` at stage 1 (worker set-up), 2 (right
+ * before the bucket-exchange gate) or 3 (right before the result-gather gate); stage 0 disarms. */
+icicle_error_t icicle_hip_test_set_virtual_devices(int slots);
+icicle_error_t icicle_hip_test_use_loopback_rccl(bool on);
+icicle_error_t icicle_hip_test_inject_failure(int slot, int stage);
 
 /* ---- collision-free aliases used by the reference-runtime plugin (plugin/):
  * same functions as the un-prefixed names above, for processes that also load the reference's own
