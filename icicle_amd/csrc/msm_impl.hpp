@@ -1361,6 +1361,7 @@ namespace icicle_hip {
         }
         acc_bases = d_mont.as<uint32_t>();
       }
+      KernelTimer::begin(2, st);
       const uint32_t* sc = d_scalars + (size_t)b0 * n * FR::N32;
       const size_t nscal = (size_t)bb * n;
       const size_t lds_dc = ((size_t)wpf << sp.hb) * 4;
@@ -1419,6 +1420,7 @@ namespace icicle_hip {
         k_bsize_scatter<<<szblk, 1024, 0, st>>>(count, d_szoff.as<uint32_t>(), d_perm.as<uint32_t>(), gbk, pl.seg);
         LAUNCH_CHECK("k_bsize_scatter", st);
       }
+      KernelTimer::end(2, st);
       KernelTimer::begin(0, st);
       {
         // waves per SIMD the register allocator must leave room for: 3 fits BN254 G1 (157 VGPRs) without
@@ -1447,6 +1449,7 @@ namespace icicle_hip {
       }
       LAUNCH_CHECK("k_accumulate", st);
       KernelTimer::end(0, st);
+      KernelTimer::begin(3, st);
       k_fold_overflow<C><<<std::min<uint32_t>(ovf_cap, 4096), 64, 0, st>>>(buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_firsts.as<uint32_t>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
       LAUNCH_CHECK("k_fold_overflow", st);
       uint32_t seg_lo = 0, nsegr = nseg;
@@ -1471,6 +1474,7 @@ namespace icicle_hip {
       }
       k_final<C><<<bb, FinalThreads<C>::value, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c);
       LAUNCH_CHECK("k_final", st);
+      KernelTimer::end(3, st);
     }
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
 

@@ -345,8 +345,8 @@ namespace icicle_hip {
     hipEvent_t a, b;
   };
   static std::mutex g_time_mtx;
-  static std::deque<TimedSpan> g_spans[2];
-  static thread_local hipEvent_t g_open[2];
+  static std::deque<TimedSpan> g_spans[4];
+  static thread_local hipEvent_t g_open[4];
 
   bool KernelTimer::enabled() { return g_timing.load(std::memory_order_relaxed); }
   void KernelTimer::begin(int which, hipStream_t s)
@@ -355,6 +355,7 @@ namespace icicle_hip {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, s);
+    if (g_open[which]) (void)hipEventDestroy(g_open[which]); // a span that was never closed (skipped phase)
     g_open[which] = e;
   }
   void KernelTimer::end(int which, hipStream_t s)
@@ -384,7 +385,7 @@ icicle_error_t icicle_hip_enable_kernel_timing(bool enable)
 
 icicle_error_t icicle_hip_kernel_timing(int which, bool reset, double* total_ms, int* launches)
 {
-  if (which < 0 || which > 1 || !total_ms || !launches) return ICICLE_INVALID_ARGUMENT;
+  if (which < 0 || which > 3 || !total_ms || !launches) return ICICLE_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> g(g_time_mtx);
   double tot = 0;
   int n = 0;

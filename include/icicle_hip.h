@@ -286,7 +286,8 @@ icicle_error_t babybear_hip_twiddle_rows(uint32_t* data, uint64_t rows, uint64_t
 icicle_error_t koalabear_hip_twiddle_rows(uint32_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t logn_total, bool inverse, icicleStreamHandle stream);
 /* Average device time (ms) of the dominant kernel's launches since the last reset, measured with
  * hipEvents on the launch stream (bench.py's live roofline figure). which: 0 = MSM bucket
- * accumulation, 1 = NTT pass kernels. */
+ * accumulation, 1 = NTT pass kernels, 2 = MSM digit extraction + bucket sort (everything in front of the
+ * accumulation), 3 = MSM bucket reduction + window combine (everything behind it). */
 icicle_error_t icicle_hip_kernel_timing(int which, bool reset, double* total_ms, int* launches);
 icicle_error_t icicle_hip_enable_kernel_timing(bool enable);
 /* Roofs of the dominant MSM kernel, measured on the spot (bench.py reports them next to the kernel's own rate):

@@ -7,6 +7,7 @@
 #   test_curve_api_{bn254,bls12_381}     icicle/tests/test_curve_api.cpp        (-DMSM -DG2_ENABLED -DECNTT, no PAIRING)
 #   test_modarith_{babybear,koalabear,bn254,bls12_381}  icicle/tests/test_mod_arithmetic_api.h via oracle/shim/tests/modarith_main.cpp
 #   example_msm, example_ntt             examples/c++/{msm,ntt}/example.cpp (bn254), run as `example_msm HIP`
+#   example_best_practice_ntt            examples/c++/best-practice-ntt/example.cpp (three streams)
 # Run with ICICLE_BACKEND_INSTALL_DIR=oracle/_ref/backend so that the reference runtime loads the HIP plugin and makes
 # "HIP" the main device (icicle/tests/test_base.h:37-46): tests/test_gpu_reference_suite.py.
 set -euo pipefail
@@ -47,5 +48,9 @@ for e in msm ntt; do
     $CXX -std=c++17 -O2 -pthread -w -I$R/include -I$EX -DCURVE_ID=1 -DFIELD_ID=1 -DG2_ENABLED "$EX/$e/example.cpp" \
       -L"$REF" -licicle_curve_bn254 -licicle_field_bn254 -licicle_device $RP -o "$OUT/example_$e" & }
 done
+# examples/c++/best-practice-ntt/example.cpp: the three-stream upload / compute / download pattern (bn254 scalar field, 2^20 x 16)
+newer "$OUT/example_best_practice_ntt" || { echo "[ref-tests] example_best_practice_ntt"
+  $CXX -std=c++17 -O2 -pthread -w -I$R/include -I$EX -DCURVE_ID=1 -DFIELD_ID=1 "$EX/best-practice-ntt/example.cpp" \
+    -L"$REF" -licicle_curve_bn254 -licicle_field_bn254 -licicle_device $RP -o "$OUT/example_best_practice_ntt" & }
 wait
 ls -la "$OUT"

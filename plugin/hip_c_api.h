@@ -114,11 +114,13 @@ struct HipExt {
   explicit HipExt(const icicle::ConfigExtension* e)
   {
     if (!e) return;
-    const bool nd = e->has("hip_num_devices"), xb = e->has("hip_msm_exchange_buckets");
-    if (!nd && !xb) return;
+    const bool nd = e->has("hip_num_devices"), xb = e->has("hip_msm_exchange_buckets"), rb = e->has("hip_bases_resident"), fr = e->has("hip_force_rccl");
+    if (!nd && !xb && !rb && !fr) return;
     h = icicle_hip_create_config_extension();
     if (nd) icicle_hip_config_extension_set_int(h, "hip_num_devices", e->get<int>("hip_num_devices"));
     if (xb) icicle_hip_config_extension_set_bool(h, "hip_msm_exchange_buckets", e->get<bool>("hip_msm_exchange_buckets"));
+    if (rb) icicle_hip_config_extension_set_bool(h, "hip_bases_resident", e->get<bool>("hip_bases_resident"));
+    if (fr) icicle_hip_config_extension_set_bool(h, "hip_force_rccl", e->get<bool>("hip_force_rccl"));
   }
   ~HipExt()
   {

@@ -261,7 +261,7 @@ def test_generated_points_are_distinct_multiples_of_g(hip):
     assert np.array_equal(pts, exp)
 
 
-@pytest.mark.parametrize("cname,logn,top", [("bn254", 26, 0x30644E72), ("bls12_381", 25, 0x73EDA753)])
+@pytest.mark.parametrize("cname,logn,top", [("bn254", 26, 0x30644E72)])  # (config 3 runs whole: test_gpu_fullsize_configs.py)
 def test_msm_full_size_split_property(hip, cname, logn, top):
     """BASELINE config 1 size (2^26 BN254) and the per-GPU share of config 3 (BLS12-381 2^28 over 8 GPUs = 2^25),
     inputs resident in HBM: the size-independent property MSM(all) == MSM(first half) + MSM(second half), with the

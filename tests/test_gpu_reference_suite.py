@@ -69,9 +69,10 @@ def test_reference_modarith_suite(hip, field):
         assert _ran(outs[0], t), (t, outs[0][-3000:])
 
 
-@pytest.mark.parametrize("example", ["msm", "ntt"])
+@pytest.mark.parametrize("example", ["msm", "ntt", "best_practice_ntt"])
 def test_reference_cpp_examples_on_hip(hip, example):
-    """examples/c++/msm and examples/c++/ntt of the reference, compiled unmodified, with device "HIP" selected by name
+    """examples/c++/msm, examples/c++/ntt and examples/c++/best-practice-ntt (uploads, downloads and in-place NTTs on three
+    streams at once) of the reference, compiled unmodified, with device "HIP" selected by name
     (examples_utils.h try_load_and_set_backend_device): the drop-in as a user of the reference sees it. The examples
     print their timings and throw (non-zero exit) on any API error."""
     exe = os.path.join(TESTS, f"example_{example}")

@@ -104,6 +104,58 @@ __global__ __launch_bounds__(512, 4) void k_tile_dma(uint32_t* __restrict__ buf,
   }
 }
 
+
+// ---- two-pass question: a 2^24 transform as 2^12 x 2^12 needs [4096 rows x T columns] tiles held
+// on chip; 1024 threads x 64 words = 4096 x 16, so T = 16 and every HBM run is 64 bytes (half a line). This is that
+// tile moved with 16-byte lanes (4 lanes per run, 16 runs per thread), in place (pass-0 pattern: rows 16 KiB apart), or
+// read from one contiguous 256 KiB chunk and written strided (last-pass pattern). SWZ: blocks b and b + 8 -- same XCD,
+// dispatched back to back -- take the two halves of the same 128-byte lines, so the second half can hit in that L2.
+template <bool SWZ, bool CONTIG_READ>
+__global__ __launch_bounds__(1024) void k_tile_2pass(uint32_t* __restrict__ buf, int write)
+{
+  constexpr uint32_t ROWS = 4096, T = 16, TPA = 4096 / T; // tiles per 2^24-element transform
+  uint32_t tile = blockIdx.x;
+  if (SWZ) {
+    const uint32_t xcd = blockIdx.x % 8, k = blockIdx.x / 8;
+    tile = ((k / 2) * 8 + xcd) * 2 + (k % 2);
+  }
+  const uint32_t a = tile / TPA, ct = tile % TPA;
+  uint32_t* tbase = buf + ((uint64_t)a << 24);
+  const uint32_t t = threadIdx.x % 4, g = threadIdx.x / 4; // 256 row groups
+  uint4 v[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) {
+    const uint32_t row = g + 256 * m;
+    const uint32_t* src = CONTIG_READ ? tbase + (uint64_t)ct * (ROWS * T) + row * T + 4 * t : tbase + (uint64_t)row * 4096 + ct * T + 4 * t;
+    v[m] = *reinterpret_cast<const uint4*>(src);
+  }
+  if (write) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      const uint32_t row = g + 256 * m;
+      v[m].x += 1;
+      *reinterpret_cast<uint4*>(tbase + (uint64_t)row * 4096 + ct * T + 4 * t) = v[m];
+    }
+  } else {
+    uint32_t s = 0;
+#pragma unroll
+    for (int m = 0; m < 16; m++)
+      s ^= v[m].x ^ v[m].y ^ v[m].z ^ v[m].w;
+    if (s == 0x12345678u) tbase[t] = s;
+  }
+}
+
+// in-place contiguous read + write over a region that is swept `reps` times inside ONE launch sequence: does a working
+// set that fits the 256 MiB Infinity Cache move faster than HBM? (row-group question: 2 rows of 2^24 words = 128 MiB)
+__global__ __launch_bounds__(256) void k_sweep(uint4* __restrict__ buf, uint64_t n4)
+{
+  const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  uint4 v = buf[i];
+  v.x += 1;
+  buf[i] = v;
+}
+
 int main()
 {
   const uint64_t n = 1ull << 30; // 4 GiB
@@ -177,6 +229,49 @@ int main()
         if (ms < best) best = ms;
       }
       printf("LDS-DMA in, 16 B/lane out, stride %6llu elements, 128 B runs, 32 rows per block   read+write %8.3f ms  %7.0f GB/s\n", (unsigned long long)stride, best, (double)n * 8 / best / 1e6);
+    }
+  }
+  { // 64-byte runs: the [4096 x 16] register tile of a two-pass plan
+    const uint32_t ntiles = (uint32_t)(n >> 24) * 256;
+    for (int write = 1; write >= 0; write--)
+      for (int variant = 0; variant < 4; variant++) {
+        float best = 1e9;
+        for (int it = 0; it < 4; it++) {
+          CK(hipEventRecord(e0));
+          switch (variant) {
+          case 0: k_tile_2pass<false, false><<<ntiles, 1024>>>(d, write); break;
+          case 1: k_tile_2pass<true, false><<<ntiles, 1024>>>(d, write); break;
+          case 2: k_tile_2pass<false, true><<<ntiles, 1024>>>(d, write); break;
+          default: k_tile_2pass<true, true><<<ntiles, 1024>>>(d, write); break;
+          }
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (ms < best) best = ms;
+        }
+        const double bytes = (double)n * 4 * (write ? 2 : 1);
+        printf("two-pass tile 4096 x 16 (64 B runs, 16 B/lane, 1024 threads) %-28s %-10s %s %8.3f ms  %7.0f GB/s\n",
+               variant >= 2 ? "contiguous read, strided write" : "strided in place (16 KiB rows)", (variant & 1) ? "XCD-paired" : "linear", write ? "read+write" : "read only ", best,
+               bytes / best / 1e6);
+      }
+  }
+  { // Infinity-Cache question: the same bytes moved as 16 sweeps over a small region vs one sweep over 4 GiB
+    for (uint64_t mb : {32ull, 64ull, 128ull, 192ull, 256ull, 512ull, 4096ull}) {
+      const uint64_t n4 = (mb << 20) / 16, reps = 4096 / mb * 4;
+      float best = 1e9;
+      for (int it = 0; it < 3; it++) {
+        CK(hipEventRecord(e0));
+        for (uint64_t r = 0; r < reps; r++)
+          k_sweep<<<(unsigned)((n4 + 255) / 256), 256>>>(reinterpret_cast<uint4*>(d), n4);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+      }
+      printf("in-place sweep of a %4llu MiB region x %3llu launches: %8.3f ms  %7.0f GB/s read+write\n", (unsigned long long)mb, (unsigned long long)reps, best,
+             (double)(mb << 20) * 2 * reps / best / 1e6);
     }
   }
   return 0;
