@@ -290,7 +290,8 @@ def main():
         msm_step()
     lib.icicle_hip_enable_kernel_timing(True)
     tot, cnt = ctypes.c_double(), ctypes.c_int()
-    lib.icicle_hip_kernel_timing(0, True, ctypes.byref(tot), ctypes.byref(cnt))
+    for which in (0, 2, 3):
+        lib.icicle_hip_kernel_timing(which, True, ctypes.byref(tot), ctypes.byref(cnt))
     barrier_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -300,7 +301,13 @@ def main():
     lib.icicle_hip_kernel_timing(0, True, ctypes.byref(tot), ctypes.byref(cnt))
     lib.icicle_hip_enable_kernel_timing(False)
     msm_ms = dt / args.steps * 1e3
-    acc_ms = tot.value / max(1, cnt.value)
+    # bucket accumulation of ONE MSM = the sum of its k_accumulate launches (one per window group of the pipelined schedule)
+    acc_ms = tot.value / max(1, args.steps)
+    acc_launches = cnt.value
+    phases = {}
+    for which, name in ((2, "sort_exposed_ms"), (3, "tail_exposed_ms")):
+        lib.icicle_hip_kernel_timing(which, True, ctypes.byref(tot), ctypes.byref(cnt))
+        phases[name] = tot.value / max(1, args.steps)
     msm_bytes = n * (32 + 64) + 96  # N*sizeof(scalar) + N*sizeof(affine) + sizeof(projective)
     total_terms = (1 << args.size_log2) if strong else world * n
     units_per_step = total_terms / float(1 << 26)  # in 2^26-term MSMs
@@ -308,7 +315,8 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "k_accumulate<bn254_g1>", "achieved": msm_bytes / (acc_ms * 1e-3) / 1e9,
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": msm_bytes / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": None, "avg_launch_ms": acc_ms, "launches": cnt.value,
+        "traffic": None, "avg_launch_ms": acc_ms, "launches": acc_launches, "launches_per_msm": acc_launches / max(1, args.steps),
+        "phases_ms": {"accumulate": acc_ms, **phases, "whole_msm": msm_ms},
         "note": "MSM is integer-ALU bound (v_mad_u64_u32), not HBM bound; see DESIGN.md and 'alu'",
     }
     # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (bench.py cannot

@@ -193,6 +193,12 @@ namespace icicle_hip {
   // a long-lived non-blocking side stream of the calling thread's device (operand staging runs beside the compute stream)
   hipStream_t side_stream(int which);
 
+  // A few events per host thread and device, created once and reused round-robin: a call that stays asynchronous may
+  // return while its stream waits are still pending, so events cannot be destroyed at the end of a call (a wait refers
+  // to the record that was current when it was issued; re-recording later is harmless).
+  hipEvent_t ring_event();
+  void ring_events_release(); // a short-lived worker thread gives its events back before it ends (its streams are idle then)
+
   // ---- dominant-kernel timing with hipEvents on the launch stream (bench.py roofline figure) ----
   struct KernelTimer {
     static bool enabled();

@@ -6,12 +6,13 @@
 // feature applies: orderings, coset generator, batch / columns_batch, 1/N on the inverse. It uses the
 // twiddle domain of the scalar-field NTT (<curve>_ntt_init_domain).
 //
-// A butterfly here is one 254-bit scalar multiplication (~380 complete point operations, ~1.2 M
-// instructions per lane) plus two point additions; memory traffic is irrelevant by five orders of
-// magnitude. So this is deliberately the plainest correct structure: points live in HBM in the
-// kernels' internal form (Montgomery limbs, 3 x 9 or 3 x 14 words), the transform is radix-2 DIT with
-// one launch per stage and one thread per butterfly, and the reorderings / coset / 1/N factors are
-// folded into the load and store kernels. The projective representative of a result differs from
+// A butterfly here is one 254-bit scalar multiplication (4-bit windows: 252 Jacobian doublings + <= 77 complete
+// additions, ~0.8 M instructions) plus two point additions; memory traffic is irrelevant by five orders of
+// magnitude, and a stage of an ECNTT of practical size has far fewer butterflies than the chip has lanes: the
+// time of a stage is the LATENCY of one scalar multiplication. So the structure is radix-2 DIT with one launch per
+// stage, points in HBM in the kernels' internal form (Montgomery limbs, 3 x 9 or 3 x 14 words), and FOUR lanes (a DPP
+// quad) per butterfly sharing the doubling chain (three dependent products per doubling instead of seven); the
+// reorderings / coset / 1/N factors are folded into the load and store kernels. The projective representative of a result differs from
 // the reference's (it depends on the order of additions); the group element is the same -- tests
 // compare to_affine() limbs, as for the MSM.
 #include "ntt_big_common.hpp"
@@ -28,15 +29,39 @@ namespace icicle_hip {
     using FR = FieldOps<typename C::fr>;
     using Proj = typename E::Proj;
 
-    // k * p, k = 8 canonical words (MSB-first double-and-add over complete formulas)
-    static __device__ Proj mul_words(const Proj& p, const uint32_t* k)
+    // k * p, k = 8 canonical words: fixed 4-bit windows, most significant first (the reference's own scalar
+    // multiplication is windowed too, include/icicle/curves/projective.h:192-224) -- per window four doublings on the
+    // Jacobian chain of ec.hpp (2M + 5S each instead of 6M + 2S + 1 for the complete doubling; Z = 0 stays Z = 0 and
+    // comes back as the identity) and at most one COMPLETE addition of a table entry, so no input is exceptional:
+    // 252 doublings + <= 63 + 14 additions instead of 255 + ~127 of the bit-serial form.
+    // QUAD: the four lanes of a DPP quad hold the same operands and share every doubling (dbl_jac_quad: three dependent
+    // products per step instead of seven) -- a butterfly is a pure latency chain and an ECNTT stage has far fewer
+    // butterflies than the chip has lanes, so spending four lanes on one chain is free.
+    template <bool QUAD>
+    static __device__ Proj mul_words(const Proj& p, const uint32_t* k, uint32_t role = 0)
     {
+      Proj tab[16];
+      tab[0] = E::proj_identity();
+      tab[1] = p;
+      tab[2] = E::dbl(p);
+      for (int i = 3; i < 16; i++)
+        tab[i] = E::add(tab[i - 1], p);
       Proj r = E::proj_identity();
       bool started = false;
-      for (int bit = 255; bit >= 0; bit--) {
-        if (started) r = E::dbl(r);
-        if ((k[bit >> 5] >> (bit & 31)) & 1) {
-          r = started ? E::add(r, p) : p;
+      for (int d = 63; d >= 0; d--) {
+        const uint32_t dig = (k[d >> 3] >> ((d & 7) * 4)) & 15u;
+        if (started) {
+          typename E::Jac j = E::to_jac(r);
+          for (int q = 0; q < 4; q++) {
+            if constexpr (QUAD)
+              j = E::dbl_jac_quad(j, role);
+            else
+              j = E::dbl_jac(j);
+          }
+          r = E::from_jac(j);
+          if (dig) r = E::add(r, tab[dig]);
+        } else if (dig) {
+          r = tab[dig];
           started = true;
         }
       }
@@ -85,20 +110,26 @@ namespace icicle_hip {
     if (lay.coset && !lay.inverse && j != 0) {
       uint32_t k[8];
       T::canonical_from_mont(k, coset_pow + j * 8);
-      p = T::mul_words(p, k);
+      p = T::template mul_words<false>(p, k);
     }
     work[b * lay.n + i] = p;
   }
 
-  // stage q: pairs (i, i + 2^q) inside blocks of 2^(q+1); twiddle w_n^(pos * n / 2^(q+1))
+  // stage q: pairs (i, i + 2^q) inside blocks of 2^(q+1); twiddle w_n^(pos * n / 2^(q+1)).
+  // Four lanes (one DPP quad) per butterfly: see EcNtt::mul_words<QUAD>. All four lanes load the same pair, lane 0 stores.
   template <class C>
   __global__ __launch_bounds__(64) void k_ecntt_stage(typename EC<C>::Proj* __restrict__ work, const uint32_t* __restrict__ tw, EcLayout lay, int q)
   {
     using T = EcNtt<C>;
     using E = typename T::E;
-    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint32_t role = threadIdx.x & 3u;
     const uint64_t half_n = lay.n >> 1;
-    if (t >= half_n * lay.batch) return;
+    const uint64_t nbf = half_n * lay.batch;
+    // a quad past the end redoes the last butterfly (same values) and does not store: every lane of a wave runs the same
+    // trip counts, which the DPP exchanges of the doubling chain rely on
+    const bool live = (lane >> 2) < nbf;
+    const uint64_t t = live ? (lane >> 2) : nbf - 1;
     const uint64_t b = t / half_n, bf = t % half_n;
     const uint64_t half = (uint64_t)1 << q;
     const uint64_t pos = bf & (half - 1);
@@ -112,10 +143,12 @@ namespace icicle_hip {
       if (lay.inverse) idx = (((uint64_t)1 << lay.log_max) - idx) & max_mask;
       uint32_t k[8];
       T::canonical_from_mont(k, tw + idx * 8);
-      v = T::mul_words(v, k);
+      v = T::template mul_words<true>(v, k, role);
     }
-    base[i] = E::add(u, v);
-    base[i + half] = E::add(u, T::neg(v));
+    if (live && role == 0) {
+      base[i] = E::add(u, v);
+      base[i + half] = E::add(u, T::neg(v));
+    }
   }
 
   // out[slot(k)] = (1/N * g^-k on the inverse) * work[b][k], in the reference's projective_t layout
@@ -129,11 +162,11 @@ namespace icicle_hip {
     const uint64_t b = t / lay.n, k = t % lay.n;
     typename E::Proj p = work[b * lay.n + k];
     if (lay.inverse) {
-      p = T::mul_words(p, ninv_canonical.w);
+      p = T::template mul_words<false>(p, ninv_canonical.w);
       if (lay.coset && k != 0) {
         uint32_t s[8];
         T::canonical_from_mont(s, coset_pow + k * 8);
-        p = T::mul_words(p, s);
+        p = T::template mul_words<false>(p, s);
       }
     }
     const uint64_t m = lay.out_rev ? bitrev64(k, lay.logn) : k;
@@ -220,7 +253,7 @@ namespace icicle_hip {
     k_ecntt_load<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(d_in, work, d_pw.as<uint32_t>(), lay);
     LAUNCH_CHECK("k_ecntt_load", st);
     for (int q = 0; q < logn; q++) {
-      k_ecntt_stage<C><<<(unsigned)((tot / 2 + 63) / 64), 64, 0, st>>>(work, dom.tw, lay, q);
+      k_ecntt_stage<C><<<(unsigned)((tot / 2 * 4 + 63) / 64), 64, 0, st>>>(work, dom.tw, lay, q);
       LAUNCH_CHECK("k_ecntt_stage", st);
     }
     k_ecntt_store<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(work, d_out, d_pw.as<uint32_t>(), ninv, lay);

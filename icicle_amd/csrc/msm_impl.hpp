@@ -31,6 +31,9 @@
 
 namespace icicle_hip {
 
+  #ifndef MSM_DEFAULT_GROUPS
+  #define MSM_DEFAULT_GROUPS 1 // window groups of the pipelined schedule (msm_run_single); ICICLE_HIP_MSM_GROUPS overrides
+  #endif
   struct MsmPlan {
     int bits;    // scalar bits considered
     int c;       // window bits
@@ -327,10 +330,11 @@ namespace icicle_hip {
   // pass A scatter: element = sign | low key bits | j | index within chunk, into partition runs
   // FINAL: single-level sort (lb == 0): the element is already the bucket-list entry (point index | sign)
   template <bool FINAL>
-  __global__ __launch_bounds__(1024) void k_a_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int nwin, int wpf, int pf, SortPlan sp, size_t cap)
+  __global__ __launch_bounds__(1024) void k_a_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int nwin, int wpf, int pf, SortPlan sp, size_t cap, int wl0)
   {
+    // wl0: first window of this launch (window groups of the pipelined schedule); every table is indexed by the global wl
     extern __shared__ uint32_t lds[];
-    const int b = blockIdx.x, wl = blockIdx.y, wp = wl % wpf;
+    const int b = blockIdx.x, wl = wl0 + (int)blockIdx.y, wp = wl % wpf;
     const size_t rowbase = (size_t)(wl / wpf) * nwin;
     const uint32_t D = 1u << sp.hb;
     TileLds t = tile_lds(lds, D);
@@ -466,10 +470,11 @@ namespace icicle_hip {
   }
 
   // single-level sort (lb == 0): bucket k of window wl IS partition k; count/offs come from pass A's table
-  static __global__ __launch_bounds__(256) void k_tables_from_a(const uint32_t* __restrict__ offA, uint32_t* __restrict__ count, uint32_t* __restrict__ offs, size_t nbk, uint32_t nb, int nblk, size_t totals_base)
+  static __global__ __launch_bounds__(256) void k_tables_from_a(const uint32_t* __restrict__ offA, uint32_t* __restrict__ count, uint32_t* __restrict__ offs, size_t nbk, uint32_t nb, int nblk, size_t totals_base, size_t bk0)
   {
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nbk) return;
+    t += bk0;
     const size_t wl = t / nb;
     const uint32_t k = (uint32_t)(t - wl * nb);
     const uint32_t ps = offA[t * nblk];
@@ -485,13 +490,15 @@ namespace icicle_hip {
   // k_b_scatter reserves a range per (block, bin) with ONE global atomic and ranks inside it in LDS.
   constexpr uint32_t CHUNKB_LOG = 17;
 
-  static __global__ __launch_bounds__(1024) void k_b_plan(const uint32_t* __restrict__ offA, uint32_t* __restrict__ bstart, uint32_t nparts, int wpf, int hb, int nblk)
+  static __global__ __launch_bounds__(1024) void k_b_plan(const uint32_t* __restrict__ offA, uint32_t* __restrict__ bstart, uint32_t nparts, int wpf, int hb, int nblk, uint32_t p0)
   {
+    // plans partitions [p0, p0 + nparts) (one window group); bstart[] is local to the group, wpf = windows of the whole launch
     __shared__ uint32_t part[1024];
     const uint32_t per = (nparts + 1023) / 1024;
     const uint32_t lo = min(nparts, threadIdx.x * per), hi = min(nparts, lo + per);
     const uint32_t nparts_w = 1u << hb;
-    auto psize = [&](uint32_t p) -> uint32_t {
+    auto psize = [&](uint32_t pl) -> uint32_t {
+      const uint32_t p = p0 + pl;
       const uint32_t wp = p >> hb, h = p & (nparts_w - 1);
       const size_t row = (size_t)p * nblk;
       const uint32_t ps = offA[row];
@@ -518,11 +525,11 @@ namespace icicle_hip {
   }
 
   // block -> (partition p, element range [r0,r1) in the window's pass-A array); false if idle
-  __device__ __forceinline__ bool b_locate(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ offA, uint32_t nparts, int wpf, int hb, int nblk, uint32_t& p, uint32_t& r0, uint32_t& r1)
+  __device__ __forceinline__ bool b_locate(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ offA, uint32_t nparts, int wpf, int hb, int nblk, uint32_t p0, uint32_t& p, uint32_t& r0, uint32_t& r1)
   {
     const uint32_t blk = blockIdx.x;
     if (blk >= bstart[nparts]) return false;
-    uint32_t lo = 0, hi = nparts; // last p with bstart[p] <= blk
+    uint32_t lo = 0, hi = nparts; // last (group-local) p with bstart[p] <= blk
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
       if (bstart[mid] <= blk) {
@@ -531,22 +538,23 @@ namespace icicle_hip {
         hi = mid;
       }
     }
-    p = lo;
+    const uint32_t first = bstart[lo];
+    p = p0 + lo; // global partition index from here on
     const uint32_t nparts_w = 1u << hb;
     const uint32_t wp = p >> hb, h = p & (nparts_w - 1);
     const size_t row = (size_t)p * nblk;
     const uint32_t ps = offA[row];
     const uint32_t pe = (h + 1 < nparts_w) ? offA[row + nblk] : offA[(size_t)wpf * nparts_w * nblk + wp];
-    r0 = ps + ((blk - bstart[p]) << CHUNKB_LOG);
+    r0 = ps + ((blk - first) << CHUNKB_LOG);
     r1 = min(pe, r0 + (1u << CHUNKB_LOG));
     return r0 < r1;
   }
 
-  static __global__ __launch_bounds__(1024) void k_b_count(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ count, uint32_t nparts, int wpf, SortPlan sp, size_t cap, uint32_t nb)
+  static __global__ __launch_bounds__(1024) void k_b_count(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ count, uint32_t nparts, int wpf, SortPlan sp, size_t cap, uint32_t nb, uint32_t p0)
   {
     extern __shared__ uint32_t lds[];
     uint32_t p, r0, r1;
-    if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p, r0, r1)) return;
+    if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p0, p, r0, r1)) return;
     const uint32_t nbins = 1u << sp.lb;
     for (uint32_t k = threadIdx.x; k < nbins; k += blockDim.x)
       lds[k] = 0;
@@ -572,11 +580,11 @@ namespace icicle_hip {
       if (lds[k]) atomicAdd(&cw[k], lds[k]);
   }
 
-  static __global__ __launch_bounds__(1024) void k_b_scatter(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted, uint32_t nparts, int wpf, int pf, SortPlan sp, size_t cap, uint32_t nb)
+  static __global__ __launch_bounds__(1024) void k_b_scatter(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted, uint32_t nparts, int wpf, int pf, SortPlan sp, size_t cap, uint32_t nb, uint32_t p0)
   {
     extern __shared__ uint32_t lds[]; // tile-sort arrays | [nblk+1] piece offsets of this partition
     uint32_t p, r0, r1;
-    if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p, r0, r1)) return;
+    if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p0, p, r0, r1)) return;
     const uint32_t D = 1u << sp.lb;
     TileLds t = tile_lds(lds, D);
     uint32_t* boffs = lds + tile_lds_bytes(D) / 4;
@@ -688,10 +696,12 @@ namespace icicle_hip {
 
   // ovf_count[0] = overflow segments, [1] = overflowing buckets, [2] = largest number of segments of one bucket;
   // firsts[i] = slot of the first segment of the i-th overflowing bucket
-  static __global__ __launch_bounds__(256) void k_plan_overflow(const uint32_t* __restrict__ count, size_t nbk, uint32_t seg, uint32_t* __restrict__ ovf_count, OvfSeg* __restrict__ ovf, uint32_t* __restrict__ firsts, uint32_t ovf_cap)
+  static __global__ __launch_bounds__(256) void k_plan_overflow(const uint32_t* __restrict__ count, size_t nbk, uint32_t seg, uint32_t* __restrict__ ovf_count, OvfSeg* __restrict__ ovf, uint32_t* __restrict__ firsts, uint32_t ovf_cap, size_t bk0)
   {
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    // buckets [bk0, bk0 + nbk) (one window group); bucket ids in the plan are global
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (t >= nbk) return;
+    t += bk0;
     const uint32_t cnt = count[t];
     if (cnt <= seg) return;
     const uint32_t extra = (cnt + seg - 1) / seg - 1;
@@ -722,7 +732,7 @@ namespace icicle_hip {
     const uint32_t q = (uint32_t)(((uint64_t)min(cnt, seg) * 256u) / seg); // 0..256
     return 256u - q;                                                       // heavy first
   }
-  static __global__ __launch_bounds__(1024) void k_bsize_count(const uint32_t* __restrict__ count, uint32_t* __restrict__ table, size_t nbk, uint32_t seg)
+  static __global__ __launch_bounds__(1024) void k_bsize_count(const uint32_t* __restrict__ count, uint32_t* __restrict__ table, size_t nbk, uint32_t seg, size_t bk0)
   {
     __shared__ uint32_t hist[SZ_BINS];
     for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
@@ -732,13 +742,13 @@ namespace icicle_hip {
 #pragma unroll
     for (int it = 0; it < 16; it++) {
       const size_t b = base + it * 1024 + threadIdx.x;
-      if (b < nbk) atomicAdd(&hist[size_class(count[b], seg)], 1u);
+      if (b < nbk) atomicAdd(&hist[size_class(count[bk0 + b], seg)], 1u);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
       table[(size_t)k * gridDim.x + blockIdx.x] = hist[k];
   }
-  static __global__ __launch_bounds__(1024) void k_bsize_scatter(const uint32_t* __restrict__ count, const uint32_t* __restrict__ table_off, uint32_t* __restrict__ perm, size_t nbk, uint32_t seg)
+  static __global__ __launch_bounds__(1024) void k_bsize_scatter(const uint32_t* __restrict__ count, const uint32_t* __restrict__ table_off, uint32_t* __restrict__ perm, size_t nbk, uint32_t seg, size_t bk0)
   {
     __shared__ uint32_t cursor[SZ_BINS];
     for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
@@ -748,7 +758,7 @@ namespace icicle_hip {
 #pragma unroll
     for (int it = 0; it < 16; it++) {
       const size_t b = base + it * 1024 + threadIdx.x;
-      if (b < nbk) perm[atomicAdd(&cursor[size_class(count[b], seg)], 1u)] = (uint32_t)b;
+      if (b < nbk) perm[atomicAdd(&cursor[size_class(count[bk0 + b], seg)], 1u)] = (uint32_t)(bk0 + b);
     }
   }
 
@@ -1009,23 +1019,26 @@ namespace icicle_hip {
   struct FinalThreads {
     static constexpr int value = sizeof(typename EC<C>::fe) > 64 ? 256 : 512;
   };
+  // Window groups (pipelined schedule): the kernel combines windows [w0, w0 + nw) of each MSM -- still scaled by their
+  // full 2^(c*w) -- and, when `partial` is given, leaves the group's sum there in the kernels' own representation for
+  // k_final_combine; the long chains of the HIGH windows then run while the low windows are still being accumulated.
   template <class C>
-  __global__ __launch_bounds__(FinalThreads<C>::value) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c)
+  __global__ __launch_bounds__(FinalThreads<C>::value) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c, int w0, int nw, typename EC<C>::Proj* __restrict__ partial)
   {
     using E = EC<C>;
     __shared__ typename E::Proj sh[128];
     // four lanes per window: the doubling chain 2^(c*w) * S_w is the latency floor of the whole MSM, and a quad
     // runs it with three dependent products per step instead of seven (ec.hpp dbl_jac_quad)
     const uint32_t role = threadIdx.x & 3u;
-    winsum += (size_t)blockIdx.x * wpf;
+    winsum += (size_t)blockIdx.x * wpf + w0;
     result += (size_t)blockIdx.x * 3 * E::N32;
     for (int w = threadIdx.x >> 2; w < 128; w += FinalThreads<C>::value >> 2) {
       typename E::Proj v = E::proj_identity();
-      if (w < wpf) {
+      if (w < nw) {
         v = winsum[w];
-        if (w > 0) { // Jacobian doubling chain (ec.hpp), 2M + 5S per step
+        if (w0 + w > 0) { // Jacobian doubling chain (ec.hpp), 2M + 5S per step
           typename E::Jac j = E::to_jac(v);
-          for (int i = 0; i < w * c; i++) // the same trip count in all four lanes of a quad
+          for (int i = 0; i < (w0 + w) * c; i++) // the same trip count in all four lanes of a quad
             j = E::dbl_jac_quad(j, role);
           v = E::from_jac(j);
         }
@@ -1034,14 +1047,31 @@ namespace icicle_hip {
     }
     __syncthreads();
     int top = 1;
-    while (top < wpf)
+    while (top < nw)
       top <<= 1;
     const int lane = threadIdx.x;
     for (int s = top >> 1; s >= 1; s >>= 1) {
       if (lane < s) sh[lane] = E::add(sh[lane], sh[lane + s]);
       __syncthreads();
     }
-    if (lane == 0) E::store_proj_canonical(result, sh[0]);
+    if (lane == 0) {
+      if (partial)
+        partial[blockIdx.x] = sh[0];
+      else
+        E::store_proj_canonical(result, sh[0]);
+    }
+  }
+  // result[b] = sum of the ng group partials of MSM b (partials[g * nmsm + b]), canonical words
+  template <class C>
+  __global__ __launch_bounds__(64) void k_final_combine(const typename EC<C>::Proj* __restrict__ partials, uint32_t* __restrict__ result, int ng, int nmsm)
+  {
+    using E = EC<C>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nmsm) return;
+    typename E::Proj v = partials[b];
+    for (int g = 1; g < ng; g++)
+      v = E::add(v, partials[(size_t)g * nmsm + b]);
+    E::store_proj_canonical(result + (size_t)b * 3 * E::N32, v);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -1314,18 +1344,18 @@ namespace icicle_hip {
     HIP_TRY(d_sorted.alloc(TW * cap * 4 + 64, st), ICICLE_ALLOCATION_FAILED); // + slack: k_accumulate reads lists in groups of 4
     HIP_TRY(d_cntA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_offA.alloc(tabA * 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_bstart.alloc((nparts + 1) * 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_bstart.alloc((nparts + 1 + 16) * 4, st), ICICLE_ALLOCATION_FAILED); // + one end marker per window group
     HIP_TRY(d_count.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_offs.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_cursor.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_buckets.alloc(nbk * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_seg.alloc(2 * TW * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED); // chunk V | chunk T
     HIP_TRY(d_win.alloc(TW * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_ovf.alloc((size_t)ovf_cap * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_ovfpart.alloc((size_t)ovf_cap * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_firsts.alloc((size_t)std::min<size_t>(ovf_cap, nbk) * 4 + 4, st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_ovfcnt.alloc(16, st), ICICLE_ALLOCATION_FAILED);
-    const size_t szblk_max = (nbk + SZ_CHUNK - 1) / SZ_CHUNK;
+    HIP_TRY(d_ovf.alloc(((size_t)ovf_cap + 16 * 16) * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED); // (+ the per-group slack of the pipelined schedule)
+    HIP_TRY(d_ovfpart.alloc(((size_t)ovf_cap + 16 * 16) * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_firsts.alloc(((size_t)ovf_cap + 16 * 17) * 4 + 4, st), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(d_ovfcnt.alloc(16 * 16, st), ICICLE_ALLOCATION_FAILED); // [overflow segments, overflowing buckets, largest bucket, -] per window group
+    const size_t szblk_max = (nbk + SZ_CHUNK - 1) / SZ_CHUNK + 16; // (+ one partial block per window group)
     HIP_TRY(d_perm.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_sztab.alloc(szblk_max * SZ_BINS * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_szoff.alloc(szblk_max * SZ_BINS * 4, st), ICICLE_ALLOCATION_FAILED);
@@ -1383,98 +1413,234 @@ namespace icicle_hip {
         k_scan_apply<<<dim3(nch, (unsigned)tw), 1024, 0, st>>>(cntA, d_scansum.as<uint32_t>(), offA, nullptr, offA + (size_t)tw * m, m);
       }
       LAUNCH_CHECK("k_scan_a", st);
-      if (single_level) {
-        k_a_scatter<true><<<dim3(sp.nblk, (unsigned)tw), 1024, ldsA, st>>>(dig, offA, sorted, n, pl.nwin, wpf, pf, sp, cap);
-        LAUNCH_CHECK("k_a_scatter<final>", st);
-        k_tables_from_a<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(offA, count, offs, gbk, nb, sp.nblk, gparts * sp.nblk);
-        LAUNCH_CHECK("k_tables_from_a", st);
-      } else {
-        uint32_t* partA = d_partA.as<uint32_t>();
-        const size_t elems = (size_t)bb * n * pl.nwin + 1;
-        const uint32_t nblkB = (uint32_t)std::min<size_t>(gparts + (elems >> CHUNKB_LOG) + 2, maxblkB);
-        k_a_scatter<false><<<dim3(sp.nblk, (unsigned)tw), 1024, ldsA, st>>>(dig, offA, partA, n, pl.nwin, wpf, pf, sp, cap);
-        LAUNCH_CHECK("k_a_scatter", st);
-        k_b_plan<<<1, 1024, 0, st>>>(offA, d_bstart.as<uint32_t>(), (uint32_t)gparts, (int)tw, sp.hb, sp.nblk);
-        LAUNCH_CHECK("k_b_plan", st);
-        HIP_TRY(hipMemsetAsync(count, 0, gbk * 4, st), ICICLE_COPY_FAILED);
-        k_b_count<<<nblkB, 1024, ((size_t)1 << sp.lb) * 4, st>>>(partA, offA, d_bstart.as<uint32_t>(), count, (uint32_t)gparts, (int)tw, sp, cap, nb);
-        LAUNCH_CHECK("k_b_count", st);
-        {
-          const uint32_t nch = (nb + SCAN_CHUNK - 1) / SCAN_CHUNK;
-          k_scan_sums<<<dim3(nch, (unsigned)tw), 1024, 0, st>>>(count, d_scansum.as<uint32_t>(), nb);
-          k_scan_apply<<<dim3(nch, (unsigned)tw), 1024, 0, st>>>(count, d_scansum.as<uint32_t>(), offs, d_cursor.as<uint32_t>(), nullptr, nb);
-        }
-        LAUNCH_CHECK("k_scan_buckets", st);
-        k_b_scatter<<<nblkB, 1024, ldsB, st>>>(partA, offA, d_bstart.as<uint32_t>(), d_cursor.as<uint32_t>(), sorted, (uint32_t)gparts, (int)tw, pf, sp, cap, nb);
-        LAUNCH_CHECK("k_b_scatter", st);
+
+      // ---- window groups ("pipelined schedule"). Everything behind the digit pass is independent
+      // per window, and the phases are bound by different things: the sort by memory latency, bucket accumulation by
+      // VALU issue, the window combine by the latency of one doubling chain. A single large MSM is therefore cut into
+      // NG groups of windows, HIGHEST windows first: while group g is accumulated on the main stream, group g + 1 is
+      // sorted on a second stream and group g - 1 is reduced and scaled by its 2^(c*w) on a third, so the long doubling
+      // chains of the high windows and most of the sort leave the critical path. NG = 1 is the plain sequence.
+      // Batches (bb > 1) already fill the chip with independent work, and a bucket-exchange hook wants all windows at once.
+      int NG = 1;
+      if (bb == 1 && !hook && tw >= 4) {
+        static const int env_ng = getenv("ICICLE_HIP_MSM_GROUPS") ? atoi(getenv("ICICLE_HIP_MSM_GROUPS")) : MSM_DEFAULT_GROUPS;
+        NG = std::max(1, std::min<int>(env_ng, (int)tw / 2));
       }
-      HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16, st), ICICLE_COPY_FAILED);
-      k_plan_overflow<<<(unsigned)((gbk + 255) / 256), 256, 0, st>>>(count, gbk, pl.seg, d_ovfcnt.as<uint32_t>(), d_ovf.as<OvfSeg>(), d_firsts.as<uint32_t>(), ovf_cap);
-      LAUNCH_CHECK("k_plan_overflow", st);
+      // group g = windows [glo[g], ghi[g]); g = 0 holds the top windows; the end groups are half as wide as the inner
+      // ones (a short first group lets accumulation start early, a short last one leaves little to reduce at the end)
+      int glo[16], ghi[16];
+      NG = std::min(NG, 16);
       {
-        const unsigned szblk = (unsigned)((gbk + SZ_CHUNK - 1) / SZ_CHUNK);
-        const uint32_t m = szblk * SZ_BINS, nch = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        k_bsize_count<<<szblk, 1024, 0, st>>>(count, d_sztab.as<uint32_t>(), gbk, pl.seg);
-        k_scan_sums<<<dim3(nch, 1), 1024, 0, st>>>(d_sztab.as<uint32_t>(), d_scansum.as<uint32_t>(), m);
-        k_scan_apply<<<dim3(nch, 1), 1024, 0, st>>>(d_sztab.as<uint32_t>(), d_scansum.as<uint32_t>(), d_szoff.as<uint32_t>(), nullptr, nullptr, m);
-        k_bsize_scatter<<<szblk, 1024, 0, st>>>(count, d_szoff.as<uint32_t>(), d_perm.as<uint32_t>(), gbk, pl.seg);
-        LAUNCH_CHECK("k_bsize_scatter", st);
-      }
-      KernelTimer::end(2, st);
-      KernelTimer::begin(0, st);
-      {
-        // waves per SIMD the register allocator must leave room for: 3 fits BN254 G1 (157 VGPRs) without
-        // spilling, 2 fits BLS12-381 G1 (14-limb elements) and BN254 G2, 1 for BLS12-381 G2
-        constexpr bool BIGPT = sizeof(typename E::XYZZ) > 256; // G2
-        static const int minw = getenv("ICICLE_HIP_MSM_ACC_WAVES") ? atoi(getenv("ICICLE_HIP_MSM_ACC_WAVES"))
-                                                                   : (BIGPT ? (sizeof(typename E::XYZZ) <= 288 ? 2 : 1) : (E::F::N <= 9 ? 3 : 2));
-        const size_t nthreads_acc = gbk + ovf_cap;
-        const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
-        const size_t bstride = shared ? 0 : npts_one * PW;
-#define ACC_ARGS acc_bases, sorted, count, offs, buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_ovfcnt.as<uint32_t>(), d_perm.as<uint32_t>(), ovf_cap, nb, gbk, cap, pl.seg, wpf, bstride
-        if constexpr (BIGPT) {
-          if constexpr (sizeof(typename E::XYZZ) <= 288) {
-            if (minw >= 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
-            else k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
-          } else {
-            k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
-          }
-        } else {
-          if (minw == 2) k_accumulate<C, 2><<<gridn, 128, 0, st>>>(ACC_ARGS);
-          else if (minw == 4) k_accumulate<C, 4><<<gridn, 128, 0, st>>>(ACC_ARGS);
-          else if (minw == 1) k_accumulate<C, 1><<<gridn, 128, 0, st>>>(ACC_ARGS);
-          else k_accumulate<C, 3><<<gridn, 128, 0, st>>>(ACC_ARGS);
+        const double unit = (double)tw / (NG <= 2 ? NG : NG - 1);
+        double acc = 0;
+        int hi = (int)tw;
+        for (int g = 0; g < NG; g++) {
+          acc += (NG <= 2 || (g > 0 && g < NG - 1)) ? unit : unit / 2;
+          int lo = g == NG - 1 ? 0 : std::max(0, (int)tw - (int)(acc + 0.5));
+          lo = std::min(lo, hi - 1);
+          if (g < NG - 1) lo = std::max(lo, NG - 1 - g); // every later group keeps at least one window
+          glo[g] = lo, ghi[g] = hi;
+          hi = lo;
         }
-#undef ACC_ARGS
       }
-      LAUNCH_CHECK("k_accumulate", st);
-      KernelTimer::end(0, st);
-      KernelTimer::begin(3, st);
-      k_fold_overflow<C><<<std::min<uint32_t>(ovf_cap, 4096), 64, 0, st>>>(buckets, d_ovfpart.as<typename E::Proj>(), d_ovf.as<OvfSeg>(), d_firsts.as<uint32_t>(), d_ovfcnt.as<uint32_t>(), ovf_cap);
-      LAUNCH_CHECK("k_fold_overflow", st);
-      uint32_t seg_lo = 0, nsegr = nseg;
-      if (hook) {
-        bool skip = false;
-        ICICLE_TRY(hook->after_accumulate(buckets, tw, nb, nseg, m, st, &skip, &seg_lo, &nsegr));
-        if (skip) continue; // another shard of this device (or the exchange step) produces the result
+      hipStream_t s_sort = st, s_red = st, s_acc = st;
+      if (NG > 1) {
+        s_sort = side_stream(10);
+        s_red = side_stream(11);
+        if (!s_sort || !s_red) return ICICLE_STREAM_CREATION_FAILED;
+      }
+      // scratch that concurrent groups must not share
+      TempBuf d_gscan, d_part;
+      const size_t scan_words = tw * (std::max<size_t>((size_t)sp.nblk << sp.hb, nb) / SCAN_CHUNK + 1) + (szblk_max * SZ_BINS) / SCAN_CHUNK + 16;
+      if (NG > 1) {
+        HIP_TRY(d_gscan.alloc((size_t)NG * scan_words * 4, st), ICICLE_ALLOCATION_FAILED);
+        HIP_TRY(d_part.alloc((size_t)NG * bb * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
+        HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16 * 16, st), ICICLE_COPY_FAILED);
+      }
+      hipEvent_t ev_ready = nullptr, ev_sorted[16] = {nullptr}, ev_acc[16] = {nullptr}, ev_red[16] = {nullptr};
+      if (NG > 1) {
+        ev_ready = ring_event();
+        if (!ev_ready) return ICICLE_ALLOCATION_FAILED;
+        HIP_TRY(hipEventRecord(ev_ready, st), ICICLE_SYNCHRONIZATION_FAILED); // digits, pass-A tables and every buffer lease are in place
+        HIP_TRY(hipStreamWaitEvent(s_sort, ev_ready, 0), ICICLE_SYNCHRONIZATION_FAILED);
       }
       typename E::Proj* chunkV = d_seg.as<typename E::Proj>();
       typename E::Proj* chunkT = chunkV + TW * nseg;
-      const bool direct = (nseg == 1 && nsegr == 1 && seg_lo == 0);
-      if (tw * nsegr) {
-        k_reduce_wave<C><<<(unsigned)(tw * nsegr), 64, 0, st>>>(buckets, chunkV, chunkT, direct ? d_win.as<typename E::Proj>() : nullptr, nb, mrow, seg_lo, nsegr);
-        LAUNCH_CHECK("k_reduce_wave", st);
+      uint32_t ovf_off = 0;
+      uint32_t g_ovf_off[16], g_ovf_cap[16];
+      for (int g = 0; g < NG; g++) { // overflow segments of a group <= (list entries of its windows) / seg; the caps add up to ovf_cap + 16 NG
+        size_t src = 0; // source windows folded into the group's target windows (precompute: j * wpf + wp < nwin)
+        for (int wp = glo[g]; wp < ghi[g]; wp++)
+          for (int j = 0; j < pf; j++)
+            src += (j * wpf + wp % wpf < pl.nwin) ? 1 : 0;
+        g_ovf_off[g] = ovf_off;
+        g_ovf_cap[g] = NG == 1 ? ovf_cap : (uint32_t)std::min<size_t>(((size_t)n * src) / pl.seg + 16, ovf_cap);
+        ovf_off += g_ovf_cap[g];
       }
-      if (!direct) {
-        unsigned rthreads = 64; // power of two (LDS tree), >= nsegr
-        while (rthreads < nsegr && rthreads < RWL)
-          rthreads <<= 1;
-        k_reduce_window<C><<<(unsigned)tw, rthreads, 0, st>>>(chunkV, chunkT, d_win.as<typename E::Proj>(), nsegr, seg_lo, log_chunk);
-        LAUNCH_CHECK("k_reduce_window", st);
+
+      // ---- phase 1 of a group: bucket lists (pass-A scatter, pass B, overflow plan, size-balanced order)
+      auto sort_group = [&](int g, hipStream_t sq) -> icicle_error_t {
+        const int w0 = glo[g], nw = ghi[g] - glo[g];
+        const size_t bk0 = (size_t)w0 * nb, nbk_g = (size_t)nw * nb;
+        const uint32_t p0 = (uint32_t)((size_t)w0 << sp.hb), np_g = (uint32_t)((size_t)nw << sp.hb);
+        uint32_t* scan_g = NG > 1 ? d_gscan.as<uint32_t>() + (size_t)g * scan_words : d_scansum.as<uint32_t>();
+        if (single_level) {
+          k_a_scatter<true><<<dim3(sp.nblk, (unsigned)nw), 1024, ldsA, sq>>>(dig, offA, sorted, n, pl.nwin, wpf, pf, sp, cap, w0);
+          LAUNCH_CHECK("k_a_scatter<final>", sq);
+          k_tables_from_a<<<(unsigned)((nbk_g + 255) / 256), 256, 0, sq>>>(offA, count, offs, nbk_g, nb, sp.nblk, gparts * sp.nblk, bk0);
+          LAUNCH_CHECK("k_tables_from_a", sq);
+        } else {
+          uint32_t* partA = d_partA.as<uint32_t>();
+          uint32_t* bstart = d_bstart.as<uint32_t>() + p0 + (NG - 1 - g); // nparts_g + 1 entries per group, groups in window order
+          const size_t elems = (size_t)bb * n * pf * (size_t)nw + 1;
+          const uint32_t nblkB = (uint32_t)std::min<size_t>(np_g + (elems >> CHUNKB_LOG) + 2, maxblkB);
+          k_a_scatter<false><<<dim3(sp.nblk, (unsigned)nw), 1024, ldsA, sq>>>(dig, offA, partA, n, pl.nwin, wpf, pf, sp, cap, w0);
+          LAUNCH_CHECK("k_a_scatter", sq);
+          k_b_plan<<<1, 1024, 0, sq>>>(offA, bstart, np_g, (int)tw, sp.hb, sp.nblk, p0);
+          LAUNCH_CHECK("k_b_plan", sq);
+          HIP_TRY(hipMemsetAsync(count + bk0, 0, nbk_g * 4, sq), ICICLE_COPY_FAILED);
+          k_b_count<<<nblkB, 1024, ((size_t)1 << sp.lb) * 4, sq>>>(partA, offA, bstart, count, np_g, (int)tw, sp, cap, nb, p0);
+          LAUNCH_CHECK("k_b_count", sq);
+          {
+            const uint32_t nch = (nb + SCAN_CHUNK - 1) / SCAN_CHUNK;
+            k_scan_sums<<<dim3(nch, (unsigned)nw), 1024, 0, sq>>>(count + bk0, scan_g, nb);
+            k_scan_apply<<<dim3(nch, (unsigned)nw), 1024, 0, sq>>>(count + bk0, scan_g, offs + bk0, d_cursor.as<uint32_t>() + bk0, nullptr, nb);
+          }
+          LAUNCH_CHECK("k_scan_buckets", sq);
+          k_b_scatter<<<nblkB, 1024, ldsB, sq>>>(partA, offA, bstart, d_cursor.as<uint32_t>(), sorted, np_g, (int)tw, pf, sp, cap, nb, p0);
+          LAUNCH_CHECK("k_b_scatter", sq);
+        }
+        uint32_t* ovfcnt = d_ovfcnt.as<uint32_t>() + 4 * g;
+        if (NG == 1) HIP_TRY(hipMemsetAsync(ovfcnt, 0, 16, sq), ICICLE_COPY_FAILED);
+        k_plan_overflow<<<(unsigned)((nbk_g + 255) / 256), 256, 0, sq>>>(count, nbk_g, pl.seg, ovfcnt, d_ovf.as<OvfSeg>() + g_ovf_off[g], d_firsts.as<uint32_t>() + g_ovf_off[g] + g, g_ovf_cap[g], bk0);
+        LAUNCH_CHECK("k_plan_overflow", sq);
+        {
+          const unsigned szblk = (unsigned)((nbk_g + SZ_CHUNK - 1) / SZ_CHUNK);
+          const size_t sz0 = (bk0 / SZ_CHUNK + (size_t)(NG - 1 - g)) * SZ_BINS; // this group's slice of the size tables (groups in window order)
+          const uint32_t m = szblk * SZ_BINS, nch = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
+          uint32_t* sztab = d_sztab.as<uint32_t>() + sz0;
+          uint32_t* szoff = d_szoff.as<uint32_t>() + sz0;
+          k_bsize_count<<<szblk, 1024, 0, sq>>>(count, sztab, nbk_g, pl.seg, bk0);
+          k_scan_sums<<<dim3(nch, 1), 1024, 0, sq>>>(sztab, scan_g, m);
+          k_scan_apply<<<dim3(nch, 1), 1024, 0, sq>>>(sztab, scan_g, szoff, nullptr, nullptr, m);
+          k_bsize_scatter<<<szblk, 1024, 0, sq>>>(count, szoff, d_perm.as<uint32_t>() + bk0, nbk_g, pl.seg, bk0);
+          LAUNCH_CHECK("k_bsize_scatter", sq);
+        }
+        return ICICLE_SUCCESS;
+      };
+
+      // ---- phase 2 of a group: bucket accumulation (+ the fold of the overflow partials)
+      auto accumulate_group = [&](int g, hipStream_t sq) -> icicle_error_t {
+        const int w0 = glo[g], nw = ghi[g] - glo[g];
+        const size_t bk0 = (size_t)w0 * nb, nbk_g = (size_t)nw * nb;
+        uint32_t* ovfcnt = d_ovfcnt.as<uint32_t>() + 4 * g;
+        OvfSeg* ovf = d_ovf.as<OvfSeg>() + g_ovf_off[g];
+        typename E::Proj* ovfpart = d_ovfpart.as<typename E::Proj>() + g_ovf_off[g];
+        const uint32_t ocap = g_ovf_cap[g];
+        KernelTimer::begin(0, sq);
+        {
+          // waves per SIMD the register allocator must leave room for: 3 fits BN254 G1 (157 VGPRs) without
+          // spilling, 2 fits BLS12-381 G1 (14-limb elements) and BN254 G2, 1 for BLS12-381 G2
+          constexpr bool BIGPT = sizeof(typename E::XYZZ) > 256; // G2
+          static const int minw = getenv("ICICLE_HIP_MSM_ACC_WAVES") ? atoi(getenv("ICICLE_HIP_MSM_ACC_WAVES"))
+                                                                     : (BIGPT ? (sizeof(typename E::XYZZ) <= 288 ? 2 : 1) : (E::F::N <= 9 ? 3 : 2));
+          const size_t nthreads_acc = nbk_g + ocap;
+          const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
+          const size_t bstride = shared ? 0 : npts_one * PW;
+#define ACC_ARGS acc_bases, sorted, count, offs, buckets, ovfpart, ovf, ovfcnt, d_perm.as<uint32_t>() + bk0, ocap, nb, nbk_g, cap, pl.seg, wpf, bstride
+          if constexpr (BIGPT) {
+            if constexpr (sizeof(typename E::XYZZ) <= 288) {
+              if (minw >= 2) k_accumulate<C, 2><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+              else k_accumulate<C, 1><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+            } else {
+              k_accumulate<C, 1><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+            }
+          } else {
+            if (minw == 2) k_accumulate<C, 2><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+            else if (minw == 4) k_accumulate<C, 4><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+            else if (minw == 1) k_accumulate<C, 1><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+            else k_accumulate<C, 3><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+          }
+#undef ACC_ARGS
+        }
+        LAUNCH_CHECK("k_accumulate", sq);
+        KernelTimer::end(0, sq);
+        k_fold_overflow<C><<<std::min<uint32_t>(ocap, 4096), 64, 0, sq>>>(buckets, ovfpart, ovf, d_firsts.as<uint32_t>() + g_ovf_off[g] + g, ovfcnt, ocap);
+        LAUNCH_CHECK("k_fold_overflow", sq);
+        return ICICLE_SUCCESS;
+      };
+
+      // ---- phase 3 of a group: bucket reduction of its windows, then their share of the window combine
+      auto reduce_group = [&](int g, hipStream_t sq, uint32_t seg_lo, uint32_t nsegr) -> icicle_error_t {
+        const int w0 = glo[g], nw = ghi[g] - glo[g];
+        const bool direct = (nseg == 1 && nsegr == 1 && seg_lo == 0);
+        typename E::Proj* win = d_win.as<typename E::Proj>() + w0;
+        if ((size_t)nw * nsegr) {
+          k_reduce_wave<C><<<(unsigned)((size_t)nw * nsegr), 64, 0, sq>>>(buckets + (size_t)w0 * nb, chunkV + (size_t)w0 * nseg, chunkT + (size_t)w0 * nseg, direct ? win : nullptr, nb, mrow, seg_lo, nsegr);
+          LAUNCH_CHECK("k_reduce_wave", sq);
+        }
+        if (!direct) {
+          unsigned rthreads = 64; // power of two (LDS tree), >= nsegr
+          while (rthreads < nsegr && rthreads < RWL)
+            rthreads <<= 1;
+          k_reduce_window<C><<<(unsigned)nw, rthreads, 0, sq>>>(chunkV + (size_t)w0 * nseg, chunkT + (size_t)w0 * nseg, win, nsegr, seg_lo, log_chunk);
+          LAUNCH_CHECK("k_reduce_window", sq);
+        }
+        if (NG > 1) { // (bb == 1) this group's windows, scaled, into its partial
+          k_final<C><<<1, FinalThreads<C>::value, 0, sq>>>(d_win.as<typename E::Proj>(), nullptr, wpf, pl.c, w0, nw, d_part.as<typename E::Proj>() + g);
+          LAUNCH_CHECK("k_final(group)", sq);
+        }
+        return ICICLE_SUCCESS;
+      };
+
+      if (NG == 1) {
+        ICICLE_TRY(sort_group(0, st));
+        KernelTimer::end(2, st);
+        ICICLE_TRY(accumulate_group(0, st));
+        KernelTimer::begin(3, st);
+        uint32_t seg_lo = 0, nsegr = nseg;
+        if (hook) {
+          bool skip = false;
+          ICICLE_TRY(hook->after_accumulate(buckets, tw, nb, nseg, m, st, &skip, &seg_lo, &nsegr));
+          if (skip) continue; // another shard of this device (or the exchange step) produces the result
+        }
+        ICICLE_TRY(reduce_group(0, st, seg_lo, nsegr));
+        k_final<C><<<bb, FinalThreads<C>::value, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c, 0, wpf, nullptr);
+        LAUNCH_CHECK("k_final", st);
+        KernelTimer::end(3, st);
+      } else {
+        // main stream: sort(0), accumulate(0), accumulate(1), ... ; sort stream: sort(1), sort(2), ... ; reduce stream:
+        // reduce(0), reduce(1), ... each behind its accumulation. The main stream finally waits for the reduce stream.
+        for (int g = 0; g < NG; g++) {
+          ev_sorted[g] = ring_event();
+          ev_acc[g] = ring_event();
+          if (!ev_sorted[g] || !ev_acc[g]) return ICICLE_ALLOCATION_FAILED;
+        }
+        ICICLE_TRY(sort_group(0, st));
+        KernelTimer::end(2, st); // (the exposed part of the sort)
+        for (int g = 1; g < NG; g++) {
+          ICICLE_TRY(sort_group(g, s_sort));
+          HIP_TRY(hipEventRecord(ev_sorted[g], s_sort), ICICLE_SYNCHRONIZATION_FAILED);
+        }
+        for (int g = 0; g < NG; g++) {
+          if (g > 0) HIP_TRY(hipStreamWaitEvent(s_acc, ev_sorted[g], 0), ICICLE_SYNCHRONIZATION_FAILED);
+          ICICLE_TRY(accumulate_group(g, s_acc));
+          HIP_TRY(hipEventRecord(ev_acc[g], s_acc), ICICLE_SYNCHRONIZATION_FAILED);
+          if (g < NG - 1) {
+            HIP_TRY(hipStreamWaitEvent(s_red, ev_acc[g], 0), ICICLE_SYNCHRONIZATION_FAILED);
+            ICICLE_TRY(reduce_group(g, s_red, 0, nseg));
+          }
+        }
+        KernelTimer::begin(3, st); // (the exposed tail: the last group's reduction + the combine)
+        ICICLE_TRY(reduce_group(NG - 1, st, 0, nseg));
+        hipEvent_t ev_tail = ring_event();
+        if (!ev_tail) return ICICLE_ALLOCATION_FAILED;
+        HIP_TRY(hipEventRecord(ev_tail, s_red), ICICLE_SYNCHRONIZATION_FAILED);
+        HIP_TRY(hipStreamWaitEvent(st, ev_tail, 0), ICICLE_SYNCHRONIZATION_FAILED);
+        k_final_combine<C><<<1, 64, 0, st>>>(d_part.as<typename E::Proj>(), d_res + (size_t)b0 * RW, NG, bb);
+        LAUNCH_CHECK("k_final_combine", st);
+        KernelTimer::end(3, st);
       }
-      k_final<C><<<bb, FinalThreads<C>::value, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c);
-      LAUNCH_CHECK("k_final", st);
-      KernelTimer::end(3, st);
     }
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
 

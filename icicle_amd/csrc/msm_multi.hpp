@@ -67,6 +67,16 @@ namespace icicle_hip {
       }
       return !failed;
     }
+    // registers an arrival without waiting for the others: a worker that is on its way OUT (error return, exception)
+    // owes one arrival to every gate it has not passed, possibly to several -- if it waited at the first of them while
+    // its peers still wait for it at another, nobody would ever move (found by the rehearsal test: set-up failure of one
+    // slot with the bucket exchange on)
+    void leave(bool ok)
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!ok) failed = true;
+      if (++arrived == expected) cv.notify_all();
+    }
   };
   // A worker's obligation to arrive at a gate exactly once. If the worker leaves early -- error return or exception --
   // the destructor arrives for it with "failed", so the peers skip the collective instead of waiting for ever.
@@ -85,32 +95,9 @@ namespace icicle_hip {
     }
     ~GateTicket()
     {
-      if (gate && !used) (void)gate->arrive(false);
+      if (gate && !used) gate->leave(false);
     }
   };
-
-  // A few events per host thread and device, created once and reused round-robin: a call that stays asynchronous may
-  // return while its stream waits are still pending, so events cannot be destroyed at the end of a call (a wait refers
-  // to the record that was current when it was issued; re-recording later is harmless).
-  inline hipEvent_t ring_event()
-  {
-    struct Ring {
-      std::vector<hipEvent_t> ev;
-      size_t next = 0;
-    };
-    thread_local std::map<int, Ring> rings;
-    Ring& r = rings[current_device_id()];
-    if (r.ev.size() < 64) {
-      hipEvent_t e = nullptr;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-      }
-      r.ev.push_back(e);
-      return e;
-    }
-    return r.ev[r.next++ % r.ev.size()];
-  }
 
   // ---- bases kept on the devices between calls ("hip_bases_resident") ----
   struct ResidentKey {
@@ -472,7 +459,9 @@ namespace icicle_hip {
       }
       if (threaded) {
         (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(cs);
         (void)hipStreamDestroy(st);
+        ring_events_release();
       } else if (rc != ICICLE_SUCCESS) {
         (void)hipStreamSynchronize(st); // nothing of a failed call may still be running when its buffers are reused
       }

@@ -316,6 +316,36 @@ namespace icicle_hip {
     return g_fail_stage.compare_exchange_strong(expect, 0); // one shot
   }
 
+  // A few events per host thread and device, created once and reused round-robin: a call that stays asynchronous may
+  // return while its stream waits are still pending, so events cannot be destroyed at the end of a call (a wait refers
+  // to the record that was current when it was issued; re-recording later is harmless).
+  struct EventRing {
+    std::vector<hipEvent_t> ev;
+    size_t next = 0;
+  };
+  static thread_local std::map<int, EventRing> t_event_rings;
+  hipEvent_t ring_event()
+  {
+    EventRing& r = t_event_rings[current_device_id()];
+    if (r.ev.size() < 64) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+      r.ev.push_back(e);
+      return e;
+    }
+    return r.ev[r.next++ % r.ev.size()];
+  }
+  void ring_events_release()
+  {
+    for (auto& kv : t_event_rings)
+      for (hipEvent_t e : kv.second.ev)
+        (void)hipEventDestroy(e);
+    t_event_rings.clear();
+  }
+
   MultiStats& multi_stats()
   {
     static MultiStats s;

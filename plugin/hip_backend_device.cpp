@@ -9,6 +9,7 @@
 // with the reference runtime living in the same process.
 // Structural model: the reference's only in-tree GPU DeviceAPI,
 // icicle/backend/cuda_pqc/src/cuda_pqc_device_api.cu:11-121 (not copied; different API, same contract).
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <mutex>
 #include <vector>
@@ -99,7 +100,28 @@ public:
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size > total_b) return eIcicleError::OUT_OF_MEMORY;
-    return tr(hipMalloc(ptr, size ? size : 1), eIcicleError::ALLOCATION_FAILED);
+    hipError_t e = hipMalloc(ptr, size ? size : 1);
+    if (e != hipSuccess) {
+      // msm() / ntt() keep GiBs of temporaries cached in libicicle_hip.so (about 8-12 GiB after a 2^26 MSM): give the idle
+      // part back -- parked stream-ordered frees first, then the workspace arenas of this device -- and retry once
+      // (icicle_malloc through the reference runtime could fail while the cache sat idle)
+      (void)hipGetLastError();
+      reap(true);
+      release_backend_workspace();
+      e = hipMalloc(ptr, size ? size : 1);
+    }
+    return tr(e, eIcicleError::ALLOCATION_FAILED);
+  }
+  // libicicle_hip.so is loaded by the curve / field parts of the plugin, not by this one: look it up if it is there
+  static void release_backend_workspace()
+  {
+    void* h = dlopen("libicicle_hip.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) return;
+    auto set_dev = (int (*)(int))dlsym(h, "icicle_hip_set_device");
+    auto rel = (int (*)(void))dlsym(h, "icicle_hip_release_workspace");
+    int dev = 0;
+    if (set_dev && rel && hipGetDevice(&dev) == hipSuccess && set_dev(dev) == 0) (void)rel();
+    dlclose(h);
   }
   // Stream-ordered allocation without the hipMallocAsync pool (it lost data on this ROCm stack, profiles/r01_notes.md):
   // the block exists when the call returns, which satisfies any stream order; the free is deferred behind an event

@@ -105,3 +105,43 @@ def test_ecntt_device_and_errors(env, hip):
         N.ecntt(cname, x, N.FORWARD, size=48)  # not a power of two
     with pytest.raises(hip.IcicleError):
         N.ecntt(cname, x, N.FORWARD, size=1 << (DOMAIN_LOG + 1))  # larger than the domain
+
+
+def test_ecntt_timing_vs_reference_cpu(hip):
+    """ECNTT 2^10 / 2^12 timed on the GPU and on the reference CPU backend (the box's host cores),
+    results equal as group elements; the numbers are appended to gpurun_out/ecntt_timing.txt (copied into profiles/)."""
+    import os
+    import time
+
+    from icicle_amd import ntt as N
+
+    cname = "bn254"
+    C = pyref.CURVES[cname]
+    L = C.limbs_q
+    refc = ref.RefCurve(cname)
+    sf = ref.RefScalarNttField(cname)
+    root = N.get_root_of_unity(cname, 1 << 12)
+    N.init_domain(cname, root)
+    sf.init_domain(root)
+    lines = []
+    try:
+        for logn in (10, 12):
+            n = 1 << logn
+            base = refc.generate_affine_points(n)
+            x = np.ascontiguousarray(np.concatenate([base, np.tile(to_words([1], L), (n, 1))], axis=1).astype(np.uint32)).reshape(-1)
+            N.ecntt(cname, x, N.FORWARD)  # warm
+            t0 = time.perf_counter()
+            got = N.ecntt(cname, x, N.FORWARD)
+            t_gpu = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            exp = refc.ecntt(x, n, 0)
+            t_cpu = time.perf_counter() - t0
+            assert np.array_equal(refc.to_affine(got.reshape(-1, 3 * L)), refc.to_affine(exp.reshape(-1, 3 * L)))
+            lines.append(f"ecntt {cname} 2^{logn}: GPU {t_gpu * 1e3:9.2f} ms (host in/out)   reference CPU backend {t_cpu * 1e3:9.2f} ms on {os.cpu_count()} threads   x{t_cpu / t_gpu:.1f}")
+    finally:
+        N.release_domain(cname)
+        sf.release_domain()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "ecntt_timing.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))

@@ -24,7 +24,9 @@ import pytest
 from oracle import pyref, ref
 from tests.util import cached_points, points_to_array, rand_scalars, to_words
 
-pytestmark = pytest.mark.gpu
+# a dead-locked collective must cost two minutes, not the whole run (the main thread then sits in a C call: only the
+# watchdog-thread method can end it)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180, method="thread")]
 
 
 @pytest.fixture()

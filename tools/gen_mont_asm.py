@@ -92,7 +92,7 @@ def emit_inplace(n: int) -> str:
     for ln in lines:
         out.append(re.sub(r"%\d+", lambda mo: ren.get(mo.group(0), mo.group(0)), ln))
     body = "\n".join(f'      "{ln}\\n"' for ln in out)
-    outs = ", ".join([f'"+v"(a[{i}])' for i in range(n)] + [f'"=&v"(m[{i}])' for i in range(n)] + ['"=&{v[2:3]}"(acc)'])
+    outs = ", ".join([f'"+&v"(a[{i}])' for i in range(n)] + [f'"=&v"(m[{i}])' for i in range(n)] + ['"=&{v[2:3]}"(acc)'])
     ins = ", ".join([f'"v"(b[{i}])' for i in range(n)] + [f'"s"(PR::P[{i}])' for i in range(n)] + ['"s"(PR::PINV)'])
     return f"""  // mul in place (a <- a*b), N = {n}
   template <class PR>
@@ -123,7 +123,7 @@ def emit_mul_add_inplace_c(n: int) -> str:
         ren[f"%{j}"] = f"%{j - n}"
     out = [re.sub(r"%\d+", lambda mo: ren.get(mo.group(0), mo.group(0)), ln) for ln in lines]
     body = "\n".join(f'      "{ln}\\n"' for ln in out)
-    outs = ", ".join([f'"+v"(c[{i}])' for i in range(n)] + [f'"=&v"(m[{i}])' for i in range(n)] + ['"=&{v[2:3]}"(acc)'])
+    outs = ", ".join([f'"+&v"(c[{i}])' for i in range(n)] + [f'"=&v"(m[{i}])' for i in range(n)] + ['"=&{v[2:3]}"(acc)'])
     ins = ", ".join([f'"v"({nm}[{i}])' for nm in ("a", "b", "d") for i in range(n)] + [f'"s"(PR::P[{i}])' for i in range(n)] + ['"s"(PR::PINV)'])
     return f"""  // mul_add in place (c <- a*b + c*d), N = {n}
   template <class PR>

@@ -85,6 +85,52 @@ def ntt_scalar_case(field, logn, batch):
     N.release_domain(field)
 
 
+def msm_precompute_case(curve, logn, pf, batch=1):
+    """the reference's precompute sweep (docs/docs/api/cpp/msm.md:186-201, wrappers/rust/icicle-core/src/msm/mod.rs:386-470):
+    msm_precompute_bases once, then timed msm() calls with precompute_factor = pf (shared bases over the batch)"""
+    n = 1 << logn
+    L = M.LIMBS[curve]
+    bases = torch.empty((n, 2 * L), dtype=torch.int32, device=dev)
+    check(getattr(lib, f"{curve}_hip_generate_affine_points")(bases.data_ptr(), n, 1, True, None))
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    sc = torch.randint(-(2 ** 31), 2 ** 31, (n * batch, 8), dtype=torch.int32, device=dev, generator=g)
+    sc[:, 7] = torch.randint(0, TOP[curve], (n * batch,), dtype=torch.int32, device=dev, generator=g)
+    res = torch.empty((batch, 3 * L), dtype=torch.int32, device=dev)
+    cfg = MSMConfig.default()
+    cfg.batch_size = batch
+    cfg.is_async = True
+    cfg.precompute_factor = pf
+    table = bases
+    t_pre = 0.0
+    if pf > 1:
+        table = torch.empty((n * pf, 2 * L), dtype=torch.int32, device=dev)
+        t0 = time.perf_counter()
+        M.precompute_bases(curve, bases.data_ptr(), cfg, output=table.data_ptr(), nof_bases=n)
+        torch.cuda.synchronize()
+        t_pre = (time.perf_counter() - t0) * 1e3
+    ms = time_it(lambda: M.msm(curve, sc.data_ptr(), table.data_ptr(), cfg, results=res.data_ptr(), msm_size=n))
+    print(f"msm {curve:10s} 2^{logn:<2d} batch {batch:<4d} precompute_factor {pf}  {ms:9.3f} ms  (precompute_bases {t_pre:8.2f} ms)", flush=True)
+
+
+def ecntt_case(curve, logn, batch=1):
+    n = 1 << logn
+    L = M.LIMBS[curve]
+    N.init_domain(curve, N.get_root_of_unity(curve, n))
+    aff = torch.empty((n * batch, 2 * L), dtype=torch.int32, device=dev)
+    check(getattr(lib, f"{curve}_hip_generate_affine_points")(aff.data_ptr(), n * batch, 7, True, None))
+    one = torch.zeros((n * batch, L), dtype=torch.int32, device=dev)
+    one[:, 0] = 1
+    x = torch.cat([aff, one], dim=1).contiguous()  # projective_t (x, y, 1)
+    y = torch.empty_like(x)
+    cfg = NTTConfigU256.default()
+    cfg.batch_size = batch
+    cfg.is_async = True
+    ms = time_it(lambda: N.ecntt(curve, x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n), reps=2)
+    print(f"ecntt {curve:10s} 2^{logn:<2d} batch {batch:<3d} {ms:10.2f} ms  ({n // 2 * logn * batch} butterflies, {ms * 1e3 / max(1, logn):8.1f} us per stage)", flush=True)
+    N.release_domain(curve)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "csweep":
         sweep = ((16, (9, 10, 11, 12, 13)), (20, (12, 13, 14, 15, 16)), (22, (14, 15, 16, 17, 18)), (24, (16, 17, 18, 19, 20)), (26, (18, 19, 20, 21)))
@@ -130,6 +176,21 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ntt":
         for logn, batch in ((12, 4096), (16, 1024), (20, 256), (22, 128), (24, 64), (24, 8), (27, 4)):
             ntt_case("babybear", logn, batch)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "precompute":
+        for logn, batch in ((16, 1), (16, 16), (20, 1), (20, 16), (22, 1), (24, 1)):
+            for pf in (1, 4, 8):
+                msm_precompute_case("bn254", logn, pf, batch)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ecntt":
+        for logn in (10, 12, 14):
+            ecntt_case("bn254", logn)
+        ecntt_case("bls12_381", 10)
+        ecntt_case("bn254", 10, batch=8)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "midsize":
+        for logn in (16, 18, 20, 21, 22, 23, 24):
+            msm_case("bn254", logn)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g2":
         for logn in (12, 16, 20, 22, 24):
