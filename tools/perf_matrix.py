@@ -188,6 +188,12 @@ if __name__ == "__main__":
         ecntt_case("bls12_381", 10)
         ecntt_case("bn254", 10, batch=8)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "groups":  # A/B of the pipelined schedule: run once per ICICLE_HIP_MSM_GROUPS value
+        print("ICICLE_HIP_MSM_GROUPS =", os.environ.get("ICICLE_HIP_MSM_GROUPS", "(default)"), " SORT_CUS =", os.environ.get("ICICLE_HIP_MSM_SORT_CUS", "-"), flush=True)
+        for logn in (12, 16, 20, 22, 24, 26):
+            msm_case("bn254", logn)
+        msm_case("bls12_381", 24)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "midsize":
         for logn in (16, 18, 20, 21, 22, 23, 24):
             msm_case("bn254", logn)
