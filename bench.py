@@ -347,7 +347,14 @@ def main():
     roofline["alu"] = {"window_bits": pc.value, "windows": pw.value, "mixed_adds": madds,
                        "mixed_adds_per_s": madds / (acc_ms * 1e-3), "roof": rate.value,
                        "frac": madds / (acc_ms * 1e-3) / rate.value,
-                       "roof_is": "XYZZ mixed adds/s, operands in registers, measured in this run (icicle_hip_ubench_mixed_add)"}
+                       "roof_is": "XYZZ mixed adds/s, operands in registers, measured in this run (icicle_hip_ubench_mixed_add)",
+                       # the hardware's own figure beside the self-referential one: pure v_mad_u64_u32 issue. 1024 SIMDs x f / 6.05
+                       # cycles per wave-instruction x 64 lanes / 1467 mads per mixed add (profiles/r02_alu_ubench.txt); f = 2.4 GHz
+                       # nominal. Under this all-mad load the chip sustains ~0.83 of the clock it holds half-loaded
+                       # (profiles/r03_notes.md section 1), i.e. ~14.7e9/s.
+                       "hw_roof_nominal_clock": 1024 * 2.4e9 / 6.05 * 64 / 1467,
+                       "hw_frac_nominal_clock": madds / (acc_ms * 1e-3) / (1024 * 2.4e9 / 6.05 * 64 / 1467),
+                       "hw_roof_is": "v_mad_u64_u32 issue roof: 1024 SIMDs x 2.4 GHz / 6.05 cycles x 64 lanes / 1467 mads per mixed add"}
     # every mixed add gathers one 64-byte point at a random address of the bases array: ceiling of that access pattern
     # over a region of the same size, measured in this run
     check(lib.icicle_hip_ubench_gather(max(64, n * 64), 1 << 27, ctypes.byref(rate)), "ubench_gather")

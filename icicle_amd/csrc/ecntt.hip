@@ -29,35 +29,54 @@ namespace icicle_hip {
     using FR = FieldOps<typename C::fr>;
     using Proj = typename E::Proj;
 
-    // k * p, k = 8 canonical words: fixed 4-bit windows, most significant first (the reference's own scalar
-    // multiplication is windowed too, include/icicle/curves/projective.h:192-224) -- per window four doublings on the
-    // Jacobian chain of ec.hpp (2M + 5S each instead of 6M + 2S + 1 for the complete doubling; Z = 0 stays Z = 0 and
-    // comes back as the identity) and at most one COMPLETE addition of a table entry, so no input is exceptional:
-    // 252 doublings + <= 63 + 14 additions instead of 255 + ~127 of the bit-serial form.
-    // QUAD: the four lanes of a DPP quad hold the same operands and share every doubling (dbl_jac_quad: three dependent
-    // products per step instead of seven) -- a butterfly is a pure latency chain and an ECNTT stage has far fewer
-    // butterflies than the chip has lanes, so spending four lanes on one chain is free.
-    template <bool QUAD>
-    static __device__ Proj mul_words(const Proj& p, const uint32_t* k, uint32_t role = 0)
+    // k * p, k = 8 canonical words, MSB-first double-and-add over the complete formulas: the cold uses (coset factors on
+    // the way in, 1/N and coset factors on the way out: n scalar multiplications per transform against n/2 log n in the
+    // butterflies)
+    static __device__ Proj mul_words_serial(const Proj& p, const uint32_t* k)
     {
-      Proj tab[16];
-      tab[0] = E::proj_identity();
-      tab[1] = p;
-      tab[2] = E::dbl(p);
-      for (int i = 3; i < 16; i++)
-        tab[i] = E::add(tab[i - 1], p);
+      Proj r = E::proj_identity();
+      bool started = false;
+      for (int bit = 255; bit >= 0; bit--) {
+        if (started) r = E::dbl(r);
+        if ((k[bit >> 5] >> (bit & 31)) & 1) {
+          r = started ? E::add(r, p) : p;
+          started = true;
+        }
+      }
+      return r;
+    }
+    // The butterflies' k * p: fixed 4-bit windows, most significant first (the reference's own scalar multiplication is
+    // windowed too, include/icicle/curves/projective.h:192-224) -- per window four doublings on the Jacobian chain of
+    // ec.hpp (2M + 5S each instead of 6M + 2S + 1 for the complete doubling; Z = 0 stays Z = 0 and comes back as the
+    // identity) and at most one COMPLETE addition of a table entry, so no input is exceptional: 252 doublings +
+    // <= 63 + 14 additions instead of 255 + ~127 of the bit-serial form.
+    // The four lanes of a DPP quad hold the same operands and share every doubling (dbl_jac_quad: three dependent products
+    // per step instead of seven) -- a butterfly is a pure latency chain and an ECNTT stage has far fewer butterflies than
+    // the chip has lanes, so spending four lanes on one chain is free. `tab` = 16 entries of LDS owned by the quad (a
+    // private array indexed by the digit would live in scratch memory). Every lane of the WAVE must call this together
+    // (the table is published with a barrier); lanes with go == false compute on the identity and the result is unused.
+    static __device__ Proj mul_words_quad(const Proj& p, const uint32_t* k, uint32_t role, Proj* tab)
+    {
+      Proj e = E::proj_identity();
+      for (int i = 0; i < 16; i++) {
+        if (role == 0) tab[i] = e;
+        e = (i == 1) ? E::dbl(p) : E::add(e, p); // 0, p, 2p, 3p, ...
+        if (i == 0) e = p;
+      }
+      __syncthreads();
       Proj r = E::proj_identity();
       bool started = false;
       for (int d = 63; d >= 0; d--) {
         const uint32_t dig = (k[d >> 3] >> ((d & 7) * 4)) & 15u;
         if (started) {
           typename E::Jac j = E::to_jac(r);
-          for (int q = 0; q < 4; q++) {
-            if constexpr (QUAD)
-              j = E::dbl_jac_quad(j, role);
-            else
-              j = E::dbl_jac(j);
-          }
+#ifdef ECNTT_NOQUAD
+          for (int q = 0; q < 4; q++)
+            j = E::dbl_jac(j);
+#else
+          for (int q = 0; q < 4; q++)
+            j = E::dbl_jac_quad(j, role);
+#endif
           r = E::from_jac(j);
           if (dig) r = E::add(r, tab[dig]);
         } else if (dig) {
@@ -110,7 +129,7 @@ namespace icicle_hip {
     if (lay.coset && !lay.inverse && j != 0) {
       uint32_t k[8];
       T::canonical_from_mont(k, coset_pow + j * 8);
-      p = T::template mul_words<false>(p, k);
+      p = T::mul_words_serial(p, k);
     }
     work[b * lay.n + i] = p;
   }
@@ -137,14 +156,31 @@ namespace icicle_hip {
     typename E::Proj* base = work + b * lay.n;
     const typename E::Proj u = base[i];
     typename E::Proj v = base[i + half];
+#ifdef ECNTT_OLD_MUL
     if (pos != 0) {
       const uint64_t max_mask = ((uint64_t)1 << lay.log_max) - 1;
       uint64_t idx = (pos << (lay.logn - 1 - q)) << (lay.log_max - lay.logn);
       if (lay.inverse) idx = (((uint64_t)1 << lay.log_max) - idx) & max_mask;
       uint32_t k[8];
       T::canonical_from_mont(k, tw + idx * 8);
-      v = T::template mul_words<true>(v, k, role);
+      v = T::mul_words_serial(v, k);
     }
+#else
+    {
+      __shared__ typename E::Proj tabs[16][16]; // [quad][multiple]
+      const uint64_t max_mask = ((uint64_t)1 << lay.log_max) - 1;
+      uint64_t idx = (pos << (lay.logn - 1 - q)) << (lay.log_max - lay.logn);
+      if (lay.inverse) idx = (((uint64_t)1 << lay.log_max) - idx) & max_mask;
+      uint32_t k[8];
+      T::canonical_from_mont(k, tw + (pos != 0 ? idx : 0) * 8);
+      if (pos == 0) { // w^0 = 1: k = 1, the multiplication returns v itself (one table read, no doubling)
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+          k[w] = w == 0 ? 1u : 0u;
+      }
+      v = T::mul_words_quad(v, k, role, tabs[threadIdx.x >> 2]);
+    }
+#endif
     if (live && role == 0) {
       base[i] = E::add(u, v);
       base[i + half] = E::add(u, T::neg(v));
@@ -162,11 +198,11 @@ namespace icicle_hip {
     const uint64_t b = t / lay.n, k = t % lay.n;
     typename E::Proj p = work[b * lay.n + k];
     if (lay.inverse) {
-      p = T::template mul_words<false>(p, ninv_canonical.w);
+      p = T::mul_words_serial(p, ninv_canonical.w);
       if (lay.coset && k != 0) {
         uint32_t s[8];
         T::canonical_from_mont(s, coset_pow + k * 8);
-        p = T::template mul_words<false>(p, s);
+        p = T::mul_words_serial(p, s);
       }
     }
     const uint64_t m = lay.out_rev ? bitrev64(k, lay.logn) : k;

@@ -150,10 +150,19 @@ if __name__ == "__main__":
             bases_d = torch.empty((n, 16), dtype=torch.int32, device=dev)
             check(lib.bn254_hip_generate_affine_points(bases_d.data_ptr(), n, 1, True, None))
             hb = bases_d.cpu().numpy().view(np.uint32)
-            del bases_d
             rng = np.random.default_rng(0)
             hs = rng.integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32)
             hs[:, 7] &= 0x0FFFFFFF
+            # host scalars (the wrappers' HostSlice), bases resident on the device: chunks of scalars are uploaded behind the
+            # previous chunk's MSM (msm_multi.hpp); pageable and pinned (torch pin_memory) host memory
+            out = np.zeros((1, 24), dtype=np.uint32)
+            for label, src in (("pageable", hs), ("pinned", torch.from_numpy(hs.view(np.int32)).pin_memory().numpy().view(np.uint32))):
+                M.msm("bn254", src, bases_d.data_ptr(), MSMConfig.default(), results=out, msm_size=n)
+                t0 = time.perf_counter()
+                M.msm("bn254", src, bases_d.data_ptr(), MSMConfig.default(), results=out, msm_size=n)
+                ms = (time.perf_counter() - t0) * 1e3
+                print(f"msm bn254 2^{logn} host scalars ({label}), device-resident bases: {ms:9.2f} ms  ({hs.nbytes / 1e9:.2f} GB of scalars over PCIe)", flush=True)
+            del bases_d
             M.msm("bn254", hs, hb)
             t0 = time.perf_counter()
             M.msm("bn254", hs, hb)
@@ -167,11 +176,13 @@ if __name__ == "__main__":
             hx = rng.integers(0, 0x78000001, size=(batch, 1 << 24), dtype=np.uint32)
             cfg = NTTConfigU32.default()
             cfg.batch_size = batch
-            N.ntt("babybear", hx, N.FORWARD, cfg)
-            t0 = time.perf_counter()
-            N.ntt("babybear", hx, N.FORWARD, cfg)
-            ms = (time.perf_counter() - t0) * 1e3
-            print(f"ntt babybear 2^24 x {batch} host-resident in/out: {ms:9.2f} ms  ({2 * hx.nbytes / ms / 1e6:.1f} GB/s effective both ways)", flush=True)
+            for label, src in (("pageable", hx), ("pinned", torch.from_numpy(hx.view(np.int32)).pin_memory().numpy().view(np.uint32))):
+                dst = src if label == "pageable" else torch.empty(src.shape, dtype=torch.int32).pin_memory().numpy().view(np.uint32)
+                N.ntt("babybear", src, N.FORWARD, cfg, out=dst if label == "pinned" else None)
+                t0 = time.perf_counter()
+                N.ntt("babybear", src, N.FORWARD, cfg, out=dst if label == "pinned" else None)
+                ms = (time.perf_counter() - t0) * 1e3
+                print(f"ntt babybear 2^24 x {batch} host-resident in/out ({label}): {ms:9.2f} ms  ({2 * hx.nbytes / ms / 1e6:.1f} GB/s effective both ways)", flush=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ntt":
         for logn, batch in ((12, 4096), (16, 1024), (20, 256), (22, 128), (24, 64), (24, 8), (27, 4)):
