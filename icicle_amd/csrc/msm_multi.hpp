@@ -47,58 +47,6 @@ namespace icicle_hip {
     *hi = *lo + base + (g < rem ? 1 : 0);
   }
 
-  // Rendezvous of the per-device host threads in front of a collective: a thread that failed earlier (allocation,
-  // copy, launch) must not leave its peers blocked inside ncclSend/ncclRecv/ncclAllGather forever. Every thread
-  // arrives exactly once per gate, with its status; all of them leave with "everybody was fine" or all with "someone
-  // failed" and then skip the collective.
-  struct PhaseGate {
-    std::mutex mu;
-    std::condition_variable cv;
-    int expected = 1, arrived = 0;
-    bool failed = false;
-    bool arrive(bool ok)
-    {
-      std::unique_lock<std::mutex> lk(mu);
-      if (!ok) failed = true;
-      if (++arrived == expected) {
-        cv.notify_all();
-      } else {
-        cv.wait(lk, [&] { return arrived == expected; });
-      }
-      return !failed;
-    }
-    // registers an arrival without waiting for the others: a worker that is on its way OUT (error return, exception)
-    // owes one arrival to every gate it has not passed, possibly to several -- if it waited at the first of them while
-    // its peers still wait for it at another, nobody would ever move (found by the rehearsal test: set-up failure of one
-    // slot with the bucket exchange on)
-    void leave(bool ok)
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      if (!ok) failed = true;
-      if (++arrived == expected) cv.notify_all();
-    }
-  };
-  // A worker's obligation to arrive at a gate exactly once. If the worker leaves early -- error return or exception --
-  // the destructor arrives for it with "failed", so the peers skip the collective instead of waiting for ever.
-  struct GateTicket {
-    PhaseGate* gate = nullptr;
-    bool used = false;
-    GateTicket() = default;
-    explicit GateTicket(PhaseGate* g) : gate(g) {}
-    GateTicket(const GateTicket&) = delete;
-    GateTicket& operator=(const GateTicket&) = delete;
-    bool arrive(bool ok)
-    {
-      if (!gate || used) return ok;
-      used = true;
-      return gate->arrive(ok);
-    }
-    ~GateTicket()
-    {
-      if (gate && !used) gate->leave(false);
-    }
-  };
-
   // ---- bases kept on the devices between calls ("hip_bases_resident") ----
   struct ResidentKey {
     const void* bases;

@@ -856,6 +856,8 @@ namespace icicle_hip {
   template <class PR>
   static icicle_error_t ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, uint32_t lanes);
 
+#include "ntt_split.hpp"
+
   // Batched NTT over several devices behind the unchanged <field>_ntt symbol: config.ext {"hip_num_devices": G} cuts
   // the batch into G contiguous row shards (rows are independent transforms: no collective) over
   // min(G, visible GPUs) device slots -- ntt_multi.hpp holds the slot threads and the upload / compute / download
@@ -910,7 +912,21 @@ namespace icicle_hip {
     if (!cfg) return ICICLE_INVALID_POINTER;
     if (cfg->ext && !cfg->columns_batch) {
       const int G = reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_num_devices", 0);
-      if (G >= 1) return ntt_multi_run<PR>(input, size, dir, cfg, output, lanes, G, 0);
+      if (G >= 1) {
+        // fewer transforms than devices: cut every transform itself over the device slots (four-step, all-to-all
+        // exchanges: ntt_split.hpp) when its shape allows; otherwise (and for every batch >= G) rows over devices
+        if (std::max(1, cfg->batch_size) < G && lanes == 1 && cfg->ordering == ICICLE_kNN && cfg->coset_gen == 1 && size > 0 && (size & (size - 1)) == 0 && input && output &&
+            (dir == ICICLE_NTT_FORWARD || dir == ICICLE_NTT_INVERSE)) {
+          DeviceSlots ds;
+          ICICLE_TRY(make_device_slots(G, &ds));
+          int logn = 0;
+          while ((1 << logn) < size)
+            logn++;
+          SplitShape shp;
+          if (ds.P == G && split_shape(logn, ds.P, &shp)) return ntt_split_run<PR>(input, size, dir, cfg, output, ds, shp);
+        }
+        return ntt_multi_run<PR>(input, size, dir, cfg, output, lanes, G, 0);
+      }
     }
     // host-resident rows of a large batch on one GPU: row groups through the upload / compute / download pipeline
     if (!cfg->columns_batch && (!cfg->are_inputs_on_device || !cfg->are_outputs_on_device) && size > 0 && input && output && virtual_device_slots() == 0) {

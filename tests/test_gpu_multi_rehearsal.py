@@ -344,3 +344,55 @@ def test_host_resident_ntt_batch_is_pipelined(hip):
     finally:
         N.release_domain(fname)
         rf.release_domain()
+
+
+@pytest.mark.parametrize("fname", ["babybear", "koalabear"])
+@pytest.mark.parametrize("P,logn", [(2, 6), (2, 11), (4, 9), (4, 14), (8, 8), (8, 16), (8, 20)])
+def test_single_ntt_split_over_device_slots(hip, slots, fname, P, logn):
+    """hip_num_devices = P with FEWER transforms than devices: every transform is cut over the P slots (four-step, three
+    all-to-all exchanges with grouped send / recv, icicle_amd/csrc/ntt_split.hpp) -- the in-library form of the north
+    star's "all-to-all of NTT chunks". memcmp against the reference CPU backend, forward and inverse, batch 1 and 3."""
+    from icicle_amd import ntt as N
+    from icicle_amd._lib import lib, multi_stats
+    from icicle_amd.runtime import DeviceVec
+
+    if fname == "koalabear" and (P, logn) not in ((2, 11), (8, 16)):
+        pytest.skip("second field: two shapes are enough")
+    F = pyref.NTT_FIELDS[fname]
+    n = 1 << logn
+    rng = np.random.default_rng(P * 100 + logn)
+    rf = ref.RefNttField(fname)
+    root = N.get_root_of_unity(fname, n)
+    rf.init_domain(root)
+    N.init_domain(fname, root)
+    ext = _ext(hip_num_devices=P)
+    try:
+        slots(P)
+        for batch in ((1, 3) if logn <= 16 else (1,)):
+            if batch >= P:
+                continue
+            x = rng.integers(0, F.p, size=batch * n, dtype=np.uint32)
+            exp = rf.ntt(x, n, 0, batch=batch)
+            cfg = hip.NTTConfigU32.default()
+            cfg.batch_size = batch
+            cfg.ext = ext
+            multi_stats(reset=True)
+            y = N.ntt(fname, x, N.FORWARD, cfg)  # host in / out
+            st = multi_stats()
+            assert st["threaded_calls"] == 1 and st["exchanged_bucket_bytes"] == 3 * batch * P * (P - 1) * (n // (P * P)) * 4, st  # the split path ran: 3 exchanges
+            assert np.array_equal(y, exp), (fname, P, logn, batch, "forward")
+            back = N.ntt(fname, y, N.INVERSE, cfg)
+            assert np.array_equal(back, x), (fname, P, logn, batch, "inverse")
+            dx, dy = DeviceVec.from_host(x), DeviceVec(x.nbytes)
+            N.ntt(fname, dx, N.FORWARD, cfg, out=dy, size=n)  # operands on the calling device
+            assert np.array_equal(dy.to_host(shape=x.shape), exp)
+        # a configuration the split does not cover (bit-reversed output) falls back to the row-shard path: same bytes as the reference
+        x = rng.integers(0, F.p, size=n, dtype=np.uint32)
+        cfg = hip.NTTConfigU32.default()
+        cfg.ext = ext
+        cfg.ordering = N.kNR
+        assert np.array_equal(N.ntt(fname, x, N.FORWARD, cfg), rf.ntt(x, n, 0, ordering=N.kNR))
+    finally:
+        lib.destroy_config_extension(ext)
+        N.release_domain(fname)
+        rf.release_domain()
