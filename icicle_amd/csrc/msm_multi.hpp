@@ -253,9 +253,12 @@ namespace icicle_hip {
       GateTicket t_gather(use_rccl ? &gate_gather : nullptr);
       if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED; // (tickets arrive with "failed" on the way out)
       if (icicle_hip_set_device(ds.devs[p]) != ICICLE_SUCCESS) return ICICLE_INVALID_DEVICE;
-      hipStream_t st = (hipStream_t)cfg->stream; // one slot: the caller's stream
-      if (threaded && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return ICICLE_STREAM_CREATION_FAILED;
-      hipStream_t cs = side_stream(threaded ? 1 + p : 0); // operand staging; slots that share a device get their own
+      // one slot: the caller's stream. Several: a long-lived stream per (device, slot) -- never a stream created and
+      // destroyed per call: the workspace arenas keep last-use events recorded on whatever stream used them, and an event
+      // whose stream is gone makes later hipEventSynchronize / hipStreamWaitEvent calls fail (seen in the rehearsal suite)
+      hipStream_t st = threaded ? side_stream(200 + p) : (hipStream_t)cfg->stream;
+      if (threaded && !st) return ICICLE_STREAM_CREATION_FAILED;
+      hipStream_t cs = side_stream(threaded ? 300 + p : 0); // operand staging; slots that share a device get their own
       icicle_error_t rc;
       { // the hook's buffers are released in stream order: it must die before a stream created here does
         BucketExchange<C> hook;
@@ -408,7 +411,6 @@ namespace icicle_hip {
       if (threaded) {
         (void)hipStreamSynchronize(st);
         (void)hipStreamSynchronize(cs);
-        (void)hipStreamDestroy(st);
         ring_events_release();
       } else if (rc != ICICLE_SUCCESS) {
         (void)hipStreamSynchronize(st); // nothing of a failed call may still be running when its buffers are reused

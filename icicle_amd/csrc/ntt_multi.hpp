@@ -55,8 +55,8 @@ namespace icicle_hip {
     auto worker = [&](int p) -> icicle_error_t {
       if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED;
       ICICLE_TRY(icicle_hip_set_device(ds.devs[p]));
-      hipStream_t st = job.stream;
-      if (threaded) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
+      hipStream_t st = threaded ? side_stream(200 + p) : job.stream; // long-lived per (device, slot): see msm_multi.hpp
+      if (threaded && !st) return ICICLE_STREAM_CREATION_FAILED;
       icicle_error_t rc = [&]() -> icicle_error_t {
         if (ds.devs[p] != home) ICICLE_TRY(ensure_domain(st));
         std::vector<int> mine;
@@ -166,10 +166,7 @@ namespace icicle_hip {
         return ICICLE_SUCCESS;
       }();
       if (rc != ICICLE_SUCCESS) (void)hipDeviceSynchronize(); // nothing of a failed call may still run when its buffers are reused
-      if (threaded) {
-        (void)hipStreamSynchronize(st);
-        (void)hipStreamDestroy(st);
-      }
+      if (threaded) (void)hipStreamSynchronize(st);
       return rc;
     };
 

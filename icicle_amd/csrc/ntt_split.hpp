@@ -79,8 +79,8 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
     GateTicket ticket(&gate);
     if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED;
     ICICLE_TRY(icicle_hip_set_device(ds.devs[p]));
-    hipStream_t st = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
+    hipStream_t st = side_stream(200 + p); // long-lived per (device, slot): see msm_multi.hpp
+    if (!st) return ICICLE_STREAM_CREATION_FAILED;
     icicle_error_t rc = [&]() -> icicle_error_t {
       const RcclApi* api = rccl_api();
       void* comm = cset->comms[p];
@@ -147,7 +147,6 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
       return ICICLE_SUCCESS;
     }();
     (void)hipStreamSynchronize(st);
-    (void)hipStreamDestroy(st);
     ring_events_release();
     return rc;
   };

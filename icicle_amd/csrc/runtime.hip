@@ -47,6 +47,10 @@ namespace icicle_hip {
   {
     const int id = current_device_id();
     if (id < 0 || id >= device_count_cached()) return ICICLE_INVALID_DEVICE;
+    // every entry point passes here first: drop whatever error an earlier, deliberately ignored call left in this thread's
+    // HIP state (an hipEventQuery that was not ready, a clean-up call on a path that had already failed) -- the launch
+    // checks below read hipGetLastError() and must only ever see their own launches
+    (void)hipGetLastError();
     HIP_TRY(hipSetDevice(id), ICICLE_INVALID_DEVICE);
     return ICICLE_SUCCESS;
   }
