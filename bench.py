@@ -66,9 +66,12 @@ def synth_scalars(n, device, seed):
     """n x 8 uint32 limbs, value < r (top limb drawn below r's top limb), resident on `device`."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    s = torch.randint(-(2 ** 31), 2 ** 31, (n, 8), dtype=torch.int32, device=device, generator=g)
-    top = torch.randint(0, BN254_R_TOP, (n,), dtype=torch.int32, device=device, generator=g)
-    s[:, 7] = top
+    s = torch.empty((n, 8), dtype=torch.int32, device=device)
+    step = 1 << 26  # drawn in slices: the in-process N-GPU leg asks for N * 2^26 scalars (2^32 words at N = 8)
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        s[lo:hi] = torch.randint(-(2 ** 31), 2 ** 31, (hi - lo, 8), dtype=torch.int32, device=device, generator=g)
+        s[lo:hi, 7] = torch.randint(0, BN254_R_TOP, (hi - lo,), dtype=torch.int32, device=device, generator=g)
     return s
 
 
@@ -123,7 +126,7 @@ def launch_self(args):
     if not args.no_inproc:
         try:
             r2 = subprocess.run([sys.executable, os.path.abspath(__file__)] + passthrough + ["--inproc-only"], capture_output=True, text=True,
-                                env=env, timeout=900)
+                                env=env, timeout=300)
             out["inproc"] = _last_json_line(r2.stdout) or {"error": f"rc {r2.returncode}: " + (r2.stderr or r2.stdout)[-1500:]}
         except Exception as e:  # the second leg never costs the primary line
             out["inproc"] = {"error": repr(e)}
@@ -194,7 +197,9 @@ def inproc_main(args):
             N.init_domain("babybear", N.get_root_of_unity("babybear", nn))
             g = torch.Generator(device=dev)
             g.manual_seed(77)
-            x = torch.randint(0, 0x78000001, (rows, nn), dtype=torch.int32, device=dev, generator=g)
+            x = torch.empty((rows, nn), dtype=torch.int32, device=dev)
+            for r0 in range(0, rows, 16):
+                x[r0:r0 + 16] = torch.randint(0, 0x78000001, (min(16, rows - r0), nn), dtype=torch.int32, device=dev, generator=g)
             y = torch.empty_like(x)
             z = torch.empty_like(x)
             ncfg = NTTConfigU32.default()
@@ -554,7 +559,7 @@ def main():
                                                                         "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                                         "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
                 r2 = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--inproc-only"], capture_output=True,
-                                    text=True, env=env, timeout=420)
+                                    text=True, env=env, timeout=300)
                 out["inproc"] = _last_json_line(r2.stdout) or {"error": f"rc {r2.returncode}: " + (r2.stderr or r2.stdout)[-1500:]}
         except Exception as e:
             out["inproc"] = {"error": repr(e)}

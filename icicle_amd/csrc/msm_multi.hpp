@@ -253,6 +253,10 @@ namespace icicle_hip {
       GateTicket t_gather(use_rccl ? &gate_gather : nullptr);
       if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED; // (tickets arrive with "failed" on the way out)
       if (icicle_hip_set_device(ds.devs[p]) != ICICLE_SUCCESS) return ICICLE_INVALID_DEVICE;
+      if (ds.devs[p] != home) { // operands are pulled from the calling device: direct xGMI copies where the platform allows them
+        (void)hipDeviceEnablePeerAccess(home, 0); // (already enabled / not supported: the copies then take the runtime's own route)
+        (void)hipGetLastError();
+      }
       // one slot: the caller's stream. Several: a long-lived stream per (device, slot) -- never a stream created and
       // destroyed per call: the workspace arenas keep last-use events recorded on whatever stream used them, and an event
       // whose stream is gone makes later hipEventSynchronize / hipStreamWaitEvent calls fail (seen in the rehearsal suite)

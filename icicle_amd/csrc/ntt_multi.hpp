@@ -55,6 +55,10 @@ namespace icicle_hip {
     auto worker = [&](int p) -> icicle_error_t {
       if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED;
       ICICLE_TRY(icicle_hip_set_device(ds.devs[p]));
+      if (ds.devs[p] != home) {
+        (void)hipDeviceEnablePeerAccess(home, 0);
+        (void)hipGetLastError();
+      }
       hipStream_t st = threaded ? side_stream(200 + p) : job.stream; // long-lived per (device, slot): see msm_multi.hpp
       if (threaded && !st) return ICICLE_STREAM_CREATION_FAILED;
       icicle_error_t rc = [&]() -> icicle_error_t {

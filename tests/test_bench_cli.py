@@ -1,0 +1,37 @@
+"""CPU: bench.py's launcher contract (VERDICT r02 item 2 i): `python bench.py --gpus N` without a rendezvous in the
+environment must not die on an assertion -- it launches itself one rank per GPU, or, on a box with fewer than N GPUs,
+prints ONE JSON line with an "error" key and exits 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_n_without_enough_devices_reports_json_error():
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    want = max(2, have + 1)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--size-log2", "16"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == want and out["value"] is None
+    assert f"needs {want} devices" in out["error"]
+    assert out["metric"] == "bn254_msm_2^26_per_sec" and out["unit"] == "MSM/s"
+
+
+def test_bench_rank_count_mismatch_is_a_json_error_too():
+    """WORLD_SIZE set by a launcher but different from --gpus: a JSON line, not a traceback"""
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert "error" in out and "WORLD_SIZE=3" in out["error"]
