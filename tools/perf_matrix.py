@@ -131,6 +131,57 @@ def ecntt_case(curve, logn, batch=1):
     N.release_domain(curve)
 
 
+
+def criterion_sweep():
+    """The shape of the reference's own criterion benches (wrappers/rust/icicle-core/src/msm/mod.rs:386-470: sizes
+    2^13..2^25, precompute_factor {1, 4, 8}, batch {1, 16, 128} with batch * size <= 2^25, HOST scalars, precomputed bases
+    on the device, async on a stream; ntt/mod.rs:504-572: sizes from 2^13, batches from 2^7 with batch * size <= 2^25,
+    host in / out, both directions, all six orderings), thinned to every fourth size."""
+    import numpy as np
+
+    for logn in (13, 17, 21, 25):
+        n = 1 << logn
+        bases = torch.empty((n, 16), dtype=torch.int32, device=dev)
+        check(lib.bn254_hip_generate_affine_points(bases.data_ptr(), n, 1, True, None))
+        for pf in (1, 4, 8):
+            cfg = MSMConfig.default()
+            cfg.precompute_factor = pf
+            cfg.is_async = True
+            table = bases
+            if pf > 1:
+                table = torch.empty((n * pf, 16), dtype=torch.int32, device=dev)
+                M.precompute_bases("bn254", bases.data_ptr(), cfg, output=table.data_ptr(), nof_bases=n)
+            for batch in (1, 16, 128):
+                if batch * n > (1 << 25):
+                    continue
+                rng = np.random.default_rng(logn * 10 + batch)
+                hs = rng.integers(0, 1 << 32, size=(batch * n, 8), dtype=np.uint64).astype(np.uint32)
+                hs[:, 7] &= 0x0FFFFFFF
+                res = torch.empty((batch, 24), dtype=torch.int32, device=dev)
+                cfg.batch_size = batch
+                ms = time_it(lambda: M.msm("bn254", hs, table.data_ptr(), cfg, results=res.data_ptr(), msm_size=n))
+                print(f"criterion msm bn254 {n} x {batch} with precomp = {pf}: {ms:9.3f} ms  (host scalars, device bases)", flush=True)
+            del table
+        del bases
+    N.init_domain("babybear", N.get_root_of_unity("babybear", 1 << 21))
+    names = ["kNN", "kNR", "kRN", "kRR", "kNM", "kMN"]
+    for logn, batch in ((13, 128), (13, 4096), (17, 128), (21, 16)):
+        n = 1 << logn
+        rng = np.random.default_rng(logn)
+        hx = rng.integers(0, 0x78000001, size=(batch, n), dtype=np.uint32)
+        hy = np.empty_like(hx)
+        row = []
+        for d in (N.FORWARD, N.INVERSE):
+            for o in range(6):
+                cfg = NTTConfigU32.default()
+                cfg.batch_size = batch
+                cfg.ordering = o
+                ms = time_it(lambda: N.ntt("babybear", hx, d, cfg, out=hy))
+                row.append(f"{names[o]} {'fwd' if d == N.FORWARD else 'inv'} {ms:7.3f}")
+        print(f"criterion ntt babybear {n} x {batch} (host in / out, ms): " + ", ".join(row), flush=True)
+    N.release_domain("babybear")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "csweep":
         sweep = ((16, (9, 10, 11, 12, 13)), (20, (12, 13, 14, 15, 16)), (22, (14, 15, 16, 17, 18)), (24, (16, 17, 18, 19, 20)), (26, (18, 19, 20, 21)))
@@ -187,6 +238,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ntt":
         for logn, batch in ((12, 4096), (16, 1024), (20, 256), (22, 128), (24, 64), (24, 8), (27, 4)):
             ntt_case("babybear", logn, batch)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "criterion":
+        criterion_sweep()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "precompute":
         for logn, batch in ((16, 1), (16, 16), (20, 1), (20, 16), (22, 1), (24, 1)):
