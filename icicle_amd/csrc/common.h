@@ -200,11 +200,6 @@ namespace icicle_hip {
   hipEvent_t ring_event();
   void ring_events_release(); // a short-lived worker thread gives its events back before it ends (its streams are idle then)
 
-  // ---- pageable host memory <-> device through a pinned ring with parallel host copies (host_stage.hip); pinned, device
-  // or small operands fall through to hipMemcpyAsync. stage_d2h returns when the data is in the caller's buffer.
-  hipError_t stage_h2d(void* dst, const void* src, size_t bytes, hipStream_t st);
-  hipError_t stage_d2h(void* dst, const void* src, size_t bytes, hipStream_t st);
-
   // ---- host-thread rendezvous of the multi-device entry points (msm_multi.hpp, ntt_split.hpp) ----
   // Rendezvous of the per-device host threads in front of a collective: a thread that failed earlier (allocation,
   // copy, launch) must not leave its peers blocked inside ncclSend/ncclRecv/ncclAllGather forever. Every thread

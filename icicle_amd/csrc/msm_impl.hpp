@@ -1261,14 +1261,14 @@ namespace icicle_hip {
     if (!cfg->are_scalars_on_device) {
       const size_t bytes = (size_t)batch * n * FR::N32 * 4;
       HIP_TRY(d_sc_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
-      HIP_TRY(stage_h2d(d_sc_tmp.ptr(), scalars_v, bytes, st), ICICLE_COPY_FAILED);
+      HIP_TRY(hipMemcpyAsync(d_sc_tmp.ptr(), scalars_v, bytes, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
       d_scalars = d_sc_tmp.as<uint32_t>();
     }
     const uint32_t* d_bases = (const uint32_t*)bases_v;
     if (!cfg->are_points_on_device) {
       const size_t bytes = npts_all * PW * 4;
       HIP_TRY(d_b_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
-      HIP_TRY(stage_h2d(d_b_tmp.ptr(), bases_v, bytes, st), ICICLE_COPY_FAILED);
+      HIP_TRY(hipMemcpyAsync(d_b_tmp.ptr(), bases_v, bytes, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
       d_bases = d_b_tmp.as<uint32_t>();
     }
 

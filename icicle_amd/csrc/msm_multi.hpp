@@ -356,20 +356,14 @@ namespace icicle_hip {
             if (s.leased) HIP_TRY(hipStreamWaitEvent(cs, s.leased, 0), ICICLE_SYNCHRONIZATION_FAILED);
             if (s.copy_sc) {
               const uint32_t* src = (const uint32_t*)scalars_v + (size_t)s.lo * SW;
-              if (batch == 1) // (pageable host scalars go through the pinned ring: host_stage.hip)
-                HIP_TRY(stage_h2d(s.sc.ptr(), src, (size_t)s.ns * SW * 4, cs), ICICLE_COPY_FAILED);
-              else
-                HIP_TRY(hipMemcpy2DAsync(s.sc.ptr(), (size_t)s.ns * SW * 4, src, (size_t)n * SW * 4, (size_t)s.ns * SW * 4, batch, hipMemcpyDefault, cs), ICICLE_COPY_FAILED);
+              HIP_TRY(hipMemcpy2DAsync(s.sc.ptr(), (size_t)s.ns * SW * 4, src, (size_t)n * SW * 4, (size_t)s.ns * SW * 4, batch, hipMemcpyDefault, cs), ICICLE_COPY_FAILED);
               s.scp = (const uint32_t*)s.sc.ptr();
               multi_stats().staged_scalar_bytes += (size_t)batch * s.ns * SW * 4;
             }
             if (s.copy_b) {
               const size_t row = (size_t)s.ns * pf * PW * 4;
               const uint32_t* src = (const uint32_t*)bases_v + (size_t)s.lo * pf * PW;
-              if (brows == 1)
-                HIP_TRY(stage_h2d(s.b.ptr(), src, row, cs), ICICLE_COPY_FAILED);
-              else
-                HIP_TRY(hipMemcpy2DAsync(s.b.ptr(), row, src, (size_t)n * pf * PW * 4, row, brows, hipMemcpyDefault, cs), ICICLE_COPY_FAILED);
+              HIP_TRY(hipMemcpy2DAsync(s.b.ptr(), row, src, (size_t)n * pf * PW * 4, row, brows, hipMemcpyDefault, cs), ICICLE_COPY_FAILED);
               s.bp = (const uint32_t*)s.b.ptr();
               multi_stats().staged_base_bytes += row * brows;
             }

@@ -963,7 +963,7 @@ namespace icicle_hip {
     uint32_t* d_out = output;
     if (!cfg->are_inputs_on_device) {
       HIP_TRY(d_in_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
-      HIP_TRY(stage_h2d(d_in_tmp.ptr(), input, bytes, st), ICICLE_COPY_FAILED);
+      HIP_TRY(hipMemcpyAsync(d_in_tmp.ptr(), input, bytes, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
       d_in = d_in_tmp.as<uint32_t>();
     }
     if (!cfg->are_outputs_on_device) {
@@ -1118,7 +1118,7 @@ namespace icicle_hip {
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
 
     if (!cfg->are_outputs_on_device) {
-      HIP_TRY(stage_d2h(output, d_out, bytes, st), ICICLE_COPY_FAILED);
+      HIP_TRY(hipMemcpyAsync(output, d_out, bytes, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
       HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
     } else if (!cfg->is_async) {
       HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);

@@ -118,7 +118,7 @@ namespace icicle_hip {
           const int rows = rows_of(j, &lo);
           if (in_direct || rows == 0) return ICICLE_SUCCESS;
           HIP_TRY(hipStreamWaitEvent(cin, s.leased, 0), ICICLE_SYNCHRONIZATION_FAILED);
-          HIP_TRY(stage_h2d(s.buf.ptr(), (const char*)job.input + (size_t)lo * job.row_bytes, (size_t)rows * job.row_bytes, cin), ICICLE_COPY_FAILED); // (device-to-device for a remote slot)
+          HIP_TRY(hipMemcpyAsync(s.buf.ptr(), (const char*)job.input + (size_t)lo * job.row_bytes, (size_t)rows * job.row_bytes, hipMemcpyDefault, cin), ICICLE_COPY_FAILED);
           HIP_TRY(hipEventRecord(s.filled, cin), ICICLE_SYNCHRONIZATION_FAILED);
           multi_stats().staged_scalar_bytes += (size_t)rows * job.row_bytes;
           return ICICLE_SUCCESS;
@@ -141,7 +141,7 @@ namespace icicle_hip {
           const int rows = rows_of(j, &lo);
           if (out_direct || rows == 0) return ICICLE_SUCCESS;
           HIP_TRY(hipStreamWaitEvent(cout, s.done, 0), ICICLE_SYNCHRONIZATION_FAILED);
-          HIP_TRY(stage_d2h((char*)job.output + (size_t)lo * job.row_bytes, s.buf.ptr(), (size_t)rows * job.row_bytes, cout), ICICLE_COPY_FAILED);
+          HIP_TRY(hipMemcpyAsync((char*)job.output + (size_t)lo * job.row_bytes, s.buf.ptr(), (size_t)rows * job.row_bytes, hipMemcpyDefault, cout), ICICLE_COPY_FAILED);
           HIP_TRY(hipEventRecord(s.drained, cout), ICICLE_SYNCHRONIZATION_FAILED);
           s.has_drain = true;
           return ICICLE_SUCCESS;
