@@ -26,6 +26,7 @@
 #pragma once
 #include "common.h"
 #include "ec.hpp"
+#include "msm_plan.h"
 #include <algorithm>
 #include <tuple>
 
@@ -1421,28 +1422,13 @@ namespace icicle_hip {
       // sorted on a second stream and group g - 1 is reduced and scaled by its 2^(c*w) on a third, so the long doubling
       // chains of the high windows and most of the sort leave the critical path. NG = 1 is the plain sequence.
       // Batches (bb > 1) already fill the chip with independent work, and a bucket-exchange hook wants all windows at once.
-      int NG = 1;
+      int glo[MSM_MAX_GROUPS], ghi[MSM_MAX_GROUPS];
+      int want_groups = 1;
       if (bb == 1 && !hook && tw >= 4) {
         static const int env_ng = getenv("ICICLE_HIP_MSM_GROUPS") ? atoi(getenv("ICICLE_HIP_MSM_GROUPS")) : MSM_DEFAULT_GROUPS;
-        NG = std::max(1, std::min<int>(env_ng, (int)tw / 2));
+        want_groups = env_ng;
       }
-      // group g = windows [glo[g], ghi[g]); g = 0 holds the top windows; the end groups are half as wide as the inner
-      // ones (a short first group lets accumulation start early, a short last one leaves little to reduce at the end)
-      int glo[16], ghi[16];
-      NG = std::min(NG, 16);
-      {
-        const double unit = (double)tw / (NG <= 2 ? NG : NG - 1);
-        double acc = 0;
-        int hi = (int)tw;
-        for (int g = 0; g < NG; g++) {
-          acc += (NG <= 2 || (g > 0 && g < NG - 1)) ? unit : unit / 2;
-          int lo = g == NG - 1 ? 0 : std::max(0, (int)tw - (int)(acc + 0.5));
-          lo = std::min(lo, hi - 1);
-          if (g < NG - 1) lo = std::max(lo, NG - 1 - g); // every later group keeps at least one window
-          glo[g] = lo, ghi[g] = hi;
-          hi = lo;
-        }
-      }
+      const int NG = msm_window_groups((int)tw, want_groups, glo, ghi); // msm_plan.h
       hipStream_t s_sort = st, s_red = st, s_acc = st;
       if (NG > 1) {
         s_sort = side_stream(10);

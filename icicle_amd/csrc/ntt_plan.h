@@ -111,4 +111,20 @@ namespace icicle_hip {
     return pd;
   }
 
+  // ---- one transform split over P device slots (ntt_split.hpp): N = 2^a * 2^b, both factors at least P wide ----
+  struct SplitShape {
+    int P, logn, a, b; // N1 = 2^a, N2 = 2^b
+  };
+  static inline bool split_shape(int logn, int P, SplitShape* s)
+  {
+    if (P < 2 || (P & (P - 1)) != 0) return false;
+    int lp = 0;
+    while ((1 << lp) < P)
+      lp++;
+    const int a = std::max((logn + 1) / 2, lp), b = logn - a;
+    if (b < lp) return false;
+    *s = {P, logn, a, b};
+    return true;
+  }
+
 } // namespace icicle_hip

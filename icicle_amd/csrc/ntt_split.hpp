@@ -30,22 +30,6 @@ static __global__ __launch_bounds__(256) void k_transpose_u32(const uint32_t* __
     if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
-struct SplitShape {
-  int P, logn, a, b; // N1 = 2^a, N2 = 2^b
-};
-// may this transform be split over P slots? (power-of-two slots, both factors at least P wide)
-static inline bool split_shape(int logn, int P, SplitShape* s)
-{
-  if (P < 2 || (P & (P - 1)) != 0) return false;
-  int lp = 0;
-  while ((1 << lp) < P)
-    lp++;
-  const int a = std::max((logn + 1) / 2, lp), b = logn - a;
-  if (b < lp) return false;
-  *s = {P, logn, a, b};
-  return true;
-}
-
 template <class PR>
 static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, const DeviceSlots& ds, const SplitShape& sh)
 {

@@ -2,6 +2,7 @@
 // slot of a row exactly once on the way in, and the last pass's natural-order scatter must hit each output once.
 // The address formulas are the kernels' (k_ntt_fast / k_ntt_pass_generic / k_big_ntt_pass).
 #include "../icicle_amd/csrc/ntt_plan.h"
+#include "../icicle_amd/csrc/msm_plan.h"
 #include <cstdio>
 #include <vector>
 using namespace icicle_hip;
@@ -51,5 +52,41 @@ extern "C" int plan_check(int max_logn)
     if (int rc = check(logn, 8, 32)) return logn * 100 + rc;  // 31-bit fields
     if (int rc = check(logn, 8, 4)) return logn * 100 + rc;   // 256-bit fields: tiles of at most 4 columns
   }
+  return 0;
+}
+
+// window groups of the pipelined MSM schedule: a partition of [0, tw) into contiguous non-empty ranges, highest first
+extern "C" int msm_groups_check(void)
+{
+  for (int tw = 1; tw <= 200; tw++)
+    for (int want = 1; want <= 20; want++) {
+      int lo[MSM_MAX_GROUPS], hi[MSM_MAX_GROUPS];
+      const int ng = msm_window_groups(tw, want, lo, hi);
+      if (ng < 1 || ng > MSM_MAX_GROUPS || ng > std::max(1, want)) return 1000 * tw + want;
+      if (tw < 4 && ng != 1) return -(1000 * tw + want);
+      if (hi[0] != tw || lo[ng - 1] != 0) return 2000000 + 1000 * tw + want;
+      for (int g = 0; g < ng; g++) {
+        if (lo[g] >= hi[g]) return 3000000 + 1000 * tw + want;
+        if (g + 1 < ng && lo[g] != hi[g + 1]) return 4000000 + 1000 * tw + want;
+      }
+    }
+  return 0;
+}
+
+// shapes of a transform split over P device slots: both factors cover the slots, the factors multiply to N
+extern "C" int split_shape_check(void)
+{
+  for (int logn = 0; logn <= 30; logn++)
+    for (int P = 1; P <= 64; P++) {
+      SplitShape s;
+      const bool ok = split_shape(logn, P, &s);
+      const bool pow2 = P >= 2 && (P & (P - 1)) == 0;
+      int lp = 0;
+      while ((1 << lp) < P)
+        lp++;
+      if (!pow2 && ok) return 100 * logn + P;
+      if (ok && (s.a + s.b != logn || s.a < lp || s.b < lp || s.a < s.b)) return 10000 + 100 * logn + P;
+      if (pow2 && !ok && logn >= 2 * lp) return 20000 + 100 * logn + P; // every transform with N >= P^2 can be split
+    }
   return 0;
 }

@@ -396,3 +396,43 @@ def test_single_ntt_split_over_device_slots(hip, slots, fname, P, logn):
         lib.destroy_config_extension(ext)
         N.release_domain(fname)
         rf.release_domain()
+
+
+def test_two_host_threads_call_the_multi_device_msm_at_once(hip, slots):
+    """collectives of two calls on one communicator set must not interleave -- the per-set mutex serialises
+    host threads that enter a multi-device msm() on the same devices at the same time (ctypes drops the GIL in the call)."""
+    import threading
+
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib
+
+    C, rng, bases, sc = _inputs("bn254", 4001, 4242)
+    refc = ref.RefCurve("bn254")
+    sc2 = to_words(rand_scalars(rng, len(sc), C.r), 8)
+    exp = [refc.to_affine(refc.msm(s, bases)) for s in (sc, sc2)]
+    slots(4)
+    exts = [_ext(hip_num_devices=4, hip_msm_exchange_buckets=bool(k)) for k in range(2)]
+    got, errs = [None, None], []
+
+    def run(k, scalars):
+        try:
+            for _ in range(4):
+                cfg = hip.MSMConfig.default()
+                cfg.ext = exts[k]
+                got[k] = M.msm("bn254", scalars, bases, cfg)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    try:
+        th = [threading.Thread(target=run, args=(0, sc)), threading.Thread(target=run, args=(1, sc2))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=150)
+        assert not errs, errs
+        assert all(not t.is_alive() for t in th), "a multi-device call is stuck"
+        for k in range(2):
+            assert np.array_equal(refc.to_affine(got[k]), exp[k]), k
+    finally:
+        for e in exts:
+            lib.destroy_config_extension(e)

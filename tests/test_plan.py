@@ -11,7 +11,10 @@ def test_ntt_plan_covers_every_slot_once():
     so = os.path.join(HERE, "_build", "libplan.so")
     os.makedirs(os.path.dirname(so), exist_ok=True)
     src = os.path.join(HERE, "plan_harness.cpp")
-    hdr = os.path.join(HERE, "..", "icicle_amd", "csrc", "ntt_plan.h")
-    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+    hdrs = [os.path.join(HERE, "..", "icicle_amd", "csrc", h) for h in ("ntt_plan.h", "msm_plan.h")]
+    if not os.path.exists(so) or max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]) > os.path.getmtime(so):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", src, "-o", so])
-    assert ctypes.CDLL(so).plan_check(22) == 0
+    lib = ctypes.CDLL(so)
+    assert lib.plan_check(22) == 0
+    assert lib.msm_groups_check() == 0  # window groups of the pipelined MSM schedule (msm_plan.h)
+    assert lib.split_shape_check() == 0  # shapes of a transform split over device slots (ntt_plan.h)
