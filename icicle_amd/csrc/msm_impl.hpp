@@ -57,14 +57,29 @@ namespace icicle_hip {
     // so shared and per-MSM base tables of any batch shape work (pass config.c on both calls to tune it).
     if (c <= 0 && p.pf > 1) c = 16;
     if (c <= 0) {
-      // minimise  (#mixed adds) + (bucket-reduction adds, weighted for their poor parallelism)
+      // minimise  (#mixed adds) + (bucket-reduction work). Fitted to a measured sweep (profiles/r03_msm_csweep.txt):
+      //  * a window size whose TOP window holds only 1-3 scalar bits is never chosen: that window has a handful of
+      //    buckets with n/4 points each, i.e. one more window of mixed adds for nothing plus the whole overflow machinery
+      //    (c = 14, 18, 21 for 254-bit scalars: 2^20 4.7 / 4.6 ms against 2.9 ms at c = 17; 2^26 98 against 71 ms);
+      //  * n >= 2^16: with fewer than ~2.5 waves of bucket threads per SIMD the accumulation runs below its issue rate,
+      //    which favours MORE buckets than the add count alone suggests, and a bucket costs 2 (below 2^22) to 4 add-
+      //    equivalents in the reduction (2^16: c 13 -> 15, 2.10 -> 1.74 ms; 2^18: 2.67 -> 2.15; 2^20: 15 -> 17, 3.4 -> 2.9);
+      //  * below 2^16 the latency of the reduction and of the window combine dominates: per bucket: ~2 complete adds
+      //    (14 muls each) vs 10 muls per mixed add, weighted 8 for their poor parallelism (round 1's fit, still the best).
+      const bool mid = n >= (1 << 16);
       double best = 1e300;
       for (int cc = 2; cc <= 21; cc++) {
         const int w = (p.bits + 1 + cc - 1) / cc;
         const int wpf = (w + p.pf - 1) / p.pf;
-        // per bucket: ~2 complete adds (14 muls each) in the reduction vs 10 muls per mixed add, plus
-        // the traffic of writing/reading the bucket; weight 8 also penalises its poorer parallelism
-        const double cost = (double)w * n + 8.0 * wpf * (double)(1u << (cc - 1));
+        if (w > 1 && p.bits + 1 - cc * (w - 1) <= 3 && p.bits > 8) continue; // tiny top window
+        const double nbk = (double)wpf * (double)(1u << (cc - 1));
+        double cost;
+        if (mid) {
+          const double occupancy = std::max(1.0, 2.5 * 65536.0 / nbk); // bucket threads per SIMD lane slot
+          cost = (double)w * n * occupancy + (n >= (1 << 22) ? 4.0 : 2.0) * nbk; // (below 2^22 the reduction is latency-, not throughput-bound)
+        } else {
+          cost = (double)w * n + 8.0 * nbk;
+        }
         if (cost < best) {
           best = cost;
           c = cc;
