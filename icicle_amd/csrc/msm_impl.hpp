@@ -1029,52 +1029,50 @@ namespace icicle_hip {
   //     LDS. <1 % of the work at 2^26, but the latency floor of a small MSM.
   //     (A <<<1,1>>> serial Horner is provably wave-uniform, so hipcc compiles ALL of its field
   //     arithmetic to SALU code, which is several times slower per multiply than the VALU path.)
-  // threads of k_final: 4 lanes per window; G1 covers the 128 possible windows at once, the Fq2 curves keep the block
-  // at 256 threads (one wave per SIMD: the complete addition over Fq2 wants the whole register file)
+  // k_final: 4 lanes per window, ONE wave (16 windows) per block. A block of several busy waves was measured twice:
+  // windows 0..15 in wave 0 and 16.. in wave 1 of one block -> a 17- to 22-window combine takes 0.8-1.0 ms against
+  // 0.61-0.73 ms for 13-16 windows of the same chain length; the windows dealt round-robin to four waves -> 1.1-1.6 ms
+  // (profiles/r03_notes.md section 8): the waves of one small block share issue bandwidth instead of taking a SIMD each.
+  // Separate single-wave blocks land on different CUs; their partial sums are added by k_final_combine.
+  constexpr int FINAL_WINDOWS_PER_BLOCK = 16;
+  // Block (bw, b) combines windows [w0 + 16 bw, ...) of MSM b, at most 16 of the nw windows [w0, w0 + nw) -- still scaled
+  // by their full 2^(c*w). With `partial` the block's sum goes to partial[(slot0 + bw) * nmsm + b] in the kernels' own
+  // representation (several blocks per MSM, or a window group of the pipelined schedule); without, to result[b].
   template <class C>
-  struct FinalThreads {
-    static constexpr int value = sizeof(typename EC<C>::fe) > 64 ? 256 : 512;
-  };
-  // Window groups (pipelined schedule): the kernel combines windows [w0, w0 + nw) of each MSM -- still scaled by their
-  // full 2^(c*w) -- and, when `partial` is given, leaves the group's sum there in the kernels' own representation for
-  // k_final_combine; the long chains of the HIGH windows then run while the low windows are still being accumulated.
-  template <class C>
-  __global__ __launch_bounds__(FinalThreads<C>::value) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c, int w0, int nw, typename EC<C>::Proj* __restrict__ partial)
+  __global__ __launch_bounds__(64) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c, int w0, int nw, typename EC<C>::Proj* __restrict__ partial, int slot0, int nmsm)
   {
     using E = EC<C>;
-    __shared__ typename E::Proj sh[128];
+    __shared__ typename E::Proj sh[FINAL_WINDOWS_PER_BLOCK];
     // four lanes per window: the doubling chain 2^(c*w) * S_w is the latency floor of the whole MSM, and a quad
     // runs it with three dependent products per step instead of seven (ec.hpp dbl_jac_quad)
     const uint32_t role = threadIdx.x & 3u;
-    winsum += (size_t)blockIdx.x * wpf + w0;
-    result += (size_t)blockIdx.x * 3 * E::N32;
-    for (int w = threadIdx.x >> 2; w < 128; w += FinalThreads<C>::value >> 2) {
-      typename E::Proj v = E::proj_identity();
-      if (w < nw) {
-        v = winsum[w];
-        if (w0 + w > 0) { // Jacobian doubling chain (ec.hpp), 2M + 5S per step
-          typename E::Jac j = E::to_jac(v);
-          for (int i = 0; i < (w0 + w) * c; i++) // the same trip count in all four lanes of a quad
-            j = E::dbl_jac_quad(j, role);
-          v = E::from_jac(j);
-        }
+    const int bw = blockIdx.x, b = blockIdx.y;
+    const int wfirst = w0 + FINAL_WINDOWS_PER_BLOCK * bw;
+    const int nwb = min(FINAL_WINDOWS_PER_BLOCK, w0 + nw - wfirst);
+    winsum += (size_t)b * wpf + wfirst;
+    const int w = threadIdx.x >> 2;
+    typename E::Proj v = E::proj_identity();
+    if (w < nwb) {
+      v = winsum[w];
+      if (wfirst + w > 0) { // Jacobian doubling chain (ec.hpp), 2M + 5S per step
+        typename E::Jac j = E::to_jac(v);
+        for (int i = 0; i < (wfirst + w) * c; i++) // the same trip count in all four lanes of a quad
+          j = E::dbl_jac_quad(j, role);
+        v = E::from_jac(j);
       }
-      if (role == 0) sh[w] = v;
     }
+    if (role == 0) sh[w] = v;
     __syncthreads();
-    int top = 1;
-    while (top < nw)
-      top <<= 1;
     const int lane = threadIdx.x;
-    for (int s = top >> 1; s >= 1; s >>= 1) {
+    for (int s = FINAL_WINDOWS_PER_BLOCK >> 1; s >= 1; s >>= 1) {
       if (lane < s) sh[lane] = E::add(sh[lane], sh[lane + s]);
       __syncthreads();
     }
     if (lane == 0) {
       if (partial)
-        partial[blockIdx.x] = sh[0];
+        partial[(size_t)(slot0 + bw) * nmsm + b] = sh[0];
       else
-        E::store_proj_canonical(result, sh[0]);
+        E::store_proj_canonical(result + (size_t)b * 3 * E::N32, sh[0]);
     }
   }
   // result[b] = sum of the ng group partials of MSM b (partials[g * nmsm + b]), canonical words
@@ -1453,9 +1451,15 @@ namespace icicle_hip {
       // scratch that concurrent groups must not share
       TempBuf d_gscan, d_part;
       const size_t scan_words = tw * (std::max<size_t>((size_t)sp.nblk << sp.hb, nb) / SCAN_CHUNK + 1) + (szblk_max * SZ_BINS) / SCAN_CHUNK + 16;
+      int part_slot[MSM_MAX_GROUPS], part_slots = 0; // partial-sum slots of the window combine: one per 16 windows of a group
+      for (int g = 0; g < NG; g++) {
+        part_slot[g] = part_slots;
+        part_slots += (ghi[g] - glo[g] + FINAL_WINDOWS_PER_BLOCK - 1) / FINAL_WINDOWS_PER_BLOCK;
+      }
+      // (one group: blocks of 16 windows per MSM of the launch; several groups: bb == 1 and the slots counted above)
+      HIP_TRY(d_part.alloc((size_t)(NG > 1 ? part_slots : (wpf + FINAL_WINDOWS_PER_BLOCK - 1) / FINAL_WINDOWS_PER_BLOCK) * bb * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
       if (NG > 1) {
         HIP_TRY(d_gscan.alloc((size_t)NG * scan_words * 4, st), ICICLE_ALLOCATION_FAILED);
-        HIP_TRY(d_part.alloc((size_t)NG * bb * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
         HIP_TRY(hipMemsetAsync(d_ovfcnt.ptr(), 0, 16 * 16, st), ICICLE_COPY_FAILED);
       }
       hipEvent_t ev_ready = nullptr, ev_sorted[16] = {nullptr}, ev_acc[16] = {nullptr}, ev_red[16] = {nullptr};
@@ -1587,8 +1591,9 @@ namespace icicle_hip {
           k_reduce_window<C><<<(unsigned)nw, rthreads, 0, sq>>>(chunkV + (size_t)w0 * nseg, chunkT + (size_t)w0 * nseg, win, nsegr, seg_lo, log_chunk);
           LAUNCH_CHECK("k_reduce_window", sq);
         }
-        if (NG > 1) { // (bb == 1) this group's windows, scaled, into its partial
-          k_final<C><<<1, FinalThreads<C>::value, 0, sq>>>(d_win.as<typename E::Proj>(), nullptr, wpf, pl.c, w0, nw, d_part.as<typename E::Proj>() + g);
+        if (NG > 1) { // (bb == 1) this group's windows, scaled, into its partial slots
+          const int nbw = (nw + FINAL_WINDOWS_PER_BLOCK - 1) / FINAL_WINDOWS_PER_BLOCK;
+          k_final<C><<<dim3((unsigned)nbw, 1), 64, 0, sq>>>(d_win.as<typename E::Proj>(), nullptr, wpf, pl.c, w0, nw, d_part.as<typename E::Proj>(), part_slot[g], 1);
           LAUNCH_CHECK("k_final(group)", sq);
         }
         return ICICLE_SUCCESS;
@@ -1606,8 +1611,15 @@ namespace icicle_hip {
           if (skip) continue; // another shard of this device (or the exchange step) produces the result
         }
         ICICLE_TRY(reduce_group(0, st, seg_lo, nsegr));
-        k_final<C><<<bb, FinalThreads<C>::value, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c, 0, wpf, nullptr);
-        LAUNCH_CHECK("k_final", st);
+        {
+          const int nbw = (wpf + FINAL_WINDOWS_PER_BLOCK - 1) / FINAL_WINDOWS_PER_BLOCK;
+          k_final<C><<<dim3((unsigned)nbw, (unsigned)bb), 64, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c, 0, wpf, nbw > 1 ? d_part.as<typename E::Proj>() : nullptr, 0, bb);
+          LAUNCH_CHECK("k_final", st);
+          if (nbw > 1) { // more than 16 windows: one single-wave block per 16 of them, then the sum of the partials
+            k_final_combine<C><<<(unsigned)((bb + 63) / 64), 64, 0, st>>>(d_part.as<typename E::Proj>(), d_res + (size_t)b0 * RW, nbw, bb);
+            LAUNCH_CHECK("k_final_combine", st);
+          }
+        }
         KernelTimer::end(3, st);
       } else {
         // main stream: sort(0), accumulate(0), accumulate(1), ... ; sort stream: sort(1), sort(2), ... ; reduce stream:
@@ -1638,7 +1650,7 @@ namespace icicle_hip {
         if (!ev_tail) return ICICLE_ALLOCATION_FAILED;
         HIP_TRY(hipEventRecord(ev_tail, s_red), ICICLE_SYNCHRONIZATION_FAILED);
         HIP_TRY(hipStreamWaitEvent(st, ev_tail, 0), ICICLE_SYNCHRONIZATION_FAILED);
-        k_final_combine<C><<<1, 64, 0, st>>>(d_part.as<typename E::Proj>(), d_res + (size_t)b0 * RW, NG, bb);
+        k_final_combine<C><<<1, 64, 0, st>>>(d_part.as<typename E::Proj>(), d_res + (size_t)b0 * RW, part_slots, bb);
         LAUNCH_CHECK("k_final_combine", st);
         KernelTimer::end(3, st);
       }
