@@ -214,8 +214,12 @@ namespace icicle_hip {
   // profiles/r02_notes.md section 6): the row pass of 2^24 x 64 1.90 -> 1.83 ms, 2^16 x 1024 transforms -7 %. The same
   // paths on the column passes were built and measured neutral (+-1 %), so they are not in the tree. The host picks
   // V4 when every base is 16-byte aligned; results are identical word for word.
-  template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV, bool V4 = false>
-  __global__ __launch_bounds__(512, ntt_fast_min_waves(NR, COSET && DIF)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
+  // BIG: 1024-thread blocks for the 512- and 1024-row column passes of transforms of 2^27 points and more, so that their
+  // tiles are 32 (resp. 16) columns wide instead of 16 (8): 128-byte HBM runs instead of 64-byte ones (a 64-byte-run tile
+  // copy moves 3.9 TB/s, a 128-byte-run one 5.0: profiles/r03_notes.md section 2). The three-round column pass needs 120
+  // VGPRs, which is what a 16-wave block leaves per lane.
+  template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV, bool V4 = false, bool BIG = false>
+  __global__ __launch_bounds__(BIG ? 1024 : 512, BIG ? 1 : ntt_fast_min_waves(NR, COSET && DIF)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
   {
     using S = SmallField<PR>;
     constexpr int SS = NQ0 + 4 * (NR - 1);
@@ -833,8 +837,11 @@ namespace icicle_hip {
   }
 
   template <class PR>
-  static pass_fn_t<PR> pick_pass(int s, bool dif, bool inv, bool coset, bool outrev, bool v4)
+  static pass_fn_t<PR> pick_pass(int s, bool dif, bool inv, bool coset, bool outrev, bool v4, bool big = false)
   {
+    if (big && !dif && !coset && !outrev && s == 9) return (pass_fn_t<PR>)k_ntt_fast<PR, 1, 3, false, false, false, false, false, true>;
+    if (big && !dif && !coset && !outrev && s == 10) return (pass_fn_t<PR>)k_ntt_fast<PR, 2, 3, false, false, false, false, false, true>;
+    if (big) return nullptr;
     if (v4 && dif && !coset && !outrev && s == 8) return pick_v4<PR, 2>(inv); // 16-byte lanes: row pass of 2^8 sub-transforms, 32-column tiles
     switch (s) {
     case 1: return pick_variant<PR, 1, 1>(dif, inv, coset, outrev);
@@ -1079,7 +1086,13 @@ namespace icicle_hip {
       const uint64_t L = (uint64_t)1 << parts[p];
       // fast path: block = T * L/16 threads (<= 512), LDS = 2 buffers of L*(T+1) words (<= 160 KiB)
       const uint64_t epb = L >= 16 ? 16 : L;
-      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, 512 * epb / L));
+      // column passes of 512 / 1024 rows (transforms of 2^25 points and more): 1024-thread blocks, twice the tile width
+      static const bool big_on = !(getenv("ICICLE_HIP_NTT_BIG") && atoi(getenv("ICICLE_HIP_NTT_BIG")) == 0);
+      const bool cvar_p = nl.coset && (nl.inverse ? p == P - 1 : p == 0);
+      // Measured (profiles/r03_notes.md section 9): 2^27 x 4 5.63 -> 5.18 ms, 2^27 x 8 9.74 -> 9.15, but 2^26 x 16 7.25 -> 7.52 and
+      // 2^25 x 32 unchanged (one 16-wave block per CU hides less latency than two 8-wave ones): only from 2^27 up.
+      const bool big = big_on && fast && logn >= 27 && p < P - 1 && P >= 2 && (parts[p] == 9 || parts[p] == 10) && !cvar_p;
+      uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (big ? 1024 : 512) * epb / L));
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
         tmax >>= 1;
       PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
@@ -1097,7 +1110,7 @@ namespace icicle_hip {
         // 16-byte lanes need unit element stride, rows and bases on 16-byte boundaries and full 32-column tiles
         static const bool v4_on = !(getenv("ICICLE_HIP_NTT_V4") && atoi(getenv("ICICLE_HIP_NTT_V4")) == 0);
         const bool v4 = v4_on && pd.is_last && lanes == 1 && nl.es == 1 && nl.bs % 4 == 0 && pd.T == 32 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
-        pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, nl.out_rev != 0 && pd.is_last != 0, v4);
+        pass_fn_t<PR> fn = pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, nl.out_rev != 0 && pd.is_last != 0, v4, big && threads > 512);
         if (!fn) return ICICLE_INVALID_ARGUMENT;
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
         fn<<<dim3(pd.ntiles, gy), threads, lds_bytes, st>>>(src, dst, dom.tw, d_ctab.as<uint32_t>(), pd, nl, rpb);

@@ -62,3 +62,49 @@ def test_babybear_config2_full_size_vs_oracle(hip):
     finally:
         N.release_domain("babybear")
         rf.release_domain()
+
+
+@pytest.mark.parametrize("fname", ["babybear"])  # (KoalaBear's two-adicity is 24)
+@pytest.mark.parametrize("logn", [25, 26, 27])
+def test_transforms_beyond_2_24_against_the_four_step_identity(hip, fname, logn):
+    """2^25 .. 2^27 take 512-row column passes (at 2^27 in 1024-thread blocks with 32-column tiles: round 3). The reference CPU backend
+    needs minutes for a domain of that size, so the direct transform is compared with the same transform computed by
+    the four-step identity out of 2^12 / 2^13 / 2^14-point transforms of this backend (icicle_amd/dist.py with one rank) --
+    kernels that ARE byte-compared with the reference at their sizes -- plus the inverse round trip."""
+    import torch
+    from icicle_amd import dist as D
+    from icicle_amd import ntt as N
+
+    F = pyref.NTT_FIELDS[fname]
+    n = 1 << logn
+    N.init_domain(fname, N.get_root_of_unity(fname, n))
+    try:
+        dev = torch.device("cuda", 0)
+        g = torch.Generator(device=dev)
+        g.manual_seed(logn)
+        x = torch.randint(0, F.p, (n,), dtype=torch.int32, device=dev, generator=g)
+        y = torch.empty_like(x)
+        cfg = hip.NTTConfigU32.default()
+        cfg.is_async = True
+        N.ntt(fname, x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n)
+        torch.cuda.synchronize()
+        y4 = D.ntt_distributed(fname, x.clone(), logn, False, 0, 1, None)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y4), (fname, logn, "direct transform differs from the four-step composition")
+        assert int(y[0].item()) == int((x.to(torch.int64).sum() % F.p).item())
+        z = torch.empty_like(x)
+        N.ntt(fname, y.data_ptr(), N.INVERSE, cfg, out=z.data_ptr(), size=n)
+        torch.cuda.synchronize()
+        assert torch.equal(z, x)
+        # two rows at once (the batch loop of the wide passes)
+        if logn == 25:
+            x2 = torch.stack([x, torch.roll(x, 1)])
+            y2 = torch.empty_like(x2)
+            cfg2 = hip.NTTConfigU32.default()
+            cfg2.batch_size, cfg2.is_async = 2, True
+            N.ntt(fname, x2.data_ptr(), N.FORWARD, cfg2, out=y2.data_ptr(), size=n)
+            torch.cuda.synchronize()
+            assert torch.equal(y2[0], y)
+            assert torch.equal(y2[1], D.ntt_distributed(fname, x2[1].clone(), logn, False, 0, 1, None))
+    finally:
+        N.release_domain(fname)

@@ -239,7 +239,7 @@ if __name__ == "__main__":
                 print(f"ntt babybear 2^24 x {batch} host-resident in/out ({label}): {ms:9.2f} ms  ({2 * hx.nbytes / ms / 1e6:.1f} GB/s effective both ways)", flush=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ntt":
-        for logn, batch in ((12, 4096), (16, 1024), (20, 256), (22, 128), (24, 64), (24, 8), (27, 4)):
+        for logn, batch in ((12, 4096), (16, 1024), (20, 256), (22, 128), (24, 64), (24, 8), (25, 32), (26, 16), (27, 8), (27, 4)):
             ntt_case("babybear", logn, batch)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "criterion":
