@@ -66,7 +66,9 @@ namespace icicle_hip {
       //    equivalents in the reduction (2^16: c 13 -> 15, 2.10 -> 1.74 ms; 2^18: 2.67 -> 2.15; 2^20: 15 -> 17, 3.4 -> 2.9);
       //  * below 2^16 the latency of the reduction and of the window combine dominates: per bucket: ~2 complete adds
       //    (14 muls each) vs 10 muls per mixed add, weighted 8 for their poor parallelism (round 1's fit, still the best).
-      const bool mid = n >= (1 << 16);
+      // (a batch runs as ONE launch sequence with batch x the bucket threads and batch x the reduction work: round 1's
+      //  weights stay the better fit there -- 16 x 2^16: 3.5 ms against 4.5 ms with the single-MSM fit)
+      const bool mid = n >= (1 << 16) && std::max(1, cfg.batch_size) == 1;
       double best = 1e300;
       for (int cc = 2; cc <= 21; cc++) {
         const int w = (p.bits + 1 + cc - 1) / cc;
