@@ -357,6 +357,42 @@ namespace icicle_hip {
       r.z = F::dbl(YZ);
       return r;
     }
+    // ---- complete addition spread over the four lanes of a DPP quad (ECNTT butterflies) ----------------------------------
+    // add_body has 14 products in three dependent levels (6, 2, 6). All four lanes of a quad hold the same p and q; a lane
+    // computes one product per round, results are broadcast with quad_perm moves: five product latencies per addition
+    // instead of fourteen. Same operands, bounds and values as add_body (Renes-Costello-Batina Algorithm 7, a = 0).
+    static __device__ __forceinline__ Proj add_quad(const Proj& p, const Proj& q, uint32_t role)
+    {
+      const bool r0 = role == 0, r1 = role == 1, r2 = role == 2;
+      const bool even = (role & 1u) == 0;
+      const fe sxy1 = F::add(p.x, p.y), sxy2 = F::add(q.x, q.y);
+      const fe syz1 = F::add(p.y, p.z), syz2 = F::add(q.y, q.z);
+      const fe sxz1 = F::add(p.x, p.z), sxz2 = F::add(q.x, q.z);
+      // round A: X1 X2 | Y1 Y2 | Z1 Z2 | (X1 + Y1)(X2 + Y2)
+      const fe a = F::mul(lane_select(r0, p.x, lane_select(r1, p.y, lane_select(r2, p.z, sxy1))), lane_select(r0, q.x, lane_select(r1, q.y, lane_select(r2, q.z, sxy2))));
+      // round B: (Y1 + Z1)(Y2 + Z2) on the even lanes, (X1 + Z1)(X2 + Z2) on the odd ones
+      const fe b = F::mul(lane_select(even, syz1, sxz1), lane_select(even, syz2, sxz2));
+      const fe t0 = quad_bcast<0>(a), t1 = quad_bcast<1>(a), t2 = quad_bcast<2>(a), m3 = quad_bcast<3>(a);
+      const fe m4 = quad_bcast<0>(b), m5 = quad_bcast<1>(b);
+      const fe t3 = F::template sub<4>(m3, F::add(t0, t1)); // X1Y2 + X2Y1
+      const fe t4 = F::template sub<4>(m4, F::add(t1, t2)); // Y1Z2 + Y2Z1
+      const fe t5 = F::template sub<4>(m5, F::add(t0, t2)); // X1Z2 + X2Z1
+      const fe t0_3 = F::add(F::dbl(t0), t0);               // 3 X1X2
+      // round C: 3b Z1Z2 on the even lanes, 3b (X1Z2 + X2Z1) on the odd ones
+      const fe c = F::mul(b3(), lane_select(even, t2, t5));
+      const fe bt2 = quad_bcast<0>(c), y3 = quad_bcast<1>(c);
+      const fe z3 = F::add(t1, bt2);
+      const fe t1m = F::template sub<2>(t1, bt2);
+      // round D: t3 t1m | t4 y3 | t1m z3 | y3 t0_3
+      const fe d = F::mul(lane_select(r0, t3, lane_select(r1, t4, lane_select(r2, t1m, y3))), lane_select(r0, t1m, lane_select(r1, y3, lane_select(r2, z3, t0_3))));
+      // round E: z3 t4 on the even lanes, t0_3 t3 on the odd ones
+      const fe e = F::mul(lane_select(even, z3, t0_3), lane_select(even, t4, t3));
+      Proj r;
+      r.x = F::template sub<2>(quad_bcast<0>(d), quad_bcast<1>(d));
+      r.y = F::add(quad_bcast<2>(d), quad_bcast<3>(d));
+      r.z = F::add(quad_bcast<0>(e), quad_bcast<1>(e));
+      return r;
+    }
 #endif
 
     // k * p for a small unsigned k (bucket reduction segment offsets), MSB-first double-and-add

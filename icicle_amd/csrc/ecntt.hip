@@ -57,11 +57,16 @@ namespace icicle_hip {
     // (the table is published with a barrier); lanes with go == false compute on the identity and the result is unused.
     static __device__ Proj mul_words_quad(const Proj& p, const uint32_t* k, uint32_t role, Proj* tab)
     {
+      // the additions are quad-cooperative as well (five product latencies instead of fourteen): -DECNTT_NOQUADADD = A/B
+#ifdef ECNTT_NOQUADADD
+      auto ADD = [&](const Proj& a, const Proj& b) { return E::add(a, b); };
+#else
+      auto ADD = [&](const Proj& a, const Proj& b) { return E::add_quad(a, b, role); };
+#endif
       Proj e = E::proj_identity();
       for (int i = 0; i < 16; i++) {
         if (role == 0) tab[i] = e;
-        e = (i == 1) ? E::dbl(p) : E::add(e, p); // 0, p, 2p, 3p, ...
-        if (i == 0) e = p;
+        e = (i == 0) ? p : ((i == 1) ? E::dbl(p) : ADD(e, p)); // 0, p, 2p, 3p, ...
       }
       __syncthreads();
       Proj r = E::proj_identity();
@@ -78,7 +83,7 @@ namespace icicle_hip {
             j = E::dbl_jac_quad(j, role);
 #endif
           r = E::from_jac(j);
-          if (dig) r = E::add(r, tab[dig]);
+          if (dig) r = ADD(r, tab[dig]);
         } else if (dig) {
           r = tab[dig];
           started = true;
@@ -181,10 +186,18 @@ namespace icicle_hip {
       v = T::mul_words_quad(v, k, role, tabs[threadIdx.x >> 2]);
     }
 #endif
+#ifdef ECNTT_NOQUADADD
     if (live && role == 0) {
       base[i] = E::add(u, v);
       base[i + half] = E::add(u, T::neg(v));
     }
+#else
+    const typename E::Proj s0 = E::add_quad(u, v, role), s1 = E::add_quad(u, T::neg(v), role);
+    if (live && role == 0) {
+      base[i] = s0;
+      base[i + half] = s1;
+    }
+#endif
   }
 
   // out[slot(k)] = (1/N * g^-k on the inverse) * work[b][k], in the reference's projective_t layout
