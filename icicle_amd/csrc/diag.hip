@@ -99,6 +99,84 @@ namespace icicle_hip {
     return ICICLE_SUCCESS;
   }
 
+  // ---- self-test of the in-place asm products: aliased and constant operands ----------------------------
+  // mul_inplace / mul_add_inplace_c overwrite their read-write operand while the other operands are still being read;
+  // the read-write operands are early-clobber, so an input that is the SAME value (a squaring written as mul_inplace(a, a))
+  // or a compile-time constant must still give the value of the out-of-place product. Every thread checks a different
+  // pseudo-random operand set; mismatches are counted.
+  template <class C>
+  __global__ __launch_bounds__(64) void k_selftest_inplace(uint32_t* __restrict__ mismatches, uint32_t seed)
+  {
+    using F = typename EC<C>::F;
+    using fe = typename F::fe;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    auto seed_fe = [&](uint32_t s) {
+      fe r;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) {
+        s = diag_mix(s + i);
+        r.l[i] = s & RB_MASK;
+      }
+      r.l[F::N - 1] &= 0xfffff; // well below p
+      BF_SET_BOUND(r, 1);
+      return r;
+    };
+    auto same = [&](const fe& x, const fe& y) {
+      uint32_t d = 0;
+#pragma unroll
+      for (int i = 0; i < F::N; i++)
+        d |= x.l[i] ^ y.l[i];
+      return d == 0;
+    };
+    const fe a = seed_fe(t * 7 + seed), b = seed_fe(t * 11 + seed + 1), c = seed_fe(t * 13 + seed + 2), d = seed_fe(t * 17 + seed + 3);
+    uint32_t bad = 0;
+    { // plain: in place == out of place
+      fe x = a;
+      F::mul_inplace(x, b);
+      bad += !same(x, F::mul(a, b));
+    }
+    { // aliased: a <- a * a
+      fe x = a;
+      F::mul_inplace(x, x);
+      bad += !same(x, F::mul(a, a));
+    }
+    { // constant operands (R^2 and the Montgomery one share limbs with each other and with zero limbs)
+      fe x = a;
+      F::mul_inplace(x, F::r2());
+      bad += !same(x, F::mul(a, F::r2()));
+      fe y = F::one();
+      F::mul_inplace(y, F::one());
+      bad += !same(y, F::mul(F::one(), F::one()));
+    }
+    { // c <- a*b + c*d, plain and with every aliasing of the read-write operand
+      fe x = c;
+      F::mul_add_inplace_c(x, a, b, d);
+      bad += !same(x, F::mul_add(a, b, c, d));
+      fe y = c;
+      F::mul_add_inplace_c(y, y, b, d); // a aliases c
+      bad += !same(y, F::mul_add(c, b, c, d));
+      fe z = c;
+      F::mul_add_inplace_c(z, a, z, z); // b and d alias c
+      bad += !same(z, F::mul_add(a, c, c, c));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+  }
+
+  template <class C>
+  static icicle_error_t selftest_inplace_run(int* mismatches)
+  {
+    ICICLE_TRY(bind_current_device());
+    TempBuf cnt;
+    HIP_TRY(cnt.alloc(16, nullptr), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMemsetAsync(cnt.ptr(), 0, 16, nullptr), ICICLE_COPY_FAILED);
+    k_selftest_inplace<C><<<64, 64>>>(cnt.as<uint32_t>(), 12345u);
+    LAUNCH_CHECK("k_selftest_inplace", nullptr);
+    uint32_t h = 0;
+    HIP_TRY(hipMemcpy(&h, cnt.ptr(), 4, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
+    *mismatches = (int)h;
+    return ICICLE_SUCCESS;
+  }
+
 } // namespace icicle_hip
 
 using namespace icicle_hip;
@@ -145,4 +223,17 @@ extern "C" icicle_error_t icicle_hip_ubench_gather(uint64_t region_bytes, uint64
   } catch (...) {
     return ICICLE_INVALID_ARGUMENT;
   }
+}
+
+// In-place field products against their out-of-place forms with aliased and constant operands (curve 0 = bn254's Fq,
+// 1 = bls12_381's Fq): *mismatches must come back 0.
+extern "C" icicle_error_t icicle_hip_selftest_inplace_products(int curve, int* mismatches)
+{
+  if (!mismatches) return ICICLE_INVALID_POINTER;
+  try {
+    if (curve == 0) return selftest_inplace_run<bn254_g1>(mismatches);
+    if (curve == 1) return selftest_inplace_run<bls12_381_g1>(mismatches);
+  } catch (...) {
+  }
+  return ICICLE_INVALID_ARGUMENT;
 }

@@ -296,6 +296,9 @@ icicle_error_t icicle_hip_enable_kernel_timing(bool enable);
  * pattern of its base fetch; also the known-byte-count kernel the FETCH_SIZE counter is calibrated on). */
 icicle_error_t icicle_hip_ubench_mixed_add(int curve, double* adds_per_second);
 icicle_error_t icicle_hip_ubench_gather(uint64_t region_bytes, uint64_t gathers, double* gathers_per_second);
+/* Device self-test of the in-place asm field products with aliased and constant operands (curve 0 = bn254, 1 = bls12_381):
+ * *mismatches must be 0 (tests/test_gpu_msm.py). */
+icicle_error_t icicle_hip_selftest_inplace_products(int curve, int* mismatches);
 /* msm()/ntt() keep their temporaries cached between calls (about 8 GiB after a 2^26-term MSM). release_workspace gives
  * the idle part back to the device (it is also given back automatically when an allocation would otherwise fail, and by
  * <field>_ntt_release_domain); workspace_bytes reports what is cached for the active device. */

@@ -382,3 +382,16 @@ def test_msm_large_batch_fused_digit_histogram(hip, cname):
     nb2 = 520
     bases2 = M.generate_affine_points(cname, n * nb2, k0=99)
     _check(hip, cname, np.ascontiguousarray(words[: n * nb2]), bases2, refc, batch=nb2, shared=False)
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_inplace_asm_products_with_aliased_and_constant_operands(hip, curve_id):
+    """ADVICE r02: the in-place asm products overwrite their read-write operand while the other operands are still read;
+    with early-clobber operands an aliased input (a <- a * a) or a constant one must still give the out-of-place value.
+    4096 pseudo-random operand sets per curve, checked on the device."""
+    import ctypes
+    from icicle_amd._lib import lib, check
+
+    bad = ctypes.c_int(-1)
+    check(lib.icicle_hip_selftest_inplace_products(curve_id, ctypes.byref(bad)), "selftest")
+    assert bad.value == 0
