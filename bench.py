@@ -118,7 +118,10 @@ def launch_self(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + passthrough + ["--no-inproc"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
+    except subprocess.TimeoutExpired as e:
+        r = subprocess.CompletedProcess(cmd, 124, stdout=(e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or ""), stderr="one-process-per-GPU leg timed out after 1200 s")
     out = _last_json_line(r.stdout)
     if out is None:
         out = {"metric": "bn254_msm_2^26_per_sec", "value": None, "unit": "MSM/s", "n_gpus": args.gpus,
@@ -126,7 +129,7 @@ def launch_self(args):
     if not args.no_inproc:
         try:
             r2 = subprocess.run([sys.executable, os.path.abspath(__file__)] + passthrough + ["--inproc-only"], capture_output=True, text=True,
-                                env=env, timeout=300)
+                                env=env, timeout=240)
             out["inproc"] = _last_json_line(r2.stdout) or {"error": f"rc {r2.returncode}: " + (r2.stderr or r2.stdout)[-1500:]}
         except Exception as e:  # the second leg never costs the primary line
             out["inproc"] = {"error": repr(e)}
@@ -448,12 +451,12 @@ def main():
         def emergency():
             if split_done.is_set():
                 return
-            out["ntt_split"] = {"error": "no completion within 180 s; skipped"}
+            out["ntt_split"] = {"error": "no completion within 150 s; skipped"}
             if rank == 0:
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
-        watchdog = threading.Timer(180.0, emergency)
+        watchdog = threading.Timer(150.0, emergency)
         watchdog.daemon = True
         watchdog.start()
         try:
@@ -559,7 +562,7 @@ def main():
                                                                         "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                                         "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
                 r2 = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--inproc-only"], capture_output=True,
-                                    text=True, env=env, timeout=300)
+                                    text=True, env=env, timeout=240)
                 out["inproc"] = _last_json_line(r2.stdout) or {"error": f"rc {r2.returncode}: " + (r2.stderr or r2.stdout)[-1500:]}
         except Exception as e:
             out["inproc"] = {"error": repr(e)}
