@@ -1320,7 +1320,19 @@ namespace icicle_hip {
     // bucket reduction geometry: a wave owns a chunk of 64*mrow buckets; at most RWL chunks per window (one thread of
     // the per-window kernel each), at least 16 rows per lane when the window is big enough to amortise the wave scans
     constexpr uint32_t RWL = ReduceWindowLanes<C>::value;
-    const uint32_t mrow = std::max<uint32_t>(1, std::max<uint32_t>(nb / (64 * RWL), std::min<uint32_t>(16, nb / 64)));
+    // Rows per lane: 16 amortise the wave scans; a single mid-size MSM has fewer reduction waves than the chip has SIMDs
+    // and is bound by the length of one wave's chain, so there the rows shrink until the waves fill the SIMDs once
+    // (2^16, c = 15: 272 waves of 16 rows -> 544 of 8, 1.78 -> 1.59 ms; at 2^20 16 rows already make 960 waves). The rule
+    // depends on the window plan only (every shard of a multi-device call derives the same geometry).
+    uint32_t mrow_cap = 16;
+    if (batch == 1 && nb >= 8192) {
+      uint32_t need = (uint32_t)(((uint64_t)pl.wpf * nb + 65535) / 65536), p2 = 2;
+      while (p2 < need)
+        p2 <<= 1;
+      mrow_cap = std::min<uint32_t>(16, p2);
+    }
+    if (const char* e = getenv("ICICLE_HIP_MSM_MROW")) mrow_cap = (uint32_t)std::max(1, atoi(e)); // (A/B knob)
+    const uint32_t mrow = std::max<uint32_t>(1, std::max<uint32_t>(nb / (64 * RWL), std::min<uint32_t>(mrow_cap, nb / 64)));
     const uint32_t m = 64 * mrow;                       // buckets per chunk ("segment" of the exchange hook)
     const uint32_t nseg = std::max<uint32_t>(1, nb / m); // chunks per window
     uint32_t log_chunk = 0;
