@@ -74,6 +74,9 @@ namespace icicle_hip {
         const int w = (p.bits + 1 + cc - 1) / cc;
         const int wpf = (w + p.pf - 1) / p.pf;
         if (w > 1 && p.bits + 1 - cc * (w - 1) <= 3 && p.bits > 8) continue; // tiny top window
+        // batches of small MSMs: the one-level sort (c <= 11) beats the two-level one by far while the windows are small
+        // (128 x 2^17: c = 11 29.2 ms, c = 12 / 13 36.4 / 34.8; 1024 x 2^12: c = 12 77 ms against 16) -- profiles/r03_notes.md 11
+        if (cfg.batch_size > 1 && n <= (1 << 17) && cc > 11) continue;
         const double nbk = (double)wpf * (double)(1u << (cc - 1));
         double cost;
         if (mid) {
