@@ -1,6 +1,8 @@
 // Host-side planning helpers of the MSM that carry no device code (also compiled by tests/plan_harness.cpp).
 #pragma once
 #include <algorithm>
+#include <cstdint>
+#include "../../include/icicle_hip.h"
 
 namespace icicle_hip {
 
@@ -26,5 +28,80 @@ namespace icicle_hip {
     }
     return NG;
   }
+
+  #ifndef MSM_DEFAULT_GROUPS
+  #define MSM_DEFAULT_GROUPS 1 // window groups of the pipelined schedule (msm_run_single); ICICLE_HIP_MSM_GROUPS overrides
+  #endif
+  struct MsmPlan {
+    int bits;    // scalar bits considered
+    int c;       // window bits
+    int nwin;    // total windows W = ceil((bits+1)/c)
+    int pf;      // precompute factor
+    int wpf;     // windows per precomputed base = target windows actually accumulated
+    uint32_t nb; // buckets per window = 2^(c-1)
+    uint32_t seg; // bucket-accumulation segment size: a bucket with more points is split across threads
+  };
+
+  static MsmPlan make_plan(int n, int scalar_bits, const icicle_msm_config_t& cfg)
+  {
+    MsmPlan p;
+    p.bits = (cfg.bitsize > 0 && cfg.bitsize < scalar_bits) ? cfg.bitsize : scalar_bits;
+    p.pf = std::max(1, cfg.precompute_factor);
+    int c = cfg.c;
+    // A precomputed base table fixes the doubling shift c * wpf, so msm_precompute_bases(nof_bases) and msm(msm_size)
+    // must agree on c. The reference derives it from the size on both sides (cpu_msm.hpp:466 vs :207), which only
+    // agrees when nof_bases == msm_size; here an unspecified c is size-independent whenever precompute_factor > 1,
+    // so shared and per-MSM base tables of any batch shape work (pass config.c on both calls to tune it).
+    if (c <= 0 && p.pf > 1) c = 16;
+    if (c <= 0) {
+      // minimise  (#mixed adds) + (bucket-reduction work). Fitted to a measured sweep (profiles/r03_msm_csweep.txt):
+      //  * a window size whose TOP window holds only 1-3 scalar bits is never chosen: that window has a handful of
+      //    buckets with n/4 points each, i.e. one more window of mixed adds for nothing plus the whole overflow machinery
+      //    (c = 14, 18, 21 for 254-bit scalars: 2^20 4.7 / 4.6 ms against 2.9 ms at c = 17; 2^26 98 against 71 ms);
+      //  * n >= 2^16: with fewer than ~2.5 waves of bucket threads per SIMD the accumulation runs below its issue rate,
+      //    which favours MORE buckets than the add count alone suggests, and a bucket costs 2 (below 2^22) to 4 add-
+      //    equivalents in the reduction (2^16: c 13 -> 15, 2.10 -> 1.74 ms; 2^18: 2.67 -> 2.15; 2^20: 15 -> 17, 3.4 -> 2.9);
+      //  * below 2^16 the latency of the reduction and of the window combine dominates: per bucket: ~2 complete adds
+      //    (14 muls each) vs 10 muls per mixed add, weighted 8 for their poor parallelism (round 1's fit, still the best).
+      // (a batch runs as ONE launch sequence with batch x the bucket threads and batch x the reduction work: round 1's
+      //  weights stay the better fit there -- 16 x 2^16: 3.5 ms against 4.5 ms with the single-MSM fit)
+      const bool mid = n >= (1 << 16) && std::max(1, cfg.batch_size) == 1;
+      double best = 1e300;
+      for (int cc = 2; cc <= 21; cc++) {
+        const int w = (p.bits + 1 + cc - 1) / cc;
+        const int wpf = (w + p.pf - 1) / p.pf;
+        if (w > 1 && p.bits + 1 - cc * (w - 1) <= 3 && p.bits > 8) continue; // tiny top window
+        // batches of small MSMs: the one-level sort (c <= 11) beats the two-level one by far while the windows are small
+        // (128 x 2^17: c = 11 29.2 ms, c = 12 / 13 36.4 / 34.8; 1024 x 2^12: c = 12 77 ms against 16) -- profiles/r03_notes.md 11
+        if (cfg.batch_size > 1 && n <= (1 << 17) && cc > 11) continue;
+        const double nbk = (double)wpf * (double)(1u << (cc - 1));
+        double cost;
+        if (mid) {
+          const double occupancy = std::max(1.0, 2.5 * 65536.0 / nbk); // bucket threads per SIMD lane slot
+          cost = (double)w * n * occupancy + (n >= (1 << 22) ? 4.0 : 2.0) * nbk; // (below 2^22 the reduction is latency-, not throughput-bound)
+        } else {
+          cost = (double)w * n + 8.0 * nbk;
+        }
+        if (cost < best) {
+          best = cost;
+          c = cc;
+        }
+      }
+    }
+    c = std::min(21, std::max(2, c)); // two-level sort: 2^hb partitions (pass A) x 2^lb bins (pass B), hb, lb <= 10
+    p.c = c;
+    p.nwin = (p.bits + 1 + c - 1) / c;
+    p.wpf = (p.nwin + p.pf - 1) / p.pf;
+    p.nb = 1u << (c - 1);
+    {
+      const double avg = (double)n * p.pf * ((double)p.nwin / p.wpf) / (double)p.nb; // points per bucket
+      uint32_t sgm = 64;
+      while ((double)sgm < 2.0 * avg)
+        sgm <<= 1;
+      p.seg = sgm;
+    }
+    return p;
+  }
+
 
 } // namespace icicle_hip

@@ -90,3 +90,29 @@ extern "C" int split_shape_check(void)
     }
   return 0;
 }
+
+// the window plan msm() picks: window size inside the sort's range, never a top window of 1-3 scalar bits, batches of
+// small MSMs on the one-level sort, a caller-set c honoured, precompute tables on the size-independent c
+extern "C" int msm_plan_check(void)
+{
+  for (int bits : {254, 255, 64, 128})
+    for (int logn = 0; logn <= 28; logn++)
+      for (int batch : {1, 16, 1024})
+        for (int pf : {1, 4}) {
+          icicle_msm_config_t cfg{};
+          cfg.batch_size = batch;
+          cfg.precompute_factor = pf;
+          const int n = 1 << logn;
+          const MsmPlan p = make_plan(n, bits, cfg);
+          const int tag = ((bits * 100 + logn) * 10 + (batch > 1)) * 10 + pf;
+          if (p.c < 2 || p.c > 21) return tag * 10 + 1;
+          if (p.nwin != (p.bits + 1 + p.c - 1) / p.c || p.wpf != (p.nwin + pf - 1) / pf || p.nb != (1u << (p.c - 1))) return tag * 10 + 2;
+          if (pf == 1 && p.nwin > 1 && p.bits > 8 && p.bits + 1 - p.c * (p.nwin - 1) <= 3) return tag * 10 + 3; // tiny top window
+          if (pf == 1 && batch > 1 && logn <= 17 && p.c > 11) return tag * 10 + 4;
+          if (pf > 1 && p.c != 16) return tag * 10 + 5;
+          cfg.c = 13;
+          if (make_plan(n, bits, cfg).c != 13) return tag * 10 + 6;
+          if (p.seg < 64 || (p.seg & (p.seg - 1)) != 0) return tag * 10 + 7;
+        }
+  return 0;
+}

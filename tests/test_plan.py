@@ -18,3 +18,4 @@ def test_ntt_plan_covers_every_slot_once():
     assert lib.plan_check(22) == 0
     assert lib.msm_groups_check() == 0  # window groups of the pipelined MSM schedule (msm_plan.h)
     assert lib.split_shape_check() == 0  # shapes of a transform split over device slots (ntt_plan.h)
+    assert lib.msm_plan_check() == 0  # the window plan of msm() (msm_plan.h make_plan)
