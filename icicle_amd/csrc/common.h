@@ -9,6 +9,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <variant>
 #include <vector>
@@ -199,6 +200,28 @@ namespace icicle_hip {
   // to the record that was current when it was issued; re-recording later is harmless).
   hipEvent_t ring_event();
   void ring_events_release(); // a short-lived worker thread gives its events back before it ends (its streams are idle then)
+
+  // ---- bases kept on the devices between calls (MSMConfig.ext "hip_bases_resident", msm_multi.hpp) ----
+  struct ResidentKey {
+    const void* bases;
+    size_t row_bytes_total; // bytes of one row of the caller's base array (n * pf * point bytes)
+    int rows, G, g, device, slot;
+    bool operator<(const ResidentKey& o) const
+    {
+      return std::tie(bases, row_bytes_total, rows, G, g, device, slot) < std::tie(o.bases, o.row_bytes_total, o.rows, o.G, o.g, o.device, o.slot);
+    }
+  };
+  struct ResidentShard {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ready = nullptr; // recorded behind the copy that filled the shard
+  };
+  std::mutex& resident_mtx();
+  std::map<ResidentKey, ResidentShard>& resident_map();
+  // frees the cached shards of `bases` (nullptr: of every pointer) on every device; returns the bytes given back.
+  // Also called when the caller frees a device allocation through icicle_free / icicle_free_async: copies made for a
+  // pointer that is gone must not be served to whatever is allocated at that address next.
+  size_t resident_release(const void* bases);
 
   // ---- host-thread rendezvous of the multi-device entry points (msm_multi.hpp, ntt_split.hpp) ----
   // Rendezvous of the per-device host threads in front of a collective: a thread that failed earlier (allocation,

@@ -47,57 +47,6 @@ namespace icicle_hip {
     *hi = *lo + base + (g < rem ? 1 : 0);
   }
 
-  // ---- bases kept on the devices between calls ("hip_bases_resident") ----
-  struct ResidentKey {
-    const void* bases;
-    size_t row_bytes_total; // bytes of one row of the caller's base array (n * pf * point bytes)
-    int rows, G, g, device, slot;
-    bool operator<(const ResidentKey& o) const
-    {
-      return std::tie(bases, row_bytes_total, rows, G, g, device, slot) < std::tie(o.bases, o.row_bytes_total, o.rows, o.G, o.g, o.device, o.slot);
-    }
-  };
-  struct ResidentShard {
-    void* ptr = nullptr;
-    size_t bytes = 0;
-    hipEvent_t ready = nullptr; // recorded behind the copy that filled the shard
-  };
-  inline std::mutex& resident_mtx()
-  {
-    static std::mutex m;
-    return m;
-  }
-  inline std::map<ResidentKey, ResidentShard>& resident_map()
-  {
-    static std::map<ResidentKey, ResidentShard> m;
-    return m;
-  }
-  // frees the cached shards of `bases` (nullptr: of every pointer) on every device; returns the bytes given back
-  inline size_t resident_release(const void* bases)
-  {
-    std::lock_guard<std::mutex> g(resident_mtx());
-    auto& m = resident_map();
-    size_t freed = 0;
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    for (auto it = m.begin(); it != m.end();) {
-      if (bases && it->first.bases != bases) {
-        ++it;
-        continue;
-      }
-      (void)hipSetDevice(it->first.device);
-      if (it->second.ready) {
-        (void)hipEventSynchronize(it->second.ready);
-        (void)hipEventDestroy(it->second.ready);
-      }
-      (void)hipFree(it->second.ptr);
-      freed += it->second.bytes;
-      it = m.erase(it);
-    }
-    (void)hipSetDevice(cur);
-    return freed;
-  }
-
   // E2 hook of one device slot: sums the bucket arrays of its logical shards, then (last shard) exchanges bucket
   // slices with the peers and leaves this device's slice, summed over all devices, in the caller's bucket array.
   template <class C>

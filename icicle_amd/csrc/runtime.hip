@@ -350,6 +350,43 @@ namespace icicle_hip {
     t_event_rings.clear();
   }
 
+  // ---- resident base shards ("hip_bases_resident") -----------------------------------------------
+  std::mutex& resident_mtx()
+  {
+    static std::mutex m;
+    return m;
+  }
+  std::map<ResidentKey, ResidentShard>& resident_map()
+  {
+    static std::map<ResidentKey, ResidentShard> m;
+    return m;
+  }
+  size_t resident_release(const void* bases)
+  {
+    std::lock_guard<std::mutex> g(resident_mtx());
+    auto& m = resident_map();
+    if (m.empty()) return 0;
+    size_t freed = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto it = m.begin(); it != m.end();) {
+      if (bases && it->first.bases != bases) {
+        ++it;
+        continue;
+      }
+      (void)hipSetDevice(it->first.device);
+      if (it->second.ready) {
+        (void)hipEventSynchronize(it->second.ready);
+        (void)hipEventDestroy(it->second.ready);
+      }
+      (void)hipFree(it->second.ptr);
+      freed += it->second.bytes;
+      it = m.erase(it);
+    }
+    (void)hipSetDevice(cur);
+    return freed;
+  }
+
   MultiStats& multi_stats()
   {
     static MultiStats s;
@@ -577,6 +614,7 @@ icicle_error_t icicle_free(void* ptr)
 {
   auto a = track_identify(ptr);
   if (!a) return ICICLE_INVALID_DEVICE; // "trying to release host memory" (src/runtime.cpp:74-77)
+  (void)resident_release(ptr); // per-device copies of bases that lived here ("hip_bases_resident") go with the allocation
   // memory of a non-active device: switch, release, switch back (src/runtime.cpp:87-92)
   const int cur = current_device_id();
   HIP_TRY(hipSetDevice(a->device), ICICLE_INVALID_DEVICE);
@@ -599,6 +637,7 @@ icicle_error_t icicle_free_async(void* ptr, icicleStreamHandle stream)
   if (!a) return ICICLE_INVALID_DEVICE;
   if (a->device != current_device_id()) return ICICLE_INVALID_DEVICE; // src/runtime.cpp:107-113
   ICICLE_TRY(bind_current_device());
+  (void)resident_release(ptr);
   hipEvent_t ev;
   HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming), ICICLE_DEALLOCATION_FAILED);
   HIP_TRY(hipEventRecord(ev, (hipStream_t)stream), ICICLE_DEALLOCATION_FAILED);

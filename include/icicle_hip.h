@@ -311,7 +311,8 @@ icicle_error_t icicle_hip_workspace_bytes(size_t* bytes);
  *   "hip_bases_resident"       bool  msm: keep the per-device copies of the base shards between calls (the caller
  *                                    promises the bases at that pointer do not change); released by the function below
  *   "hip_force_rccl"           bool  msm: take the RCCL exchange even with one device (test hook)
- * icicle_hip_msm_release_resident_bases(bases) frees the resident copies made for `bases` (NULL: for every pointer). */
+ * icicle_hip_msm_release_resident_bases(bases) frees the resident copies made for `bases` (NULL: for every pointer);
+ * icicle_free / icicle_free_async of a device allocation release the copies made for it as well. */
 icicle_error_t icicle_hip_msm_release_resident_bases(const void* bases);
 /* Counters of what the multi-device / pipelined paths moved since the last reset, out[5] = { base bytes staged to a
  * device, scalar bytes staged, bucket bytes sent by the bucket exchange, resident-base hits (shards NOT staged again),

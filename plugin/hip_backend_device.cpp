@@ -112,6 +112,15 @@ public:
     }
     return tr(e, eIcicleError::ALLOCATION_FAILED);
   }
+  // per-device copies of base shards made under MSMConfig.ext "hip_bases_resident" for an allocation that is being freed
+  static void release_resident_bases(void* ptr)
+  {
+    void* h = dlopen("libicicle_hip.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) return;
+    auto rel = (int (*)(const void*))dlsym(h, "icicle_hip_msm_release_resident_bases");
+    if (rel && ptr) (void)rel(ptr);
+    dlclose(h);
+  }
   // libicicle_hip.so is loaded by the curve / field parts of the plugin, not by this one: look it up if it is there
   static void release_backend_workspace()
   {
@@ -130,6 +139,7 @@ public:
   eIcicleError free_memory(void* ptr) const override
   {
     reap(false);
+    release_resident_bases(ptr);
     return tr(hipFree(ptr), eIcicleError::DEALLOCATION_FAILED);
   }
   eIcicleError free_memory_async(void* ptr, icicleStreamHandle stream) const override
@@ -139,6 +149,7 @@ public:
       (void)hipGetLastError();
       return eIcicleError::DEALLOCATION_FAILED;
     }
+    release_resident_bases(ptr);
     {
       std::lock_guard<std::mutex> g(mtx());
       parked().push_back({ptr, ev});

@@ -436,3 +436,33 @@ def test_two_host_threads_call_the_multi_device_msm_at_once(hip, slots):
     finally:
         for e in exts:
             lib.destroy_config_extension(e)
+
+
+def test_resident_copies_die_with_the_allocation(hip, slots):
+    """ "hip_bases_resident" copies are keyed on the base pointer: when the caller frees that device allocation
+    (icicle_free), the copies must go with it -- the next allocation may get the same address with other points."""
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib, multi_stats
+    from icicle_amd.runtime import DeviceVec
+
+    C, rng, bases, sc = _inputs("bn254", 3001, 5151)
+    refc = ref.RefCurve("bn254")
+    bases2 = np.ascontiguousarray(bases[::-1])
+    slots(4)
+    ext = _ext(hip_num_devices=4, hip_bases_resident=True)
+    try:
+        cfg = hip.MSMConfig.default()
+        cfg.ext = ext
+        d1 = DeviceVec.from_host(bases)
+        got = M.msm("bn254", sc, d1, cfg, msm_size=len(sc))
+        assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(sc, bases)))
+        addr = d1.ptr
+        d1.free()
+        d2 = DeviceVec.from_host(bases2)  # very likely the same address
+        multi_stats(reset=True)
+        got2 = M.msm("bn254", sc, d2, cfg, msm_size=len(sc))
+        st = multi_stats()
+        assert np.array_equal(refc.to_affine(got2), refc.to_affine(refc.msm(sc, bases2))), ("stale resident copy served", d2.ptr == addr)
+        assert st["staged_base_bytes"] > 0 and st["resident_base_hits"] == 0, st
+    finally:
+        lib.destroy_config_extension(ext)
