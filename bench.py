@@ -148,7 +148,11 @@ def inproc_main(args):
 
     G = args.gpus
     have = runtime.get_device_count()
-    if have < G:
+    rehearsal = os.environ.get("ICICLE_BENCH_INPROC_VIRTUAL", "0") == "1"  # this leg's own code on a box with fewer GPUs: virtual slots + loopback collectives
+    if rehearsal:
+        check(lib.icicle_hip_test_set_virtual_devices(G), "virtual devices")
+        check(lib.icicle_hip_test_use_loopback_rccl(True), "loopback")
+    elif have < G:
         print(json.dumps({"error": f"needs {G} devices, {have} visible"}))
         return
     torch.cuda.set_device(0)
@@ -158,6 +162,8 @@ def inproc_main(args):
     n = (1 << args.size_log2) * (1 if strong else G)
     res = {"form": "one process, MSMConfig.ext / NTTConfig.ext hip_num_devices = N (one host thread + stream per GPU inside the call)",
            "n_gpus": G, "scaling": args.scaling}
+    if rehearsal:
+        res["rehearsal"] = f"{G} virtual device slots on {have} GPU(s), loopback collectives: timings mean nothing"
     ext = lib.create_config_extension()
     try:
         lib.config_extension_set_int(ext, b"hip_num_devices", G)

@@ -35,3 +35,21 @@ def test_bench_rank_count_mismatch_is_a_json_error_too():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert "error" in out and "WORLD_SIZE=3" in out["error"]
+
+
+@pytest.mark.gpu
+def test_bench_inprocess_leg_rehearsed_on_virtual_slots():
+    """the single-process leg of `bench.py --gpus N` (ONE msm() / ntt() call with hip_num_devices = N, bases resident) run
+    with 4 virtual device slots + loopback collectives on the one GPU of the test box: the leg's own code, its JSON and
+    its wire-byte accounting (the second call ships scalars only)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ICICLE_BENCH_INPROC_VIRTUAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--inproc-only", "--size-log2", "16", "--ntt-log2", "14", "--ntt-batch", "4"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert "error" not in out, out
+    assert out["n_gpus"] == 4 and out["value"] > 0 and "rehearsal" in out
+    assert out["wire_bytes_per_call"]["bases"] == 0 and out["wire_bytes_per_call"]["scalars"] == 3 * (1 << 16) * 32  # three remote slots
+    assert out["resident_base_hits_per_call"] == 3
+    assert out["ntt"]["roundtrip_ok"] is True
