@@ -273,6 +273,7 @@ namespace icicle_hip {
                       hipMemcpy2DAsync(rs.ptr, row, src, (size_t)n * pf * PW * 4, row, brows, hipMemcpyDefault, cs) != hipSuccess ||
                       hipEventRecord(rs.ready, cs) != hipSuccess) {
                     (void)hipGetLastError();
+                    if (rs.ready) (void)hipEventDestroy(rs.ready);
                     (void)hipFree(rs.ptr);
                     return ICICLE_COPY_FAILED;
                   }

@@ -63,10 +63,10 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
     GateTicket ticket(&gate);
     if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED;
     ICICLE_TRY(icicle_hip_set_device(ds.devs[p]));
-      if (ds.devs[p] != home) {
-        (void)hipDeviceEnablePeerAccess(home, 0);
-        (void)hipGetLastError();
-      }
+    if (ds.devs[p] != home) {
+      (void)hipDeviceEnablePeerAccess(home, 0);
+      (void)hipGetLastError();
+    }
     hipStream_t st = side_stream(200 + p); // long-lived per (device, slot): see msm_multi.hpp
     if (!st) return ICICLE_STREAM_CREATION_FAILED;
     icicle_error_t rc = [&]() -> icicle_error_t {

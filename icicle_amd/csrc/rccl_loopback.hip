@@ -179,7 +179,10 @@ namespace icicle_hip {
       LbComm* c = t_pending[0].comm;
       hipStream_t st = t_pending[0].st;
       for (auto& p : t_pending)
-        if (p.comm != c || p.st != st) return 4; // one communicator and one stream per group is all this stand-in models
+        if (p.comm != c || p.st != st) { // one communicator and one stream per group is all this stand-in models
+          t_pending.clear();
+          return 4;
+        }
       LbWorld& w = *c->w;
       const int r = c->rank;
       std::vector<int> readers;
