@@ -156,21 +156,24 @@ RUNTIME_SYMBOLS = [
     "config_extension_set_bool", "config_extension_get_int", "config_extension_get_bool",
     "clone_config_extension",
 ]
-CURVES = ["bn254", "bls12_381"]
+CURVES = ["bn254", "bls12_381", "bls12_377", "grumpkin"]  # G1 MSM
+G2_CURVES = ["bn254", "bls12_381", "bls12_377"]
+ECNTT_CURVES = ["bn254", "bls12_381", "bls12_377"]
 NTT_FIELDS = ["babybear", "koalabear"]
-SCALAR_NTT_FIELDS = ["bn254", "bls12_381"]  # NTT over the curve's scalar field, 8-word elements
+SCALAR_NTT_FIELDS = ["bn254", "bls12_381", "bls12_377", "stark252"]  # NTT over a 256-bit field, 8-word elements
+BIG_VEC_FIELDS = SCALAR_NTT_FIELDS + ["grumpkin"]  # element-wise ops / Montgomery conversion over 8-word scalars
 API_SYMBOLS = (
     [f"{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
-    + [f"{c}_g2_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
-    + [f"icicle_hip_{c}_g2_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
+    + [f"{c}_g2_{s}" for c in G2_CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
+    + [f"icicle_hip_{c}_g2_{s}" for c in G2_CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
                                                "get_root_of_unity_from_domain", "extension_ntt", "hip_twiddle_rows")]
     + [f"{f}_{s}" for f in SCALAR_NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity",
                                                       "get_root_of_unity_from_domain")]
     + [f"icicle_hip_{f}_{s}" for f in SCALAR_NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain",
                                                                  "get_root_of_unity_from_domain")]
-    + [f"{pre}{c}_ecntt" for pre in ("", "icicle_hip_") for c in CURVES]
-    + [f"{pre}{f}_{op}" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + SCALAR_NTT_FIELDS
+    + [f"{pre}{c}_ecntt" for pre in ("", "icicle_hip_") for c in ECNTT_CURVES]
+    + [f"{pre}{f}_{op}" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + BIG_VEC_FIELDS
        for op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "scalar_add_vec", "scalar_sub_vec", "bit_reverse")]
     + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
        "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_selftest_inplace_products", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
@@ -181,10 +184,10 @@ API_SYMBOLS = (
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
                                                           "get_root_of_unity_from_domain")]
-    + [f"{pre}{f}_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in CURVES + NTT_FIELDS]
+    + [f"{pre}{f}_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in BIG_VEC_FIELDS + NTT_FIELDS]
     + [f"{pre}{f}_extension_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in NTT_FIELDS]
     + [f"{pre}{c}_{k}_convert_montgomery" for pre in ("", "icicle_hip_") for c in CURVES for k in ("affine", "projective")]
-    + [f"{pre}{c}_g2_{k}_convert_montgomery" for pre in ("", "icicle_hip_") for c in CURVES for k in ("affine", "projective")]
+    + [f"{pre}{c}_g2_{k}_convert_montgomery" for pre in ("", "icicle_hip_") for c in G2_CURVES for k in ("affine", "projective")]
 )
 
 if not os.path.exists(LIB_PATH):
@@ -228,6 +231,7 @@ for _c in CURVES:
     getattr(lib, f"{_c}_msm_precompute_bases").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.c_void_p]
     getattr(lib, f"{_c}_hip_projective_sum").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     getattr(lib, f"{_c}_hip_generate_affine_points").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_bool, ctypes.c_void_p]
+for _c in G2_CURVES:
     getattr(lib, f"{_c}_g2_msm").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.c_void_p]
     getattr(lib, f"{_c}_g2_msm_precompute_bases").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(MSMConfig), ctypes.c_void_p]
     getattr(lib, f"{_c}_g2_hip_projective_sum").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -239,13 +243,14 @@ for _f in NTT_FIELDS:
     getattr(lib, f"{_f}_hip_twiddle_rows").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_bool, ctypes.c_void_p]
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
-for _f in SCALAR_NTT_FIELDS:
+for _f in ECNTT_CURVES:
     getattr(lib, f"{_f}_ecntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU256), ctypes.c_void_p]
+for _f in SCALAR_NTT_FIELDS:
     getattr(lib, f"{_f}_ntt").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU256), ctypes.c_void_p]
     getattr(lib, f"{_f}_ntt_init_domain").argtypes = [ctypes.c_void_p, ctypes.POINTER(NTTInitDomainConfig)]
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
     getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
-for _f in NTT_FIELDS + SCALAR_NTT_FIELDS:
+for _f in NTT_FIELDS + BIG_VEC_FIELDS:
     for _op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "scalar_add_vec", "scalar_sub_vec"):
         getattr(lib, f"{_f}_{_op}").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
     getattr(lib, f"{_f}_bit_reverse").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]

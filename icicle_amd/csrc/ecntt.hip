@@ -338,3 +338,4 @@ using namespace icicle_hip;
 
 DEFINE_ECNTT(bn254)
 DEFINE_ECNTT(bls12_381)
+DEFINE_ECNTT(bls12_377)

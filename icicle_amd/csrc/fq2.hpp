@@ -1,5 +1,5 @@
-// Quadratic extension Fq2 = Fq[u]/(u^2 + 1) over bigfield.hpp, for the G2 groups of BN254 and
-// BLS12-381 (both use the non-residue -1: icicle/include/icicle/fields/snark_fields/bn254_base.h,
+// Quadratic extension Fq2 = Fq[u]/(u^2 + NONRES) over bigfield.hpp, for the G2 groups. BN254 and
+// BLS12-381 both use the non-residue -1 (icicle/include/icicle/fields/snark_fields/bn254_base.h,
 // bls12_381_base.h `nonresidue = 1, nonresidue_is_negative = true`; element layout {c0 = real,
 // c1 = imaginary}, icicle/include/icicle/fields/complex_extension.h).
 //
@@ -15,6 +15,11 @@
 // ends every product with one conditional subtraction of 2p per component (~6 % of a product), and
 // squares with c0 = a0*a0 + (16p - a1)*a1 so that the raw value stays below 4p. With that, Fq2
 // products have the same bound class as Fq products and ec.hpp needs no G2-specific constants.
+//
+// BLS12-377 extends with u^2 = -5 (bls12_377_base.h:1560-1564 `nonresidue = 5`): PR::NONRES = 5 takes the real part
+// as a0*b0 - 5*(a1*b1) from two separately reduced products (the factor cannot ride inside an interleaved reduction
+// without leaving the operand bounds), brought back below p by four conditional subtractions; the imaginary part is
+// the same mul_add as above. Its base field has R/p = 2^29, so every product comes out below (1 + 2^-20) p.
 #pragma once
 #include "bigfield.hpp"
 
@@ -34,6 +39,21 @@ namespace icicle_hip {
     static constexpr int N32 = 2 * B::N32;   // packed words per element
     static constexpr int BN32 = B::N32;
     static constexpr bool TIGHT = B::r_over_p() < 1024.0;
+    static constexpr int NR = PR::NONRES; // u^2 = -NR
+    static_assert(NR == 1 || (NR == 5 && !TIGHT), "Fq2: non-residues other than 1 need the slack of a wide base field");
+
+    // v0 - NR*v1 for two product outputs (NR = 5), brought below p: the formulas of ec.hpp give the products of a
+    // field with slack (not TIGHT) a bound of ~1
+    static HD bfe sub_nr(const bfe& v0, const bfe& v1)
+    {
+      const bfe v4 = B::dbl(B::dbl(v1));
+      bfe r = B::template sub<8>(v0, B::add(v4, v1));
+      B::template cond_sub<8>(r);
+      B::template cond_sub<4>(r);
+      B::template cond_sub<2>(r);
+      B::template cond_sub<1>(r);
+      return r;
+    }
 
     static HD void tighten(bfe& x)
     {
@@ -84,7 +104,10 @@ namespace icicle_hip {
     static HD fe mul(const fe& a, const fe& b)
     {
       fe r;
-      r.c0 = B::mul_add(a.c0, b.c0, B::template neg<16>(a.c1), b.c1);
+      if constexpr (NR == 1)
+        r.c0 = B::mul_add(a.c0, b.c0, B::template neg<16>(a.c1), b.c1);
+      else
+        r.c0 = sub_nr(B::mul(a.c0, b.c0), B::mul(a.c1, b.c1));
       r.c1 = B::mul_add(a.c0, b.c1, a.c1, b.c0);
       tighten(r.c0);
       tighten(r.c1);
@@ -95,7 +118,9 @@ namespace icicle_hip {
     static HD fe sqr(const fe& a)
     {
       fe r;
-      if constexpr (TIGHT)
+      if constexpr (NR != 1)
+        r.c0 = sub_nr(B::sqr(a.c0), B::sqr(a.c1));
+      else if constexpr (TIGHT)
         r.c0 = B::mul_add(a.c0, a.c0, B::template neg<16>(a.c1), a.c1);
       else
         r.c0 = B::mul(B::add(a.c0, a.c1), B::template sub<16>(a.c0, a.c1));
@@ -159,10 +184,12 @@ namespace icicle_hip {
     static HD bool maybe_zero_mulout(const fe& a) { return B::maybe_zero_mulout(a.c0) & B::maybe_zero_mulout(a.c1); }
     static HD bool eq(const fe& a, const fe& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
 
-    // (a0 + a1 u)^-1 = (a0 - a1 u) / (a0^2 + a1^2)
+    // (a0 + a1 u)^-1 = (a0 - a1 u) / (a0^2 + NR a1^2)
     static HD fe inv(const fe& a)
     {
-      const bfe nrm = B::reduce(B::add(B::sqr(a.c0), B::sqr(a.c1)));
+      bfe n1 = B::sqr(a.c1);
+      if constexpr (NR == 5) n1 = B::add(B::dbl(B::dbl(n1)), n1);
+      const bfe nrm = B::reduce(B::add(B::sqr(a.c0), n1));
       const bfe ni = B::inv(nrm);
       fe r;
       r.c0 = B::mul(a.c0, ni);

@@ -805,7 +805,7 @@ namespace icicle_hip {
     using S = SmallField<PR>;
     if (!rou || max_size == 0) return ICICLE_INVALID_ARGUMENT;
     uint32_t logn = 0;
-    while (((uint64_t)1 << logn) < max_size)
+    while (logn < 64 && ((uint64_t)1 << logn) < max_size)
       logn++; // ceil(log2(max_size)), src/ntt.cpp:57
     if ((int)logn > PR::TWO_ADICITY) return ICICLE_INVALID_ARGUMENT;
     uint32_t x = S::to_mont(PR::ROU);

@@ -241,7 +241,7 @@ namespace icicle_hip {
     using F = FieldOps<PR>;
     if (!rou || max_size == 0) return ICICLE_INVALID_ARGUMENT;
     uint32_t logn = 0;
-    while (((uint64_t)1 << logn) < max_size)
+    while (logn < 64 && ((uint64_t)1 << logn) < max_size)
       logn++; // ceil(log2(max_size)), src/ntt.cpp:57
     if ((int)logn > PR::TWO_ADICITY) return ICICLE_INVALID_ARGUMENT;
     typename F::fe x = F::from_canonical(PR::ROU32);
@@ -461,3 +461,5 @@ using namespace icicle_hip;
 
 DEFINE_NTT_U256(bn254, bn254_fr_params)
 DEFINE_NTT_U256(bls12_381, bls12_381_fr_params)
+DEFINE_NTT_U256(bls12_377, bls12_377_fr_params)
+DEFINE_NTT_U256(stark252, stark252_fr_params) // reference FIELD_ID 1002: a 252-bit field with an NTT and no curve

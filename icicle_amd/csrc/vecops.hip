@@ -134,9 +134,15 @@ using namespace icicle_hip;
 
 DEFINE_SCALAR_CONVERT_BIG(bn254, bn254_fr_params)
 DEFINE_SCALAR_CONVERT_BIG(bls12_381, bls12_381_fr_params)
+DEFINE_SCALAR_CONVERT_BIG(bls12_377, bls12_377_fr_params)
+DEFINE_SCALAR_CONVERT_BIG(grumpkin, bn254_fq_params) // Grumpkin's scalar field is BN254's base field
+DEFINE_SCALAR_CONVERT_BIG(stark252, stark252_fr_params)
 DEFINE_SCALAR_CONVERT_SMALL(babybear, babybear_params)
 DEFINE_SCALAR_CONVERT_SMALL(koalabear, koalabear_params)
 DEFINE_POINT_CONVERT(bn254, bn254_fq_params)
 DEFINE_POINT_CONVERT(bls12_381, bls12_381_fq_params)
+DEFINE_POINT_CONVERT(bls12_377, bls12_377_fq_params)
+DEFINE_POINT_CONVERT(grumpkin, bn254_fr_params)
 DEFINE_G2_POINT_CONVERT(bn254, bn254_fq_params)
 DEFINE_G2_POINT_CONVERT(bls12_381, bls12_381_fq_params)
+DEFINE_G2_POINT_CONVERT(bls12_377, bls12_377_fq_params)

@@ -212,3 +212,6 @@ DEFINE_VEC_ARITH(babybear, SmallElem<babybear_params>, 1)
 DEFINE_VEC_ARITH(koalabear, SmallElem<koalabear_params>, 1)
 DEFINE_VEC_ARITH(bn254, BigElem<bn254_fr_params>, 8)
 DEFINE_VEC_ARITH(bls12_381, BigElem<bls12_381_fr_params>, 8)
+DEFINE_VEC_ARITH(bls12_377, BigElem<bls12_377_fr_params>, 8)
+DEFINE_VEC_ARITH(grumpkin, BigElem<bn254_fq_params>, 8)
+DEFINE_VEC_ARITH(stark252, BigElem<stark252_fr_params>, 8)

@@ -1,8 +1,9 @@
 """msm() / precompute_bases(): mirror of wrappers/rust/icicle-core/src/msm/mod.rs:90-207.
 
 Arrays are numpy uint32 in the reference's memory layout: scalars [batch*N, 8]; affine bases
-[M, 2*L] (x then y, identity = all zeros); projective results [batch, 3*L] (L = 8 bn254, 12 bls12_381).
-With g2=True the group is G2: coordinates are Fq2 elements {c0, c1}, so L doubles (16 / 24).
+[M, 2*L] (x then y, identity = all zeros); projective results [batch, 3*L] (L = 8 bn254 / grumpkin, 12 bls12_381 /
+bls12_377).
+With g2=True the group is G2 (not grumpkin): coordinates are Fq2 elements {c0, c1}, so L doubles (16 / 24).
 Device-resident operands are passed as runtime.DeviceVec or raw integer device pointers.
 """
 import ctypes
@@ -10,7 +11,7 @@ import numpy as np
 from ._lib import lib, check, MSMConfig
 from .runtime import DeviceVec
 
-LIMBS = {"bn254": 8, "bls12_381": 12}
+LIMBS = {"bn254": 8, "bls12_381": 12, "bls12_377": 12, "grumpkin": 8}
 SCALAR_LIMBS = 8
 
 

@@ -5,6 +5,9 @@ import numpy as np
 from ._lib import lib, check, VecOpsConfig
 from .runtime import DeviceVec
 
+# u32 words per scalar (a curve name stands for its scalar field) and per base-field coordinate of a point
+_WORDS = {"bn254": 8, "bls12_381": 8, "bls12_377": 8, "grumpkin": 8, "stark252": 8, "babybear": 1, "koalabear": 1}
+_POINT_LIMBS = {"bn254": 8, "bls12_381": 12, "bls12_377": 12, "grumpkin": 8}
 
 def _ptr(x):
     if isinstance(x, DeviceVec):
@@ -28,8 +31,8 @@ def _run(symbol, inp, count, to_montgomery, cfg, out):
 
 
 def scalar_convert_montgomery(field: str, inp, to_montgomery: bool, cfg=None, out=None, size=None, extension=False):
-    """field in {bn254, bls12_381, babybear, koalabear}; `size` = elements per batch entry"""
-    words = {"bn254": 8, "bls12_381": 8, "babybear": 1, "koalabear": 1}[field] * (4 if extension else 1)
+    """field in _WORDS (a curve name means its scalar field); `size` = elements per batch entry"""
+    words = _WORDS[field] * (4 if extension else 1)
     if size is None:
         size = inp.size // words // max(1, (cfg.batch_size if cfg else 1))
     sym = f"{field}_extension_scalar_convert_montgomery" if extension else f"{field}_scalar_convert_montgomery"
@@ -37,16 +40,13 @@ def scalar_convert_montgomery(field: str, inp, to_montgomery: bool, cfg=None, ou
 
 
 def affine_convert_montgomery(curve: str, inp, to_montgomery: bool, cfg=None, out=None, n=None):
-    L = {"bn254": 8, "bls12_381": 12}[curve]
+    L = _POINT_LIMBS[curve]
     return _run(f"{curve}_affine_convert_montgomery", inp, n if n is not None else inp.size // (2 * L), to_montgomery, cfg, out)
 
 
 def projective_convert_montgomery(curve: str, inp, to_montgomery: bool, cfg=None, out=None, n=None):
-    L = {"bn254": 8, "bls12_381": 12}[curve]
+    L = _POINT_LIMBS[curve]
     return _run(f"{curve}_projective_convert_montgomery", inp, n if n is not None else inp.size // (3 * L), to_montgomery, cfg, out)
-
-
-_WORDS = {"bn254": 8, "bls12_381": 8, "babybear": 1, "koalabear": 1}
 
 
 def _vec2(op: str, field: str, a, b, size, cfg, out):

@@ -375,6 +375,47 @@ icicle_error_t icicle_hip_bn254_g2_projective_convert_montgomery(const void* inp
 icicle_error_t icicle_hip_bls12_381_g2_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 icicle_error_t icicle_hip_bls12_381_g2_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 
+/* ======================================================================================
+ * Further curves / fields of the reference that have an MSM or an NTT (icicle/cmake/features.cmake:6,17,19), with the
+ * signatures and layouts of the bn254 / bls12_381 symbols above:
+ *   bls12_377  MSM on G1 (L = 12) and on G2 over Fq2 = Fq[u]/(u^2 + 5), NTT over its 253-bit scalar field, ECNTT,
+ *              Montgomery conversion, element-wise vector ops     (curves/params/bls12_377.h)
+ *   grumpkin   MSM on G1 (L = 8; base field = BN254's scalar field, scalars = BN254's base field), Montgomery
+ *              conversion, vector ops; the reference gives it no NTT  (curves/params/grumpkin.h)
+ *   stark252   NTT + Montgomery conversion + vector ops over the 252-bit Stark field 2^251 + 17*2^192 + 1
+ *              (fields/stark_fields/stark252.h; no curve)
+ * bw6_761 (761-bit base field), goldilocks and m31 are not built.
+ * ====================================================================================== */
+#define ICICLE_HIP_DECLARE_MSM(S)                                                                                      \
+  icicle_error_t S##_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results); \
+  icicle_error_t S##_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases); \
+  icicle_error_t icicle_hip_##S##_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results); \
+  icicle_error_t icicle_hip_##S##_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases); \
+  icicle_error_t S##_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream); \
+  icicle_error_t S##_hip_projective_sum(const void* points, int n, void* out, icicleStreamHandle stream);              \
+  icicle_error_t S##_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output); \
+  icicle_error_t S##_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output); \
+  icicle_error_t icicle_hip_##S##_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output); \
+  icicle_error_t icicle_hip_##S##_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
+ICICLE_HIP_DECLARE_MSM(bls12_377)
+ICICLE_HIP_DECLARE_MSM(bls12_377_g2)
+ICICLE_HIP_DECLARE_MSM(grumpkin)
+ICICLE_HIP_DECLARE_NTT_U256(bls12_377)
+ICICLE_HIP_DECLARE_NTT_U256(stark252)
+ICICLE_HIP_DECLARE_NTT_U256_ALIASES(bls12_377)
+ICICLE_HIP_DECLARE_NTT_U256_ALIASES(stark252)
+icicle_error_t bls12_377_ecntt(const void* input, int size, int dir, const icicle_ntt_config_u256_t* config, void* output);
+icicle_error_t icicle_hip_bls12_377_ecntt(const void* input, int size, int dir, const icicle_ntt_config_u256_t* config, void* output);
+ICICLE_HIP_DECLARE_CONVERT(bls12_377)
+ICICLE_HIP_DECLARE_CONVERT(grumpkin)
+ICICLE_HIP_DECLARE_CONVERT(stark252)
+ICICLE_HIP_DECLARE_CONVERT(icicle_hip_bls12_377)
+ICICLE_HIP_DECLARE_CONVERT(icicle_hip_grumpkin)
+ICICLE_HIP_DECLARE_CONVERT(icicle_hip_stark252)
+ICICLE_HIP_DECLARE_VEC_ARITH(bls12_377)
+ICICLE_HIP_DECLARE_VEC_ARITH(grumpkin)
+ICICLE_HIP_DECLARE_VEC_ARITH(stark252)
+
 #ifdef __cplusplus
 }
 #endif

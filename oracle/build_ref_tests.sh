@@ -4,8 +4,9 @@
 # oracle/shim/gtest (GoogleTest itself is fetched from the network by the reference's CMake). Outputs travel to the
 # GPU box under oracle/_ref/tests/ (git-ignored):
 #   test_device_api                      icicle/tests/test_device_api.cpp
-#   test_curve_api_{bn254,bls12_381}     icicle/tests/test_curve_api.cpp        (-DMSM -DG2_ENABLED -DECNTT, no PAIRING)
-#   test_modarith_{babybear,koalabear,bn254,bls12_381}  icicle/tests/test_mod_arithmetic_api.h via oracle/shim/tests/modarith_main.cpp
+#   test_curve_api_{bn254,bls12_381,bls12_377}  icicle/tests/test_curve_api.cpp  (-DMSM -DG2_ENABLED -DECNTT, no PAIRING)
+#   test_curve_api_grumpkin              the same source with -DMSM only
+#   test_modarith_{babybear,koalabear,bn254,bls12_381,bls12_377,stark252}  icicle/tests/test_mod_arithmetic_api.h via oracle/shim/tests/modarith_main.cpp
 #   example_msm, example_ntt             examples/c++/{msm,ntt}/example.cpp (bn254), run as `example_msm HIP`
 #   example_best_practice_ntt            examples/c++/best-practice-ntt/example.cpp (three streams)
 # Run with ICICLE_BACKEND_INSTALL_DIR=oracle/_ref/backend so that the reference runtime loads the HIP plugin and makes
@@ -25,7 +26,7 @@ RP="-Wl,-rpath,\$ORIGIN/.."
 newer() { [ "$1" -nt "$0" ] && [ "$1" -nt "$HERE/shim/gtest/gtest/gtest.h" ]; }
 
 newer "$OUT/test_device_api" || { echo "[ref-tests] test_device_api"; $CXX $FLAGS "$R/tests/test_device_api.cpp" -L"$REF" -licicle_device $RP -o "$OUT/test_device_api" & }
-for spec in bn254:1 bls12_381:2; do
+for spec in bn254:1 bls12_381:2 bls12_377:3; do
   c=${spec%%:*}; id=${spec##*:}
   newer "$OUT/test_curve_api_$c" || { echo "[ref-tests] test_curve_api_$c"
     $CXX $FLAGS -DCURVE_ID=$id -DFIELD_ID=$id -DCURVE=$c -DFIELD=$c -DICICLE_FFI_PREFIX=$c -DMSM=ON -DNTT=ON -DECNTT=ON -DG2_ENABLED \
@@ -34,6 +35,13 @@ for spec in bn254:1 bls12_381:2; do
     $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$c -DICICLE_FFI_PREFIX=$c -DNTT=ON \
       "$HERE/shim/tests/modarith_main.cpp" -L"$REF" -licicle_field_$c -licicle_device $RP -o "$OUT/test_modarith_$c" & }
 done
+# Grumpkin: an MSM and nothing else (icicle/cmake/features.cmake:19); stark252: a 252-bit field with an NTT
+newer "$OUT/test_curve_api_grumpkin" || { echo "[ref-tests] test_curve_api_grumpkin"
+  $CXX $FLAGS -DCURVE_ID=5 -DFIELD_ID=5 -DCURVE=grumpkin -DFIELD=grumpkin -DICICLE_FFI_PREFIX=grumpkin -DMSM=ON \
+    "$R/tests/test_curve_api.cpp" -L"$REF" -licicle_curve_grumpkin -licicle_field_grumpkin -licicle_device $RP -o "$OUT/test_curve_api_grumpkin" & }
+newer "$OUT/test_modarith_stark252" || { echo "[ref-tests] test_modarith_stark252"
+  $CXX $FLAGS -DFIELD_ID=1002 -DFIELD=stark252 -DICICLE_FFI_PREFIX=stark252 -DNTT=ON \
+    "$HERE/shim/tests/modarith_main.cpp" -L"$REF" -licicle_field_stark252 -licicle_device $RP -o "$OUT/test_modarith_stark252" & }
 for spec in babybear:1001 koalabear:1004; do
   f=${spec%%:*}; id=${spec##*:}
   newer "$OUT/test_modarith_$f" || { echo "[ref-tests] test_modarith_$f"

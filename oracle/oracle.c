@@ -17,7 +17,7 @@
 #include <string.h>
 
 typedef unsigned __int128 u128;
-#define MAXL 6 /* 64-bit limbs: 4 (bn254, 254/255-bit scalars) or 6 (bls12_381 base field) */
+#define MAXL 6 /* 64-bit limbs: 4 (bn254 / grumpkin, 253..255-bit scalars) or 6 (bls12_381 / bls12_377 base field) */
 
 typedef struct {
   int nl;          /* 64-bit limbs */
@@ -30,6 +30,9 @@ static const field_t BN254_FQ = {4, {0x3c208c16d87cfd47ull, 0x97816a916871ca8dul
 static const field_t BN254_FR = {4, {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull}};
 static const field_t BLS_FQ = {6, {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull}};
 static const field_t BLS_FR = {4, {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull}};
+/* bls12_377_base.h:8-9, bls12_377_scalar.h:9-10 */
+static const field_t BLS377_FQ = {6, {0x8508c00000000001ull, 0x170b5d4430000000ull, 0x1ef3622fba094800ull, 0x1a22d9f300f5138full, 0xc63b05c06ca1493bull, 0x01ae3a4617c510eaull}};
+static const field_t BLS377_FR = {4, {0x0a11800000000001ull, 0x59aa76fed0000001ull, 0x60b44d1e5c37b001ull, 0x12ab655e9a2ca556ull}};
 
 typedef struct {
   uint64_t l[MAXL];
@@ -165,10 +168,14 @@ static void fe_store(const field_t* F, uint32_t* w, const fe_t* a)
 typedef struct {
   const field_t* fq;
   const field_t* fr;
-  uint32_t b; /* weierstrass_b: 3 (curves/params/bn254.h:25), 4 (params/bls12_381.h:26) */
+  uint32_t b; /* |weierstrass_b|: 3 (curves/params/bn254.h:25), 4 (params/bls12_381.h:26), 1 (params/bls12_377.h), 17 (params/grumpkin.h) */
+  int b_neg;  /* is_b_neg (params/grumpkin.h: b = -17) */
 } curve_t;
-static const curve_t BN254 = {&BN254_FQ, &BN254_FR, 3};
-static const curve_t BLS12_381 = {&BLS_FQ, &BLS_FR, 4};
+static const curve_t BN254 = {&BN254_FQ, &BN254_FR, 3, 0};
+static const curve_t BLS12_381 = {&BLS_FQ, &BLS_FR, 4, 0};
+static const curve_t BLS12_377 = {&BLS377_FQ, &BLS377_FR, 1, 0};
+/* Grumpkin: base field = BN254's scalar field, scalar field = BN254's base field (fields/snark_fields/grumpkin_{base,scalar}.h) */
+static const curve_t GRUMPKIN = {&BN254_FR, &BN254_FQ, 17, 1};
 
 typedef struct {
   fe_t x, y, z;
@@ -187,6 +194,11 @@ static void mul_b3(const curve_t* C, fe_t* r, const fe_t* t)
 {
   fe_t k;
   fe_set_u32(C->fq, &k, 3 * C->b);
+  if (C->b_neg) { /* field.h mul_weierstrass_b with is_b_neg: negate */
+    fe_t z;
+    memset(&z, 0, sizeof z);
+    fe_sub(C->fq, &k, &z, &k);
+  }
   fe_mul(C->fq, r, t, &k);
 }
 /* Projective + Projective, complete formula (projective.h:101-143; Renes-Costello-Batina Alg. 7, a = 0) */
@@ -264,7 +276,7 @@ static void proj_to_affine(const curve_t* C, aff_t* r, const proj_t* p)
   fe_mul(C->fq, &r->y, &p->y, &zi);
 }
 
-static const curve_t* curve_by_id(int id) { return id == 0 ? &BN254 : id == 1 ? &BLS12_381 : 0; }
+static const curve_t* curve_by_id(int id) { return id == 0 ? &BN254 : id == 1 ? &BLS12_381 : id == 2 ? &BLS12_377 : id == 3 ? &GRUMPKIN : 0; }
 
 /* get_scalar_digit (modular_arithmetic.h:280-290): c bits starting at bit digit_num*c */
 static uint32_t scalar_digit(const uint32_t* w, int nwords, int digit, int c)

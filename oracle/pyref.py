@@ -47,7 +47,29 @@ BLS12_381 = Curve(
     12,
     8,
 )
-CURVES = {"bn254": BN254, "bls12_381": BLS12_381}
+# reference: curves/params/bls12_377.h, fields/snark_fields/bls12_377_{base,scalar}.h
+BLS12_377 = Curve(
+    "bls12_377",
+    0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001,
+    0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001,
+    1,
+    0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF,
+    0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6,
+    12,
+    8,
+)
+# reference: curves/params/grumpkin.h (y^2 = x^3 - 17 over BN254's scalar field; group order = BN254's base modulus)
+GRUMPKIN = Curve(
+    "grumpkin",
+    BN254.r,
+    BN254.q,
+    BN254.r - 17,
+    1,
+    0x0000000000000002CF135E7506A45D632D270D45F1181294833FC48D823F272C,
+    8,
+    8,
+)
+CURVES = {"bn254": BN254, "bls12_381": BLS12_381, "bls12_377": BLS12_377, "grumpkin": GRUMPKIN}
 
 INF = (0, 0)  # the reference's affine identity encoding
 
@@ -115,8 +137,12 @@ def gen_points(c: Curve, n: int, k0: int = 1):
 
 
 # ----------------------------------------------------------------------------------------------
-# G2: the sextic twists over Fq2 = Fq[u]/(u^2+1) (reference: ComplexExtensionField, c0 = real, c1 = imaginary;
-# curves/params/bn254.h:32-53, bls12_381.h G2 block). Elements are (c0, c1) tuples; points ((x0,x1),(y0,y1)).
+# G2: the sextic twists over Fq2 = Fq[u]/(u^2 + nonresidue) (reference: ComplexExtensionField, c0 = real,
+# c1 = imaginary; curves/params/bn254.h:32-53, bls12_381.h / bls12_377.h G2 blocks; nonresidue 1 except BLS12-377's 5,
+# fields/snark_fields/bls12_377_base.h:1560-1564). Elements are (c0, c1) tuples; points ((x0,x1),(y0,y1)).
+_NONRES = {BLS12_377.q: 5}
+
+
 def f2_add(q, a, b):
     return ((a[0] + b[0]) % q, (a[1] + b[1]) % q)
 
@@ -126,11 +152,11 @@ def f2_sub(q, a, b):
 
 
 def f2_mul(q, a, b):
-    return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+    return ((a[0] * b[0] - _NONRES.get(q, 1) * a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
 
 
 def f2_inv(q, a):
-    ni = pow((a[0] * a[0] + a[1] * a[1]) % q, -1, q)
+    ni = pow((a[0] * a[0] + _NONRES.get(q, 1) * a[1] * a[1]) % q, -1, q)
     return (a[0] * ni % q, (-a[1]) * ni % q)
 
 
@@ -169,7 +195,20 @@ BLS12_381_G2 = G2Curve(
         0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE,
     ),
 )
-G2_CURVES = {"bn254": BN254_G2, "bls12_381": BLS12_381_G2}
+BLS12_377_G2 = G2Curve(
+    "bls12_377",
+    BLS12_377,
+    (0, 0x010222F6DB0FD6F343BD03737460C589DC7B4F91CD5FD889129207B63C6BF8000DD39E5C1CCCCCCD1C9ED9999999999A),
+    (
+        0x018480BE71C785FEC89630A2A3841D01C565F071203E50317EA501F557DB6B9B71889F52BB53540274E3E48F7C005196,
+        0x00EA6040E700403170DC5A51B1B140D5532777EE6651CECBE7223ECE0799C9DE5CF89984BFF76FE6B26BFEFA6EA16AFE,
+    ),
+    (
+        0x00690D665D446F7BD960736BCBB2EFB4DE03ED7274B49A58E458C282F832D204F2CF88886D8C7C2EF094094409FD4DDF,
+        0x00F8169FD28355189E549DA3151A70AA61EF11AC3D591BF12463B01ACEE304C24279B83F5E52270BD9A1CDD185EB8F93,
+    ),
+)
+G2_CURVES = {"bn254": BN254_G2, "bls12_381": BLS12_381_G2, "bls12_377": BLS12_377_G2}
 INF2 = ((0, 0), (0, 0))
 
 
@@ -256,7 +295,23 @@ BN254_FR = NttField(
 BLS12_381_FR = NttField(
     "bls12_381", BLS12_381.r, 0x0212D79E5B416B6F0FD56DC8D168D6C0C4024FF270B3E0941B788F500B912F1F, 32
 )
-NTT_FIELDS = {"babybear": BABYBEAR, "koalabear": KOALABEAR, "bn254": BN254_FR, "bls12_381": BLS12_381_FR}
+BLS12_377_FR = NttField(
+    "bls12_377", BLS12_377.r, 0x11D4B7F60CB92CC160C69477D1A8A12F9B506EE363E3F04A476EF4A4EC2A895E, 47
+)
+STARK252 = NttField(
+    "stark252",
+    0x0800000000000011000000000000000000000000000000000000000000000001,
+    0x005282DB87529CFA3F0464519C8B0FA5AD187148E11A61616070024F42F8EF94,
+    192,
+)
+NTT_FIELDS = {
+    "babybear": BABYBEAR,
+    "koalabear": KOALABEAR,
+    "bn254": BN254_FR,
+    "bls12_381": BLS12_381_FR,
+    "bls12_377": BLS12_377_FR,
+    "stark252": STARK252,
+}
 
 
 def omega(f: NttField, logn: int) -> int:

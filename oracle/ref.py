@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(_HERE, "_ref")
 
 
+CURVE_LIMBS = {"bn254": 8, "bls12_381": 12, "bls12_377": 12, "grumpkin": 8}  # u32 words per base-field element
+
+
 def available(name: str = "device") -> bool:
     return os.path.exists(os.path.join(REF_DIR, _libname(name)))
 
@@ -21,7 +24,7 @@ def available(name: str = "device") -> bool:
 def _libname(name):
     if name == "device":
         return "libicicle_device.so"
-    if name in ("bn254", "bls12_381"):
+    if name in CURVE_LIMBS:
         return f"libicicle_curve_{name}.so"
     return f"libicicle_field_{name}.so"
 
@@ -154,7 +157,7 @@ def ref_convert_montgomery(libname: str, symbol: str, arr: np.ndarray, count: in
 
 
 class RefCurve:
-    """bn254 / bls12_381 through the reference's own C ABI, on its "CPU" device.
+    """a curve of CURVE_LIMBS through the reference's own C ABI, on its "CPU" device.
     g2=True selects the <curve>_g2_* entry points (G2_ENABLED build): coordinates are Fq2 = 2 base-field elements."""
 
     def __init__(self, name: str, g2: bool = False):
@@ -164,7 +167,7 @@ class RefCurve:
         self.g2 = g2
         self.sym = f"{name}_g2" if g2 else name
         self.lib = _load(name)
-        self.L = {"bn254": 8, "bls12_381": 12}[name] * (2 if g2 else 1)
+        self.L = CURVE_LIMBS[name] * (2 if g2 else 1)
 
     def msm(self, scalars: np.ndarray, bases: np.ndarray, batch=1, shared=True, precompute_factor=1, c=0, bitsize=0,
             scalars_mont=False, points_mont=False, n_threads=0):
@@ -316,7 +319,7 @@ def _i8(w) -> int:
 
 
 class RefScalarNttField:
-    """NTT over a curve's 256-bit scalar field (bn254 / bls12_381) through the reference's C ABI on "CPU"
+    """NTT over a 256-bit field (a curve's scalar field, or stark252) through the reference's C ABI on "CPU"
     (src/ntt.cpp:11-84 compiled with FIELD = the curve's scalar field). Elements: 8 u32 words."""
 
     def __init__(self, name: str):

@@ -22,13 +22,20 @@ RP="-Wl,-rpath,\$ORIGIN/../..:\$ORIGIN/../../../../icicle_amd/lib"
 echo "[plugin] device"
 # host-only C++ against the HIP runtime API (no kernels here): plain clang++, the HIP headers need the platform define
 $CXX $FLAGS -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$HERE/hip_backend_device.cpp" -L"$REF" -licicle_device -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib $RP -o "$OUT/libicicle_backend_hip_device.so"
-for spec in bn254:1 bls12_381:2; do
+for spec in bn254:1 bls12_381:2 bls12_377:3; do
   c=${spec%%:*}; id=${spec##*:}
   echo "[plugin] curve $c"
   $CXX $FLAGS -DCURVE_ID=$id -DFIELD_ID=$id -DCURVE=$c -DFIELD=$c -DICICLE_FFI_PREFIX=$c -DMSM=ON -DNTT=ON -DECNTT=ON -DG2_ENABLED "$HERE/hip_backend_curve.cpp" \
     -L"$REF" -licicle_curve_$c -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_curve_$c.so"
 done
-for spec in bn254:1 bls12_381:2; do   # the curves' scalar fields: Montgomery conversion + NTT over 32-byte elements
+# Grumpkin: MSM only (icicle/cmake/features.cmake:19) -- no G2, no ECNTT, no NTT over its scalar field
+echo "[plugin] curve grumpkin"
+$CXX $FLAGS -DCURVE_ID=5 -DFIELD_ID=5 -DCURVE=grumpkin -DFIELD=grumpkin -DICICLE_FFI_PREFIX=grumpkin -DMSM=ON "$HERE/hip_backend_curve.cpp" \
+  -L"$REF" -licicle_curve_grumpkin -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_curve_grumpkin.so"
+echo "[plugin] field grumpkin (scalar field of the curve, vector ops only)"
+$CXX $FLAGS -DFIELD_ID=5 -DFIELD=grumpkin -DICICLE_FFI_PREFIX=grumpkin "$HERE/hip_backend_field.cpp" \
+  -L"$REF" -licicle_field_grumpkin -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_field_grumpkin.so"
+for spec in bn254:1 bls12_381:2 bls12_377:3 stark252:1002; do   # 256-bit fields: Montgomery conversion + NTT over 32-byte elements
   f=${spec%%:*}; id=${spec##*:}
   echo "[plugin] field $f (scalar field of the curve)"
   $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$f -DICICLE_FFI_PREFIX=$f -DNTT=ON -DHIP_PLUGIN_SCALAR_FIELD_256 "$HERE/hip_backend_field.cpp" \

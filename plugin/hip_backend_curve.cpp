@@ -7,7 +7,9 @@
 // translated key by key (HipExt, hip_c_api.h).
 #include <cstring>
 #include "icicle/backend/msm_backend.h"
-#include "icicle/backend/ecntt_backend.h"
+#ifdef ECNTT
+  #include "icicle/backend/ecntt_backend.h"
+#endif
 #include "icicle/curves/montgomery_conversion.h"
 #include "icicle/curves/curve_config.h"
 #include "icicle/utils/utils.h"
@@ -107,6 +109,7 @@ REGISTER_AFFINE_G2_CONVERT_MONTGOMERY_BACKEND("HIP", hip_g2_affine_convert);
 REGISTER_PROJECTIVE_G2_CONVERT_MONTGOMERY_BACKEND("HIP", hip_g2_projective_convert);
 #endif // G2_ENABLED
 
+#ifdef ECNTT
 // ECNTT (icicle/include/icicle/backend/ecntt_backend.h:16-33): NTTConfig<scalar_t> is passed through byte-for-byte
 static_assert(sizeof(NTTConfig<scalar_t>) == sizeof(hip_ntt_config_u256_t), "NTTConfig<scalar_t> layout drifted");
 static eIcicleError hip_ecntt(const Device& device, const projective_t* input, int size, NTTDir dir, const NTTConfig<scalar_t>& config, projective_t* output)
@@ -118,3 +121,4 @@ static eIcicleError hip_ecntt(const Device& device, const projective_t* input, i
   return (eIcicleError)HIP_FN(ecntt)(input, size, (int)dir, &c, output);
 }
 REGISTER_ECNTT_BACKEND("HIP", hip_ecntt);
+#endif // ECNTT

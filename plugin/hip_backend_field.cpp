@@ -1,7 +1,8 @@
 // Reference-runtime plugin, part 3/3: per-field APIs: scalar_convert_montgomery and the NTT family.
 // Compile once per field with -DFIELD_ID=<n> -DICICLE_FFI_PREFIX=<field> -DNTT=ON (icicle/cmake/field.cmake:42-79):
 //   31-bit fields (babybear, koalabear): add -DEXT_FIELD=ON, the extension-field NTT is registered too;
-//   the curves' 256-bit scalar fields (bn254, bls12_381): add -DHIP_PLUGIN_SCALAR_FIELD_256.
+//   256-bit fields (the scalar fields of bn254, bls12_381, bls12_377; stark252): add -DHIP_PLUGIN_SCALAR_FIELD_256;
+//   a field the reference gives no NTT (grumpkin's scalar field): leave -DNTT out, only the vector ops are registered.
 // Registers all four members of the NTT API family (a missing member makes the reference dispatcher
 // THROW through its extern "C" shim) plus the extension-field NTT, with the
 // signatures of icicle/include/icicle/backend/ntt_backend.h:13-93.
@@ -69,6 +70,7 @@ REGISTER_SCALAR_ADD_VEC_BACKEND("HIP", hip_scalar_add_vec);
 REGISTER_SCALAR_SUB_VEC_BACKEND("HIP", hip_scalar_sub_vec);
 REGISTER_BIT_REVERSE_BACKEND("HIP", hip_bit_reverse);
 
+#ifdef NTT // (Grumpkin's scalar field has none: icicle/cmake/features.cmake:19)
 #ifdef HIP_PLUGIN_SCALAR_FIELD_256
 typedef hip_ntt_config_u256_t hip_ntt_config_t;
 static_assert(sizeof(scalar_t) == 32, "HIP_PLUGIN_SCALAR_FIELD_256 is for the curves' scalar fields");
@@ -143,3 +145,4 @@ static eIcicleError hip_ext_scalar_convert(const Device& device, const extension
 }
 REGISTER_CONVERT_MONTGOMERY_EXT_FIELD_BACKEND("HIP", hip_ext_scalar_convert);
 #endif // !HIP_PLUGIN_SCALAR_FIELD_256
+#endif // NTT

@@ -56,6 +56,9 @@ void icicle_hip_config_extension_set_bool(void* ext, const char* key, bool value
   int icicle_hip_##P##_scalar_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
 HIP_DECLARE_CONVERT(bn254)
 HIP_DECLARE_CONVERT(bls12_381)
+HIP_DECLARE_CONVERT(bls12_377)
+HIP_DECLARE_CONVERT(grumpkin)
+HIP_DECLARE_CONVERT(stark252)
 HIP_DECLARE_CONVERT(babybear)
 HIP_DECLARE_CONVERT(koalabear)
 int icicle_hip_babybear_extension_scalar_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
@@ -65,15 +68,21 @@ int icicle_hip_koalabear_extension_scalar_convert_montgomery(const void*, uint64
   int icicle_hip_##C##_projective_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
 HIP_DECLARE_POINT_CONVERT(bn254)
 HIP_DECLARE_POINT_CONVERT(bls12_381)
+HIP_DECLARE_POINT_CONVERT(bls12_377)
+HIP_DECLARE_POINT_CONVERT(grumpkin)
 #define HIP_DECLARE_CURVE(C)                                                                                           \
   int icicle_hip_##C##_msm(const void*, const void*, int, const hip_msm_config_t*, void*);                              \
   int icicle_hip_##C##_msm_precompute_bases(const void*, int, const hip_msm_config_t*, void*);
 HIP_DECLARE_CURVE(bn254)
 HIP_DECLARE_CURVE(bls12_381)
+HIP_DECLARE_CURVE(bls12_377)
+HIP_DECLARE_CURVE(grumpkin)
 HIP_DECLARE_CURVE(bn254_g2)
 HIP_DECLARE_CURVE(bls12_381_g2)
+HIP_DECLARE_CURVE(bls12_377_g2)
 HIP_DECLARE_POINT_CONVERT(bn254_g2)
 HIP_DECLARE_POINT_CONVERT(bls12_381_g2)
+HIP_DECLARE_POINT_CONVERT(bls12_377_g2)
 #define HIP_DECLARE_FIELD(F)                                                                                           \
   int icicle_hip_##F##_ntt(const uint32_t*, int, int, const hip_ntt_config_u32_t*, uint32_t*);                         \
   int icicle_hip_##F##_extension_ntt(const uint32_t*, int, int, const hip_ntt_config_u32_t*, uint32_t*);               \
@@ -89,6 +98,8 @@ HIP_DECLARE_FIELD(koalabear)
   int icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t, uint32_t*);
 HIP_DECLARE_SCALAR_FIELD(bn254)
 HIP_DECLARE_SCALAR_FIELD(bls12_381)
+HIP_DECLARE_SCALAR_FIELD(bls12_377)
+HIP_DECLARE_SCALAR_FIELD(stark252)
 #define HIP_DECLARE_VEC_ARITH(F)                                                                                        \
   int icicle_hip_##F##_vector_add(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);              \
   int icicle_hip_##F##_vector_sub(const void*, const void*, uint64_t, const hip_vec_ops_config_t*, void*);              \
@@ -101,8 +112,12 @@ HIP_DECLARE_VEC_ARITH(babybear)
 HIP_DECLARE_VEC_ARITH(koalabear)
 HIP_DECLARE_VEC_ARITH(bn254)
 HIP_DECLARE_VEC_ARITH(bls12_381)
+HIP_DECLARE_VEC_ARITH(bls12_377)
+HIP_DECLARE_VEC_ARITH(grumpkin)
+HIP_DECLARE_VEC_ARITH(stark252)
 int icicle_hip_bn254_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 int icicle_hip_bls12_381_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
+int icicle_hip_bls12_377_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 }
 
 #ifdef __cplusplus

@@ -109,12 +109,11 @@ def g2_fixture(cname, seed):
     return out
 
 
-def scalar_ntt_fixture(cname, seed):
-    """NTT over the curve's 256-bit scalar field + ECNTT over G1 on the same domain"""
+def scalar_ntt_fixture(cname, seed, with_ec=True):
+    """NTT over the curve's 256-bit scalar field + ECNTT over G1 on the same domain (with_ec=False: a 256-bit field
+    without a curve, stark252)"""
     F = pyref.NTT_FIELDS[cname]
-    C = pyref.CURVES[cname]
     sf = ref.RefScalarNttField(cname)
-    refc = ref.RefCurve(cname)
     rng = np.random.default_rng(seed)
     logn, batch = 9, 2
     n = 1 << logn
@@ -129,6 +128,13 @@ def scalar_ntt_fixture(cname, seed):
     out["fwd_NR_coset"] = sf.ntt(x, n, 0, batch=batch, ordering=1, coset_gen=g)
     out["inv_RN_coset"] = sf.ntt(x, n, 1, batch=batch, ordering=2, coset_gen=g)
     out["fwd_columns"] = sf.ntt(x, n, 0, batch=batch, columns_batch=True)
+    small = [sum(int(v) << (32 * k) for k, v in enumerate(x[8 * i:8 * i + 8])) for i in range(16)]
+    assert [sum(int(v) << (32 * k) for k, v in enumerate(r)) for r in sf.ntt(x[:128].copy(), 16, 0).reshape(16, 8)] == pyref.ntt_naive(F, small, pyref.omega(F, 4))
+    if not with_ec:
+        sf.release_domain()
+        return out
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
     m = 32
     pts = pyref.gen_points(C, m, k0=4242 + seed)
     pts[7] = pyref.INF
@@ -148,14 +154,25 @@ def scalar_ntt_fixture(cname, seed):
 
 
 def main():
-    for i, c in enumerate(("bn254", "bls12_381")):
-        np.savez_compressed(os.path.join(HERE, f"msm_{c}.npz"), **msm_fixture(c, 11 + i))
+    """`--missing`: mint only the fixtures that are not there yet (inputs are seeded: the others would come out the same)"""
+    missing_only = "--missing" in sys.argv
+
+    def save(name, make):
+        path = os.path.join(HERE, name)
+        if missing_only and os.path.exists(path):
+            return
+        np.savez_compressed(path, **make())
+        print("wrote", name)
+
+    for i, c in enumerate(("bn254", "bls12_381", "bls12_377", "grumpkin")):
+        save(f"msm_{c}.npz", lambda: msm_fixture(c, 11 + i))
     for i, f in enumerate(("babybear", "koalabear")):
-        np.savez_compressed(os.path.join(HERE, f"ntt_{f}.npz"), **ntt_fixture(f, 21 + i))
-    for i, c in enumerate(("bn254", "bls12_381")):
-        np.savez_compressed(os.path.join(HERE, f"msm_g2_{c}.npz"), **g2_fixture(c, 31 + i))
-        np.savez_compressed(os.path.join(HERE, f"scalar_ntt_{c}.npz"), **scalar_ntt_fixture(c, 41 + i))
-    print("golden fixtures written to", HERE)
+        save(f"ntt_{f}.npz", lambda: ntt_fixture(f, 21 + i))
+    for i, c in enumerate(("bn254", "bls12_381", "bls12_377")):
+        save(f"msm_g2_{c}.npz", lambda: g2_fixture(c, 31 + i))
+        save(f"scalar_ntt_{c}.npz", lambda: scalar_ntt_fixture(c, 41 + i))
+    save("scalar_ntt_stark252.npz", lambda: scalar_ntt_fixture("stark252", 44, with_ec=False))
+    print("golden fixtures in", HERE)
 
 
 if __name__ == "__main__":

@@ -122,6 +122,9 @@ extern "C" int host_field_op(int field, int op, const uint32_t* a, const uint32_
   case 1: return field_op<bn254_fr_params>(op, a, b, out);
   case 2: return field_op<bls12_381_fq_params>(op, a, b, out);
   case 3: return field_op<bls12_381_fr_params>(op, a, b, out);
+  case 4: return field_op<bls12_377_fq_params>(op, a, b, out);
+  case 5: return field_op<bls12_377_fr_params>(op, a, b, out);
+  case 6: return field_op<stark252_fr_params>(op, a, b, out);
   }
   return -1;
 }
@@ -133,6 +136,9 @@ extern "C" int host_ec_op(int curve, int op, const uint32_t* pts, int n, const u
   case 1: return ec_op<bls12_381_g1>(op, pts, n, aux, out);
   case 2: return ec_op<bn254_g2>(op, pts, n, aux, out);
   case 3: return ec_op<bls12_381_g2>(op, pts, n, aux, out);
+  case 4: return ec_op<bls12_377_g1>(op, pts, n, aux, out);
+  case 5: return ec_op<grumpkin_g1>(op, pts, n, aux, out);
+  case 6: return ec_op<bls12_377_g2>(op, pts, n, aux, out);
   }
   return -1;
 }

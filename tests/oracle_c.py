@@ -7,7 +7,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
-CURVE_ID = {"bn254": 0, "bls12_381": 1}
+CURVE_ID = {"bn254": 0, "bls12_381": 1, "bls12_377": 2, "grumpkin": 3}
+LIMBS = {"bn254": 8, "bls12_381": 12, "bls12_377": 12, "grumpkin": 8}
 FIELD_ID = {"babybear": 0, "koalabear": 1}
 _lib = None
 
@@ -24,7 +25,7 @@ def lib():
 
 
 def msm(curve, scalars, bases, c=8, bitsize=0):
-    L = {"bn254": 8, "bls12_381": 12}[curve]
+    L = LIMBS[curve]
     n = scalars.size // 8
     out = np.zeros(3 * L, dtype=np.uint32)
     rc = lib().oracle_msm(CURVE_ID[curve], scalars.ctypes.data_as(ctypes.c_void_p), bases.ctypes.data_as(ctypes.c_void_p),
@@ -34,7 +35,7 @@ def msm(curve, scalars, bases, c=8, bitsize=0):
 
 
 def to_affine(curve, proj):
-    L = {"bn254": 8, "bls12_381": 12}[curve]
+    L = LIMBS[curve]
     proj = np.ascontiguousarray(proj.reshape(3 * L))
     out = np.zeros(2 * L, dtype=np.uint32)
     assert lib().oracle_to_affine(CURVE_ID[curve], proj.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)) == 0

@@ -17,7 +17,7 @@ def _affine_py(cname, proj):
     return np.concatenate([points_to_array(C, [proj_to_affine_py(C, row)[0]]) for row in proj], axis=0)
 
 
-@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381", "bls12_377", "grumpkin"])
 def test_msm_golden(hip, cname):
     from icicle_amd import msm as M
 
@@ -78,7 +78,7 @@ def _g2_affine_py(cname, proj):
     return np.stack(rows)
 
 
-@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381", "bls12_377"])
 def test_g2_msm_golden(hip, cname):
     from icicle_amd import msm as M
 
@@ -91,7 +91,7 @@ def test_g2_msm_golden(hip, cname):
     assert np.array_equal(_g2_affine_py(cname, M.msm(cname, g["scalars"], g["bases"], cfg, g2=True)), g["res_batch2_shared"])
 
 
-@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381", "bls12_377", "stark252"])
 def test_scalar_ntt_and_ecntt_golden(hip, cname):
     from icicle_amd import ntt as N
     from oracle import pyref
@@ -115,7 +115,8 @@ def test_scalar_ntt_and_ecntt_golden(hip, cname):
         assert np.array_equal(run(0, ordering=1, coset=cg), g["fwd_NR_coset"])
         assert np.array_equal(run(1, ordering=2, coset=cg), g["inv_RN_coset"])
         assert np.array_equal(run(0, columns=True), g["fwd_columns"])
-        C = pyref.CURVES[cname]
+        if "ec_points" not in g:  # stark252: a field with an NTT and no curve
+            return
         m = 32
         y = N.ecntt(cname, g["ec_points"], N.FORWARD, size=m)
         assert np.array_equal(_affine_py(cname, y.reshape(m, -1)), g["ec_fwd_NN_affine"])

@@ -11,7 +11,7 @@ from oracle import pyref, ref
 from tests.util import cached_points, from_words, points_to_array, proj_to_affine_py, rand_scalars, to_words
 
 pytestmark = pytest.mark.gpu
-CURVES = ["bn254", "bls12_381"]
+CURVES = ["bn254", "bls12_381", "bls12_377", "grumpkin"]
 
 
 def _check(hip, cname, scalars, bases, refc, **kw):

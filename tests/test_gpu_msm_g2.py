@@ -9,7 +9,7 @@ from oracle import pyref, ref
 from tests.util import rand_scalars, to_words
 
 pytestmark = pytest.mark.gpu
-CURVES = ["bn254", "bls12_381"]
+CURVES = ["bn254", "bls12_381", "bls12_377"]
 _cache = {}
 
 

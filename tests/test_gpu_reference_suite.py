@@ -6,10 +6,11 @@ test compares the two (ASSERT_EQ on group elements for MSM / ECNTT, memcmp for N
   test_device_api.cpp            all of DeviceApiTest (SetDefaultDevice, MemoryCopyAsync with malloc_async / free_async,
                                  memoryTracker with 200 live allocations, ...)
   test_curve_api.cpp             CurveApiTest.{msm, msm_pre_compute, msmCpuThreads, msm_bitsize, msmG2, MontConversion*,
-                                 ecntt, ecnttDeviceMem} + the host-arithmetic CurveSanity suite, for bn254 and bls12_381
+                                 ecntt, ecnttDeviceMem} + the host-arithmetic CurveSanity suite, for bn254, bls12_381 and
+                                 bls12_377; the MSM part of it for grumpkin
   test_mod_arithmetic_api.h      ModArithTest.{ntt, montgomeryConversion} for the base and the extension field,
                                  {vectorVectorOps, bitReverse} for the base field, ModArithTestBase.scalarVectorOps,
-                                 for babybear, koalabear and the two curves' scalar fields
+                                 for babybear, koalabear, stark252 and the three pairing curves' scalar fields
 Each binary runs in its own process (the reference runtime owns the process-wide icicle_* symbols) and several times:
 the reference tests draw their sizes / orderings / cosets from a time-seeded generator."""
 import os
@@ -50,15 +51,17 @@ def test_reference_device_api_suite(hip):
         assert _ran(out, f"DeviceApiTest.{t}"), (t, out[-3000:])
 
 
-@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377", "grumpkin"])
 def test_reference_curve_api_suite(hip, curve):
     outs = _run(f"test_curve_api_{curve}", "CurveApiTest.*:CurveSanity*", repeat=2, timeout=1500)
-    for t in ("msm", "msm_pre_compute", "msmCpuThreads", "MontConversionAffine", "MontConversionProjective", "msm_bitsize", "msmG2",
-              "MontConversionG2Affine", "MontConversionG2Projective", "ecntt", "ecnttDeviceMem"):
+    names = ["msm", "msm_pre_compute", "msmCpuThreads", "MontConversionAffine", "MontConversionProjective", "msm_bitsize"]
+    if curve != "grumpkin":  # (the reference builds Grumpkin with an MSM only: no G2, no ECNTT)
+        names += ["msmG2", "MontConversionG2Affine", "MontConversionG2Projective", "ecntt", "ecnttDeviceMem"]
+    for t in names:
         assert _ran(outs[0], f"CurveApiTest.{t}"), (t, outs[0][-3000:])
 
 
-@pytest.mark.parametrize("field", ["babybear", "koalabear", "bn254", "bls12_381"])
+@pytest.mark.parametrize("field", ["babybear", "koalabear", "bn254", "bls12_381", "bls12_377", "stark252"])
 def test_reference_modarith_suite(hip, field):
     ext = field in ("babybear", "koalabear")
     flt = "ModArithTest/*.ntt:ModArithTest/*.montgomeryConversion:ModArithTest/0.vectorVectorOps:ModArithTest/0.bitReverse:ModArithTestBase.scalarVectorOps"

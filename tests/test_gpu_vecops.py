@@ -9,17 +9,23 @@ from oracle import pyref, ref
 from tests.util import cached_points, points_to_array, rand_scalars, to_words
 
 pytestmark = pytest.mark.gpu
+BIG = ("bn254", "bls12_381", "bls12_377", "grumpkin", "stark252")  # 8-word scalars
 
 
-@pytest.mark.parametrize("field", ["bn254", "bls12_381", "babybear", "koalabear"])
+def scalar_modulus(field):
+    """a curve name stands for its scalar field"""
+    return pyref.CURVES[field].r if field in pyref.CURVES else pyref.NTT_FIELDS[field].p
+
+
+@pytest.mark.parametrize("field", ["bn254", "bls12_381", "bls12_377", "grumpkin", "stark252", "babybear", "koalabear"])
 def test_scalar_convert_montgomery(hip, field):
     from icicle_amd import vecops as V
     from icicle_amd.runtime import DeviceVec
 
     rng = np.random.default_rng(3)
     n = 5000
-    if field in ("bn254", "bls12_381"):
-        p = pyref.CURVES[field].r
+    if field in BIG:
+        p = scalar_modulus(field)
         vals = rand_scalars(rng, n, p)
         vals[:4] = [0, 1, p - 1, p // 2]
         x = to_words(vals, 8)
@@ -43,7 +49,7 @@ def test_scalar_convert_montgomery(hip, field):
         assert np.array_equal(ge, ref.ref_convert_montgomery(field, f"{field}_extension_scalar_convert_montgomery", xe, 300, True))
 
 
-@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381", "bls12_377", "grumpkin"])
 def test_point_convert_montgomery_and_wrapper_flow(hip, cname):
     from icicle_amd import msm as M
     from icicle_amd import vecops as V
@@ -91,20 +97,20 @@ def _ref_vec2(fname, op, a, b, size, batch=1, columns=False):
     return out
 
 
-@pytest.mark.parametrize("fname", ["babybear", "koalabear", "bn254", "bls12_381"])
+@pytest.mark.parametrize("fname", ["babybear", "koalabear", "bn254", "bls12_381", "bls12_377", "grumpkin", "stark252"])
 def test_vector_arithmetic_vs_reference(hip, fname):
     """vector_add / sub / mul, scalar_mul_vec, bit_reverse vs the reference CPU backend (memcmp), with batches in
     both layouts, edge values (0, 1, p-1) and device-resident operands"""
     from icicle_amd import vecops as V
     from icicle_amd.runtime import DeviceVec
 
-    F = pyref.NTT_FIELDS[fname]
-    W = 8 if fname in ("bn254", "bls12_381") else 1
+    P = scalar_modulus(fname)
+    W = 8 if fname in BIG else 1
     rng = np.random.default_rng(71)
 
     def rand(count):
-        vals = rand_scalars(rng, count, F.p)
-        vals[:3] = [0, 1, F.p - 1][: min(3, count)]
+        vals = rand_scalars(rng, count, P)
+        vals[:3] = [0, 1, P - 1][: min(3, count)]
         return np.ascontiguousarray(to_words(vals, W).reshape(-1))
 
     for size, batch, columns in ((1, 1, False), (1000, 1, False), (256, 3, False), (256, 3, True), (1 << 14, 2, True)):

@@ -14,8 +14,9 @@ from oracle import pyref
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "_build", "libhost_math.so")
 SRC = os.path.join(HERE, "host_math_harness.cpp")
-FIELDS = {0: pyref.BN254.q, 1: pyref.BN254.r, 2: pyref.BLS12_381.q, 3: pyref.BLS12_381.r}
-NL = {0: 8, 1: 8, 2: 12, 3: 8}
+FIELDS = {0: pyref.BN254.q, 1: pyref.BN254.r, 2: pyref.BLS12_381.q, 3: pyref.BLS12_381.r,
+          4: pyref.BLS12_377.q, 5: pyref.BLS12_377.r, 6: pyref.STARK252.p}
+NL = {0: 8, 1: 8, 2: 12, 3: 8, 4: 12, 5: 8, 6: 8}
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +36,7 @@ def iv(a):
     return sum(int(v) << (32 * i) for i, v in enumerate(a))
 
 
-@pytest.mark.parametrize("f", [0, 1, 2, 3])
+@pytest.mark.parametrize("f", [0, 1, 2, 3, 4, 5, 6])
 def test_field_ops(lib, f):
     p, n = FIELDS[f], NL[f]
     rnd = random.Random(f)
@@ -57,7 +58,7 @@ def test_field_ops(lib, f):
         assert out[0] == (1 if a == b else 0)
 
 
-@pytest.mark.parametrize("ci,c", [(0, pyref.BN254), (1, pyref.BLS12_381)])
+@pytest.mark.parametrize("ci,c", [(0, pyref.BN254), (1, pyref.BLS12_381), (4, pyref.BLS12_377), (5, pyref.GRUMPKIN)])
 def test_ec_ops(lib, ci, c):
     n32 = c.limbs_q
     rnd = random.Random(42 + ci)
@@ -117,7 +118,7 @@ def test_ec_ops(lib, ci, c):
     assert got == pyref.INF and raw[1] != 0
 
 
-@pytest.mark.parametrize("ci,c", [(2, pyref.BN254_G2), (3, pyref.BLS12_381_G2)])
+@pytest.mark.parametrize("ci,c", [(2, pyref.BN254_G2), (3, pyref.BLS12_381_G2), (6, pyref.BLS12_377_G2)])
 def test_g2_ec_ops(lib, ci, c):
     """same cases over Fq2 (fq2.hpp): XYZZ accumulation with its exceptional branches, complete add / dbl,
     small multiples; the bound tracker asserts inside the harness on every field operation."""

@@ -11,7 +11,7 @@ from tests import oracle_c as oc
 from tests.util import from_words, points_to_array, rand_scalars, to_words
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CURVES = ["bn254", "bls12_381"]
+CURVES = ["bn254", "bls12_381", "bls12_377", "grumpkin"]
 FIELDS = ["babybear", "koalabear"]
 ORD = {"NN": 0, "NR": 1, "RN": 2, "RR": 3}
 
@@ -107,7 +107,7 @@ def test_c_oracle_vs_reference_random_msm():
     assert np.array_equal(got, refc.to_affine(refc.msm(sc, bases))[0])
 
 
-@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381", "bls12_377"])
 def test_reference_g2_msm_matches_python_definition(cname):
     """pins pyref's Fq2 / G2 arithmetic (used by the G2 GPU tests) to the reference's G2_ENABLED build"""
     C = pyref.G2_CURVES[cname]
@@ -128,7 +128,7 @@ def test_reference_g2_msm_matches_python_definition(cname):
     assert got == pyref.g2_msm_naive(C, sc, pts)
 
 
-@pytest.mark.parametrize("fname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("fname", ["bn254", "bls12_381", "bls12_377", "stark252"])
 def test_reference_scalar_field_ntt_matches_definition(fname):
     """pins pyref.ntt_naive over the 256-bit scalar fields (used by tests/test_gpu_ntt_scalar.py)"""
     F = pyref.NTT_FIELDS[fname]
@@ -149,7 +149,7 @@ def test_reference_scalar_field_ntt_matches_definition(fname):
         rf.release_domain()
 
 
-@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381", "bls12_377"])
 def test_reference_build_matches_new_row_goldens(cname):
     """the committed G2 / scalar-field NTT / ECNTT fixtures are what the reference build produces today"""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"msm_g2_{cname}.npz"))

@@ -17,12 +17,24 @@ BIG = {
         12,
     ),
     "bls12_381_fr": (0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, 8),
+    "bls12_377_fq": (
+        0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001,
+        12,
+    ),
+    "bls12_377_fr": (0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001, 8),
+    # the Stark curve's base field, 2^251 + 17 * 2^192 + 1: a field with an NTT only (reference FIELD_ID 1002)
+    "stark252_fr": (0x0800000000000011000000000000000000000000000000000000000000000001, 8),
 }
+# quadratic non-residue of the G2 extension Fq2 = Fq[u]/(u^2 + NONRES) (reference fq_config::nonresidue with
+# nonresidue_is_negative = true: bn254_base.h:67-71, bls12_381_base.h, bls12_377_base.h:1560-1564)
+NONRES = {"bn254_fq": 1, "bls12_381_fq": 1, "bls12_377_fq": 5}
 # scalar fields with an NTT: root of unity of order 2^two_adicity (reference fp_config::rou,
 # fields/snark_fields/bn254_scalar.h:68-69, bls12_381_scalar.h:46-47)
 BIG_ROU = {
     "bn254_fr": 0x2A3C09F0A58A7E8500E0A7EB8EF62ABC402D111E41112ED49BD61B6E725B19F0,
     "bls12_381_fr": 0x0212D79E5B416B6F0FD56DC8D168D6C0C4024FF270B3E0941B788F500B912F1F,
+    "bls12_377_fr": 0x11D4B7F60CB92CC160C69477D1A8A12F9B506EE363E3F04A476EF4A4EC2A895E,
+    "stark252_fr": 0x005282DB87529CFA3F0464519C8B0FA5AD187148E11A61616070024F42F8EF94,
 }
 RB = 29
 
@@ -71,6 +83,8 @@ def gen_big(name, p, l32):
     s.append(f"  static constexpr uint32_t CANON_TO_REFMONT[{nl}] = {arr(limbs(c4, nl))}; // 2^{32*l32} * R mod p")
     c3 = r32 % p  # our-Montgomery x*R -> reference-Montgomery: montmul(xR, C) = x*C => C = 2^(32 l32)
     s.append(f"  static constexpr uint32_t MONT_TO_REFMONT[{nl}] = {arr(limbs(c3, nl))}; // 2^{32*l32} mod p")
+    if name in NONRES:
+        s.append(f"  static constexpr int NONRES = {NONRES[name]}; // Fq2 = Fq[u]/(u^2 + NONRES)")
     if name in BIG_ROU:
         rou = BIG_ROU[name]
         ta = ((p - 1) & -(p - 1)).bit_length() - 1
@@ -91,6 +105,15 @@ CURVES = {
         0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
         0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1,
     ),
+    "bls12_377": (
+        "bls12_377_fq",
+        "bls12_377_fr",
+        1,
+        0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF,
+        0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6,
+    ),
+    # y^2 = x^3 - 17 over BN254's scalar field; its group order is BN254's base-field modulus (the curves form a cycle)
+    "grumpkin": ("bn254_fr", "bn254_fq", -17, 1, 0x0000000000000002CF135E7506A45D632D270D45F1181294833FC48D823F272C),
 }
 
 
@@ -120,21 +143,34 @@ G2 = {
             0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE,
         ),
     ),
+    "bls12_377": (
+        "(0, 0x010222f6...) over u^2 = -5",
+        (
+            0x018480BE71C785FEC89630A2A3841D01C565F071203E50317EA501F557DB6B9B71889F52BB53540274E3E48F7C005196,
+            0x00EA6040E700403170DC5A51B1B140D5532777EE6651CECBE7223ECE0799C9DE5CF89984BFF76FE6B26BFEFA6EA16AFE,
+        ),
+        (
+            0x00690D665D446F7BD960736BCBB2EFB4DE03ED7274B49A58E458C282F832D204F2CF88886D8C7C2EF094094409FD4DDF,
+            0x00F8169FD28355189E549DA3151A70AA61EF11AC3D591BF12463B01ACEE304C24279B83F5E52270BD9A1CDD185EB8F93,
+        ),
+    ),
 }
 
 
-def f2mul(a, b, p):
-    return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+def f2mul(a, b, p, nr=1):
+    return ((a[0] * b[0] - nr * a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
 
 
-def f2inv(a, p):
-    ni = pow((a[0] * a[0] + a[1] * a[1]) % p, -1, p)
+def f2inv(a, p, nr=1):
+    ni = pow((a[0] * a[0] + nr * a[1] * a[1]) % p, -1, p)
     return (a[0] * ni % p, (-a[1]) * ni % p)
 
 
 def g2_b(name, p):
     if name == "bn254":
         return f2mul((3, 0), f2inv((9, 1), p), p)
+    if name == "bls12_377":  # reference curves/params/bls12_377.h weierstrass_b_g2_{re,im}
+        return (0, 0x010222F6DB0FD6F343BD03737460C589DC7B4F91CD5FD889129207B63C6BF8000DD39E5C1CCCCCCD1C9ED9999999999A)
     return (4, 4)
 
 
@@ -144,12 +180,13 @@ def gen_curve_g2(name, fq, fr):
     R = 1 << (RB * nl)
     _, gx, gy = G2[name]
     b = g2_b(name, p)
-    x3 = f2mul(f2mul(gx, gx, p), gx, p)
-    y2 = f2mul(gy, gy, p)
+    nr = NONRES[fq]
+    x3 = f2mul(f2mul(gx, gx, p, nr), gx, p, nr)
+    y2 = f2mul(gy, gy, p, nr)
     assert ((y2[0] - x3[0] - b[0]) % p, (y2[1] - x3[1] - b[1]) % p) == (0, 0), name
     pair = lambda v: "{" + ", ".join(arr(limbs(c * R % p, nl)) for c in v) + "}"
     s = []
-    s.append(f"struct {name}_g2 {{ // twist over Fq2 = Fq[u]/(u^2+1), b' = {G2[name][0]}")
+    s.append(f"struct {name}_g2 {{ // twist over Fq2 = Fq[u]/(u^2+{nr}), b' = {G2[name][0]}")
     s.append(f"  using fq = {fq}_params;")
     s.append(f"  using fr = {fr}_params;")
     s.append("  static constexpr int EXT_DEGREE = 2;")
@@ -170,7 +207,7 @@ def gen_curve(name, fq, fr, b, gx, gy):
     s.append(f"  using fq = {fq}_params;")
     s.append(f"  using fr = {fr}_params;")
     s.append("  static constexpr int EXT_DEGREE = 1;")
-    s.append(f"  static constexpr uint32_t B3[{nl}] = {arr(limbs(3 * b * R % p, nl))}; // 3*b, Montgomery")
+    s.append(f"  static constexpr uint32_t B3[{nl}] = {arr(limbs(3 * b % p * R % p, nl))}; // 3*b, Montgomery")
     s.append(f"  static constexpr uint32_t GX[{nl}] = {arr(limbs(gx * R % p, nl))}; // generator, Montgomery")
     s.append(f"  static constexpr uint32_t GY[{nl}] = {arr(limbs(gy * R % p, nl))};")
     s.append("};")
@@ -215,7 +252,8 @@ def main():
         out.append(gen_big(name, p, l32))
     for name, (fq, fr, b, gx, gy) in CURVES.items():
         out.append(gen_curve(name, fq, fr, b, gx, gy))
-        out.append(gen_curve_g2(name, fq, fr))
+        if name in G2:
+            out.append(gen_curve_g2(name, fq, fr))
     for name, (p, rou) in SMALL.items():
         out.append(gen_small(name, p, rou))
     out.append("} // namespace icicle_hip")
