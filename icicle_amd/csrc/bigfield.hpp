@@ -434,8 +434,11 @@ namespace icicle_hip {
     static HD fe inv(const fe& a)
     {
       fe r = one(), base = a;
+      uint32_t borrow = 2; // exponent p - 2, word by word (BLS12-377's p ends in ...00000001: the borrow travels)
       for (int wi = 0; wi < N32; wi++) {
-        const uint32_t e = PR::P32[wi] - (wi == 0 ? 2u : 0u);
+        const uint32_t w = PR::P32[wi];
+        const uint32_t e = w - borrow;
+        borrow = w < borrow ? 1u : 0u;
         for (int b = 0; b < 32; b++) {
           if ((e >> b) & 1) r = mul(r, base);
           base = sqr(base);

@@ -39,6 +39,7 @@ namespace {
       out[0] = F::is_zero(F::template sub<2>(x, y)) ? 1 : 0;
       return 0;
     }
+    case 9: r = F::inv(x); break; // x^(p-2); 0 -> 0 (the reference's inverse(0) = 0, projective.h:55-59)
     default: return -1;
     }
     F::to_canonical(out, r);
