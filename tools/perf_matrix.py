@@ -15,7 +15,7 @@ from icicle_amd._lib import MSMConfig, NTTConfigU32, NTTConfigU256, lib, check  
 
 runtime.set_device(0)
 dev = torch.device("cuda", 0)
-TOP = {"bn254": 0x30644E72, "bls12_381": 0x73EDA753}
+TOP = {"bn254": 0x30644E72, "bls12_381": 0x73EDA753, "bls12_377": 0x12AB655E, "grumpkin": 0x30644E72}  # top scalar word
 
 
 def time_it(fn, reps=3):
@@ -265,6 +265,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "midsize":
         for logn in (16, 18, 20, 21, 22, 23, 24):
             msm_case("bn254", logn)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "curves":  # the further curves / fields next to the two of the BASELINE configs
+        for curve in ("bn254", "grumpkin", "bls12_381", "bls12_377"):
+            for logn in (16, 20, 22):
+                msm_case(curve, logn)
+        msm_case("bls12_381", 18, g2=True)
+        msm_case("bls12_377", 18, g2=True)
+        for field in ("bn254", "bls12_377", "stark252"):
+            ntt_scalar_case(field, 20, 4)
+        ecntt_case("bls12_377", 10)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g2":
         for logn in (12, 16, 20, 22, 24):
