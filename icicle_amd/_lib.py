@@ -107,6 +107,28 @@ class NTTConfigU256(ctypes.Structure):
             self.coset_gen[i] = (g >> (32 * i)) & 0xFFFFFFFF
 
 
+class NTTConfigU64(ctypes.Structure):
+    """icicle::NTTConfig<S> for goldilocks' 8-byte scalar_t, 40 bytes (include/icicle_hip.h icicle_ntt_config_u64_t)."""
+    _fields_ = [
+        ("stream", ctypes.c_void_p),
+        ("coset_gen", ctypes.c_uint32 * 2),
+        ("batch_size", ctypes.c_int),
+        ("columns_batch", ctypes.c_bool),
+        ("ordering", ctypes.c_int),
+        ("are_inputs_on_device", ctypes.c_bool),
+        ("are_outputs_on_device", ctypes.c_bool),
+        ("is_async", ctypes.c_bool),
+        ("ext", ctypes.c_void_p),
+    ]
+
+    @classmethod
+    def default(cls):
+        return cls(None, (ctypes.c_uint32 * 2)(1, 0), 1, False, 0, False, False, False, None)
+
+    def set_coset_gen(self, g: int):
+        self.coset_gen[0], self.coset_gen[1] = g & 0xFFFFFFFF, (g >> 32) & 0xFFFFFFFF
+
+
 class VecOpsConfig(ctypes.Structure):
     """icicle::VecOpsConfig (include/icicle/vec_ops.h:19-37), 32 bytes."""
     _fields_ = [
@@ -162,6 +184,7 @@ ECNTT_CURVES = ["bn254", "bls12_381", "bls12_377"]
 NTT_FIELDS = ["babybear", "koalabear"]
 SCALAR_NTT_FIELDS = ["bn254", "bls12_381", "bls12_377", "stark252"]  # NTT over a 256-bit field, 8-word elements
 BIG_VEC_FIELDS = SCALAR_NTT_FIELDS + ["grumpkin"]  # element-wise ops / Montgomery conversion over 8-word scalars
+GOLD = "goldilocks"  # 2-word elements, NTTConfigU64; extension field = 2 components
 API_SYMBOLS = (
     [f"{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
     + [f"{c}_g2_{s}" for c in G2_CURVES for s in ("msm", "msm_precompute_bases", "hip_generate_affine_points", "hip_projective_sum")]
@@ -173,7 +196,9 @@ API_SYMBOLS = (
     + [f"icicle_hip_{f}_{s}" for f in SCALAR_NTT_FIELDS for s in ("ntt", "ntt_init_domain", "ntt_release_domain",
                                                                  "get_root_of_unity_from_domain")]
     + [f"{pre}{c}_ecntt" for pre in ("", "icicle_hip_") for c in ECNTT_CURVES]
-    + [f"{pre}{f}_{op}" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + BIG_VEC_FIELDS
+    + [f"{GOLD}_{s}" for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity", "get_root_of_unity_from_domain")]
+    + [f"icicle_hip_{GOLD}_{s}" for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity_from_domain")]
+    + [f"{pre}{f}_{op}" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + BIG_VEC_FIELDS + [GOLD]
        for op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "scalar_add_vec", "scalar_sub_vec", "bit_reverse")]
     + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
        "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_selftest_inplace_products", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
@@ -184,8 +209,8 @@ API_SYMBOLS = (
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
     + [f"icicle_hip_{f}_{s}" for f in NTT_FIELDS for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain",
                                                           "get_root_of_unity_from_domain")]
-    + [f"{pre}{f}_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in BIG_VEC_FIELDS + NTT_FIELDS]
-    + [f"{pre}{f}_extension_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in NTT_FIELDS]
+    + [f"{pre}{f}_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in BIG_VEC_FIELDS + NTT_FIELDS + [GOLD]]
+    + [f"{pre}{f}_extension_scalar_convert_montgomery" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + [GOLD]]
     + [f"{pre}{c}_{k}_convert_montgomery" for pre in ("", "icicle_hip_") for c in CURVES for k in ("affine", "projective")]
     + [f"{pre}{c}_g2_{k}_convert_montgomery" for pre in ("", "icicle_hip_") for c in G2_CURVES for k in ("affine", "projective")]
 )
@@ -250,7 +275,12 @@ for _f in SCALAR_NTT_FIELDS:
     getattr(lib, f"{_f}_ntt_init_domain").argtypes = [ctypes.c_void_p, ctypes.POINTER(NTTInitDomainConfig)]
     getattr(lib, f"{_f}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
     getattr(lib, f"{_f}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
-for _f in NTT_FIELDS + BIG_VEC_FIELDS:
+for _s in ("ntt", "extension_ntt"):
+    getattr(lib, f"{GOLD}_{_s}").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(NTTConfigU64), ctypes.c_void_p]
+getattr(lib, f"{GOLD}_ntt_init_domain").argtypes = [ctypes.c_void_p, ctypes.POINTER(NTTInitDomainConfig)]
+getattr(lib, f"{GOLD}_get_root_of_unity").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+getattr(lib, f"{GOLD}_get_root_of_unity_from_domain").argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+for _f in NTT_FIELDS + BIG_VEC_FIELDS + [GOLD]:
     for _op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "scalar_add_vec", "scalar_sub_vec"):
         getattr(lib, f"{_f}_{_op}").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
     getattr(lib, f"{_f}_bit_reverse").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]

@@ -17,6 +17,7 @@
 // product-free stages, +2 per later stage, <= 23.2 after ten stages (limit 64, reduce() accepts
 // < 32), back to canonical on every store.
 #include "ntt_big_common.hpp"
+#include "goldfield.hpp"
 #include "ntt_plan.h"
 #include "ntt_multi.hpp"
 #include <algorithm>
@@ -37,7 +38,9 @@ namespace icicle_hip {
     extern __shared__ uint32_t lds_raw[];
     fe* tile = reinterpret_cast<fe*>(lds_raw);
     const uint32_t L = 1u << pd.s, T = pd.T;
-    const uint64_t boff = (uint64_t)(nl.row0 + blockIdx.y) * nl.bs; // launched in slices of <= 65535 rows
+    constexpr int W = B::W; // words per element in memory
+    const uint32_t bq = nl.row0 + blockIdx.y; // lane-transform index (launched in slices of <= 65535)
+    const uint64_t boff = (uint64_t)(bq / nl.lanes) * nl.bs + (bq % nl.lanes); // lanes > 1: components of an extension-field element
     const uint32_t a = blockIdx.x / pd.tiles_per_a, ct = blockIdx.x % pd.tiles_per_a;
     const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
     const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
@@ -48,7 +51,7 @@ namespace icicle_hip {
       idx &= max_mask;
       if (nl.inverse) idx = (((uint64_t)1 << nl.log_max) - idx) & max_mask;
       uint32_t w[8];
-      load8(w, tw + idx * 8);
+      loadw<W>(w, tw + idx * W);
       return F::unpack(w);
     };
 
@@ -57,11 +60,11 @@ namespace icicle_hip {
       const uint32_t t = e % T, k = e / T;
       const uint64_t addr = in_base + (uint64_t)k * pd.in_sk + (uint64_t)t * pd.in_st;
       const uint64_t maddr = (nl.in_rev && pd.pidx == 0) ? bitrev64(addr, nl.logn) : addr;
-      load8(wbuf, in + (boff + maddr * nl.es) * 8);
+      loadw<W>(wbuf, in + (boff + maddr * nl.es) * W);
       fe v = F::unpack(wbuf);
       if (nl.coset && !nl.inverse && pd.pidx == 0) {
         uint32_t cw[8];
-        load8(cw, coset_pow + addr * 8);
+        loadw<W>(cw, coset_pow + addr * W);
         v = F::mul(v, F::unpack(cw));
       }
       tile[(pd.s == 0 ? 0u : (__brev(k) >> (32 - pd.s))) * T + t] = v;
@@ -150,14 +153,14 @@ namespace icicle_hip {
           v = F::mul(v, F::unpack(ninv_mont.w));
           if (nl.coset) {
             uint32_t cw[8];
-            load8(cw, coset_pow + oaddr * 8);
+            loadw<W>(cw, coset_pow + oaddr * W);
             v = F::mul(v, F::unpack(cw));
           }
         }
         if (nl.out_rev) oaddr = bitrev64(oaddr, nl.logn);
       }
       B::store_packed(wbuf, v);
-      store8(out + (boff + oaddr * nl.es) * 8, wbuf);
+      storew<W>(out + (boff + oaddr * nl.es) * W, wbuf);
     }
   }
 
@@ -171,7 +174,7 @@ namespace icicle_hip {
     std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
     auto& dom = BigDomainStore<PR>::map()[dev];
     if (dom.tw) return ICICLE_SUCCESS; // already initialised: silent success (cpu_ntt_domain.h:69)
-    if (words_is_zero(root) || !words_lt_p<PR>(root)) return ICICLE_INVALID_ARGUMENT;
+    if (words_is_zero(root, PR::NL32) || !words_lt_p<PR>(root)) return ICICLE_INVALID_ARGUMENT;
     // order of the root by repeated squaring (cpu_ntt_domain.h:78-94)
     const typename F::fe r = F::from_canonical(root);
     typename F::fe x = r;
@@ -184,14 +187,15 @@ namespace icicle_hip {
     hipStream_t st = (hipStream_t)cfg->stream;
     const size_t n = (size_t)1 << log_max;
     uint32_t* tw = nullptr;
-    HIP_TRY(hipMalloc(&tw, n * 32), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMalloc(&tw, n * PR::NL32 * 4), ICICLE_ALLOCATION_FAILED);
     k_big_gen_twiddles<PR><<<(unsigned)((n / 64 + 256) / 256), 256, 0, st>>>(tw, mont_words<PR>(r), n);
     LAUNCH_CHECK("k_big_gen_twiddles", st);
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED); // see ntt.hip: published to every stream at once
     dom.tw = tw;
     dom.log_max = log_max;
-    memcpy(dom.root, root, 32);
+    memset(dom.root, 0, sizeof dom.root);
+    memcpy(dom.root, root, PR::NL32 * 4);
     return ICICLE_SUCCESS;
   }
 
@@ -252,12 +256,14 @@ namespace icicle_hip {
     return ICICLE_SUCCESS;
   }
 
+  // lanes > 1: every element is `lanes` field elements (an extension field: the transform runs per component with the
+  // base field's twiddles)
   template <class PR>
-  static icicle_error_t big_ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output);
+  static icicle_error_t big_ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output, int lanes = 1);
 
   // row shards over device slots / row groups of a host-resident batch: see ntt_multi.hpp (same contract as ntt.hip)
   template <class PR>
-  static icicle_error_t big_ntt_multi_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output, int G, int max_slots)
+  static icicle_error_t big_ntt_multi_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output, int G, int max_slots, int lanes)
   {
     if (size <= 0 || !input || !output) return ICICLE_INVALID_ARGUMENT;
     ICICLE_TRY(bind_current_device());
@@ -275,7 +281,7 @@ namespace icicle_hip {
     sub.is_async = true;
     NttRowsJob job;
     job.input = input, job.output = output;
-    job.row_bytes = (size_t)size * 32;
+    job.row_bytes = (size_t)size * PR::NL32 * 4 * lanes;
     job.batch = std::max(1, cfg->batch_size);
     job.G = G, job.max_slots = max_slots;
     job.in_on_device = cfg->are_inputs_on_device, job.out_on_device = cfg->are_outputs_on_device, job.is_async = cfg->is_async;
@@ -286,7 +292,7 @@ namespace icicle_hip {
         icicle_ntt_config_u256_t c2 = sub;
         c2.stream = st;
         c2.batch_size = rows;
-        return big_ntt_run<PR>((const uint32_t*)src, size, dir, &c2, (uint32_t*)dst);
+        return big_ntt_run<PR>((const uint32_t*)src, size, dir, &c2, (uint32_t*)dst, lanes);
       },
       [&](hipStream_t st) -> icicle_error_t {
         icicle_ntt_init_domain_config_t ic{st, false, nullptr};
@@ -299,18 +305,19 @@ namespace icicle_hip {
   }
 
   template <class PR>
-  static icicle_error_t big_ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output)
+  static icicle_error_t big_ntt_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* cfg, uint32_t* output, int lanes)
   {
     using F = FieldOps<PR>;
+    constexpr size_t EB = (size_t)PR::NL32 * 4; // bytes per field element
     using fe = typename F::fe;
     if (!cfg) return ICICLE_INVALID_POINTER;
     if (cfg->ext && !cfg->columns_batch) {
       const int G = reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_num_devices", 0);
-      if (G >= 1) return big_ntt_multi_run<PR>(input, size, dir, cfg, output, G, 0);
+      if (G >= 1) return big_ntt_multi_run<PR>(input, size, dir, cfg, output, G, 0, lanes);
     }
     if (!cfg->columns_batch && (!cfg->are_inputs_on_device || !cfg->are_outputs_on_device) && size > 0 && input && output && virtual_device_slots() == 0) {
-      const int groups = ntt_host_row_groups((size_t)size * 32, std::max(1, cfg->batch_size));
-      if (groups > 1) return big_ntt_multi_run<PR>(input, size, dir, cfg, output, groups, 1);
+      const int groups = ntt_host_row_groups((size_t)size * EB * lanes, std::max(1, cfg->batch_size));
+      if (groups > 1) return big_ntt_multi_run<PR>(input, size, dir, cfg, output, groups, 1, lanes);
     }
     if (size <= 0 || (size & (size - 1)) != 0) return ICICLE_INVALID_ARGUMENT; // cpu_ntt_main.h:38-41
     if (!input || !output) return ICICLE_INVALID_POINTER;
@@ -334,7 +341,7 @@ namespace icicle_hip {
 
     hipStream_t st = (hipStream_t)cfg->stream;
     const uint64_t n = (uint64_t)size;
-    const size_t bytes = (size_t)n * batch * 32;
+    const size_t bytes = (size_t)n * batch * lanes * EB;
 
     TempBuf d_in_tmp, d_out_tmp, d_pw, d_work;
     const uint32_t* d_in = input;
@@ -369,14 +376,14 @@ namespace icicle_hip {
     NttLaunch nl;
     nl.logn = logn;
     nl.n = n;
-    nl.nbatch = (uint32_t)batch;
-    nl.lanes = 1;
+    nl.nbatch = (uint32_t)(batch * lanes); // lane-transforms; offset(b') = (b'/lanes)*bs + (b'%lanes), in field elements
+    nl.lanes = (uint32_t)lanes;
     if (cfg->columns_batch) { // element j of transform b at j*batch + b (ntt_cpu.h:250,274-275)
-      nl.bs = 1;
-      nl.es = (uint64_t)batch;
+      nl.bs = (uint64_t)lanes;
+      nl.es = (uint64_t)batch * lanes;
     } else {
-      nl.bs = n;
-      nl.es = 1;
+      nl.bs = n * lanes;
+      nl.es = (uint64_t)lanes;
     }
     const int ord = cfg->ordering;
     nl.in_rev = (ord == ICICLE_kRN || ord == ICICLE_kRR);
@@ -388,7 +395,7 @@ namespace icicle_hip {
     if (nl.inverse) ninv = mont_words<PR>(host_ninv<PR>(logn));
     nl.coset = !words_is_one(cfg->coset_gen);
     if (nl.coset) {
-      HIP_TRY(d_pw.alloc(n * 32, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(d_pw.alloc(n * EB, st), ICICLE_ALLOCATION_FAILED);
       fe gm = F::from_canonical(cfg->coset_gen);
       if (nl.inverse) gm = host_inverse<PR>(gm);
       k_big_coset_powers<PR><<<(unsigned)((n / 16 + 256) / 256), 256, 0, st>>>(d_pw.as<uint32_t>(), mont_words<PR>(gm), n);
@@ -407,8 +414,9 @@ namespace icicle_hip {
       const uint32_t* src = (p == 0) ? d_in : Wk;
       uint32_t* dst = (p == P - 1) ? d_out : Wk;
       const uint64_t L = (uint64_t)1 << parts[p];
-      // tile of L x T elements, 36 B each, <= 72 KiB so that two blocks share a CU; T = 4 gives 128 B runs
-      uint32_t tmax = 4;
+      // tile of L x T elements (36 B each in LDS for the 256-bit fields), <= 72 KiB so that two blocks share a CU; runs
+      // of T elements are >= 128 B in HBM: T = 4 of 32 B, 16 of 8 B
+      uint32_t tmax = std::max(4, 32 / PR::NL32);
       while (tmax > 1 && L * tmax * sizeof(fe) > 72 * 1024)
         tmax >>= 1;
       const PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
@@ -436,11 +444,8 @@ using namespace icicle_hip;
     return ICICLE_INVALID_ARGUMENT;                                                                                    \
   }
 
-#define DEFINE_NTT_U256(F, PRM)                                                                                        \
-  extern "C" icicle_error_t F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* config, uint32_t* output) \
-  {                                                                                                                    \
-    GUARDED(big_ntt_run<PRM>(input, size, dir, config, output));                                                       \
-  }                                                                                                                    \
+// domain / root-of-unity entry points (src/ntt.cpp:26,41,55,75) + collision-free aliases for the plugin
+#define DEFINE_NTT_DOMAIN_API(F, PRM)                                                                                  \
   extern "C" icicle_error_t F##_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config) \
   {                                                                                                                    \
     GUARDED(big_init_domain_run<PRM>(primitive_root, config));                                                         \
@@ -454,12 +459,39 @@ using namespace icicle_hip;
   {                                                                                                                    \
     GUARDED(big_rou_from_domain_run<PRM>(logn, rou));                                                                  \
   }                                                                                                                    \
-  extern "C" icicle_error_t icicle_hip_##F##_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u256_t* c, uint32_t* o) { GUARDED(big_ntt_run<PRM>(i, n, d, c, o)); } \
   extern "C" icicle_error_t icicle_hip_##F##_ntt_init_domain(const uint32_t* r, const icicle_ntt_init_domain_config_t* c) { GUARDED(big_init_domain_run<PRM>(r, c)); } \
   extern "C" icicle_error_t icicle_hip_##F##_ntt_release_domain(void) { GUARDED(big_release_domain_run<PRM>()); }      \
   extern "C" icicle_error_t icicle_hip_##F##_get_root_of_unity_from_domain(uint64_t l, uint32_t* r) { GUARDED(big_rou_from_domain_run<PRM>(l, r)); }
+
+#define DEFINE_NTT_U256(F, PRM)                                                                                        \
+  extern "C" icicle_error_t F##_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u256_t* config, uint32_t* output) \
+  {                                                                                                                    \
+    GUARDED(big_ntt_run<PRM>(input, size, dir, config, output));                                                       \
+  }                                                                                                                    \
+  extern "C" icicle_error_t icicle_hip_##F##_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u256_t* c, uint32_t* o) { GUARDED(big_ntt_run<PRM>(i, n, d, c, o)); } \
+  DEFINE_NTT_DOMAIN_API(F, PRM)
 
 DEFINE_NTT_U256(bn254, bn254_fr_params)
 DEFINE_NTT_U256(bls12_381, bls12_381_fr_params)
 DEFINE_NTT_U256(bls12_377, bls12_377_fr_params)
 DEFINE_NTT_U256(stark252, stark252_fr_params) // reference FIELD_ID 1002: a 252-bit field with an NTT and no curve
+
+
+// Goldilocks (reference FIELD_ID 1005: NTT + EXT_FIELD): 8-byte elements, NTTConfig<scalar_t> is 40 bytes with a 2-word
+// coset generator; the quadratic extension field (u^2 = 7) transforms its two components with the base field's twiddles.
+static icicle_error_t goldilocks_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u64_t* c, uint32_t* output, int lanes)
+{
+  if (!c) return ICICLE_INVALID_POINTER;
+  icicle_ntt_config_u256_t w{};
+  w.stream = c->stream;
+  w.coset_gen[0] = c->coset_gen[0], w.coset_gen[1] = c->coset_gen[1];
+  w.batch_size = c->batch_size, w.columns_batch = c->columns_batch, w.ordering = c->ordering;
+  w.are_inputs_on_device = c->are_inputs_on_device, w.are_outputs_on_device = c->are_outputs_on_device, w.is_async = c->is_async;
+  w.ext = c->ext;
+  return big_ntt_run<goldilocks_params>(input, size, dir, &w, output, lanes);
+}
+extern "C" icicle_error_t goldilocks_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u64_t* c, uint32_t* o) { GUARDED(goldilocks_run(i, n, d, c, o, 1)); }
+extern "C" icicle_error_t goldilocks_extension_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u64_t* c, uint32_t* o) { GUARDED(goldilocks_run(i, n, d, c, o, 2)); }
+extern "C" icicle_error_t icicle_hip_goldilocks_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u64_t* c, uint32_t* o) { GUARDED(goldilocks_run(i, n, d, c, o, 1)); }
+extern "C" icicle_error_t icicle_hip_goldilocks_extension_ntt(const uint32_t* i, int n, int d, const icicle_ntt_config_u64_t* c, uint32_t* o) { GUARDED(goldilocks_run(i, n, d, c, o, 2)); }
+DEFINE_NTT_DOMAIN_API(goldilocks, goldilocks_params)

@@ -47,7 +47,7 @@ namespace icicle_hip {
   };
 
   struct BigDomain {
-    uint32_t* tw = nullptr; // tw[i*8 .. i*8+7] = packed Montgomery w_max^i, i < max_size
+    uint32_t* tw = nullptr; // tw[i*W .. i*W+W-1] = packed Montgomery w_max^i, i < max_size (W = words per element: 8, or 2 for goldilocks)
     int log_max = -1;
     uint32_t root[8] = {0}; // canonical w_max
     int owner = -1;         // >= 0: brought up by a multi-device call of device `owner` (released with its domain)
@@ -82,7 +82,7 @@ namespace icicle_hip {
     const typename B::fe r = F::unpack(root_mont.w);
     typename B::fe x = B::pow_u64(r, (uint64_t)i0);
     for (size_t i = i0; i < i0 + 64 && i < n; i++) {
-      B::store_packed(tw + i * 8, x);
+      B::store_packed(tw + i * B::W, x);
       x = F::mul(x, r);
     }
   }
@@ -99,7 +99,7 @@ namespace icicle_hip {
     const typename B::fe g = F::unpack(g_mont.w);
     typename B::fe x = B::pow_u64(g, i0);
     for (uint64_t i = i0; i < i0 + 16 && i < n; i++) {
-      B::store_packed(pw + i * 8, x);
+      B::store_packed(pw + i * B::W, x);
       x = F::mul(x, g);
     }
   }
@@ -116,34 +116,58 @@ namespace icicle_hip {
     ((uint4*)dst)[1] = make_uint4(src[4], src[5], src[6], src[7]);
   }
 
+  // W words of one element (8: the 256-bit fields; 2: goldilocks)
+  template <int W>
+  __device__ __forceinline__ void loadw(uint32_t* dst, const uint32_t* __restrict__ src)
+  {
+    if constexpr (W == 8) {
+      load8(dst, src);
+    } else {
+      static_assert(W == 2, "element width");
+      const uint2 a = ((const uint2*)src)[0];
+      dst[0] = a.x, dst[1] = a.y;
+    }
+  }
+  template <int W>
+  __device__ __forceinline__ void storew(uint32_t* __restrict__ dst, const uint32_t* src)
+  {
+    if constexpr (W == 8) {
+      store8(dst, src);
+    } else {
+      static_assert(W == 2, "element width");
+      ((uint2*)dst)[0] = make_uint2(src[0], src[1]);
+    }
+  }
+
   // ---- host ------------------------------------------------------------------------------------
+  // (w holds PR::NL32 words of the caller's)
   template <class PR>
   static bool words_lt_p(const uint32_t* w)
   {
-    for (int i = 7; i >= 0; i--) {
+    for (int i = PR::NL32 - 1; i >= 0; i--) {
       if (w[i] < PR::P32[i]) return true;
       if (w[i] > PR::P32[i]) return false;
     }
     return false;
   }
-  static inline bool words_is_zero(const uint32_t* w)
+  static inline bool words_is_zero(const uint32_t* w, int nw = 8)
   {
     uint32_t o = 0;
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < nw; i++)
       o |= w[i];
     return o == 0;
   }
-  static inline bool words_is_one(const uint32_t* w)
+  static inline bool words_is_one(const uint32_t* w, int nw = 8)
   {
     uint32_t o = w[0] ^ 1u;
-    for (int i = 1; i < 8; i++)
+    for (int i = 1; i < nw; i++)
       o |= w[i];
     return o == 0;
   }
   template <class PR>
   static BigWords mont_words(const typename FieldOps<PR>::fe& x)
   {
-    BigWords r;
+    BigWords r{};
     BigNtt<PR>::store_packed(r.w, x);
     return r;
   }

@@ -9,6 +9,7 @@
 #include "common.h"
 #include "bigfield.hpp"
 #include "smallfield.hpp"
+#include "goldfield.hpp"
 
 namespace icicle_hip {
 
@@ -32,6 +33,20 @@ namespace icicle_hip {
 #pragma unroll
     for (int i = 0; i < F::N32; i++)
       out[t * F::N32 + i] = w[i];
+  }
+
+  // goldilocks: x -> x * 2^64 or x * 2^-64 mod p (goldilocks.h:179-184), n elements of 2 words
+  __global__ __launch_bounds__(256) void k_convert_gold(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n, bool to_mont)
+  {
+    using F = FieldOps<goldilocks_params>;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; t < n; t += stride) {
+      const uint2 v = ((const uint2*)in)[t];
+      const uint32_t w[2] = {v.x, v.y};
+      const GoldFe r = F::mul(F::unpack(w), F::make(to_mont ? goldilocks_params::EPS : goldilocks_params::R_INV));
+      ((uint2*)out)[t] = make_uint2((uint32_t)r.v, (uint32_t)(r.v >> 32));
+    }
   }
 
   template <class PR>
@@ -95,6 +110,12 @@ namespace icicle_hip {
       k_convert_small<PR><<<(unsigned)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(i, o, n, to_mont);
     });
   }
+  static icicle_error_t convert_gold(const void* in, uint64_t nelem, bool to_mont, const icicle_vec_ops_config_t* cfg, void* out)
+  {
+    return convert_run(in, nelem, 2, cfg, out, [&](const uint32_t* i, uint32_t* o, size_t n, hipStream_t st) {
+      k_convert_gold<<<(unsigned)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(i, o, n, to_mont);
+    });
+  }
   static uint64_t batch_of(const icicle_vec_ops_config_t* c) { return (c && c->batch_size > 1) ? (uint64_t)c->batch_size : 1; }
 
 } // namespace icicle_hip
@@ -146,3 +167,8 @@ DEFINE_POINT_CONVERT(grumpkin, bn254_fr_params)
 DEFINE_G2_POINT_CONVERT(bn254, bn254_fq_params)
 DEFINE_G2_POINT_CONVERT(bls12_381, bls12_381_fq_params)
 DEFINE_G2_POINT_CONVERT(bls12_377, bls12_377_fq_params)
+// goldilocks and its quadratic extension (two components per element)
+extern "C" icicle_error_t goldilocks_scalar_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_gold(i, n * batch_of(c), to, c, o)); }
+extern "C" icicle_error_t goldilocks_extension_scalar_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_gold(i, 2 * n * batch_of(c), to, c, o)); }
+extern "C" icicle_error_t icicle_hip_goldilocks_scalar_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_gold(i, n * batch_of(c), to, c, o)); }
+extern "C" icicle_error_t icicle_hip_goldilocks_extension_scalar_convert_montgomery(const void* i, uint64_t n, bool to, const icicle_vec_ops_config_t* c, void* o) { GUARDED(convert_gold(i, 2 * n * batch_of(c), to, c, o)); }

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "bigfield.hpp"
 #include "smallfield.hpp"
+#include "goldfield.hpp"
 
 namespace icicle_hip {
 
@@ -61,6 +62,20 @@ namespace icicle_hip {
       if (op == VOP_ADD) return F::add(a, b);
       if (op == VOP_SUB) return F::template sub<2>(a, b);
       return F::mul(F::mul(a, b), F::from_const(PR::R2));
+    }
+  };
+
+  struct GoldElem { // goldilocks: canonical 64-bit values, goldfield.hpp
+    using F = FieldOps<goldilocks_params>;
+    static constexpr int W = 2;
+    using T = GoldFe;
+    static __device__ __forceinline__ T load(const uint32_t* p) { return F::unpack(p); }
+    static __device__ __forceinline__ void store(uint32_t* p, const T& x) { F::pack(p, x); }
+    static __device__ __forceinline__ T apply(int op, const T& a, const T& b)
+    {
+      if (op == VOP_ADD) return F::add(a, b);
+      if (op == VOP_SUB) return F::template sub<2>(a, b);
+      return F::mul(a, b);
     }
   };
 
@@ -215,3 +230,4 @@ DEFINE_VEC_ARITH(bls12_381, BigElem<bls12_381_fr_params>, 8)
 DEFINE_VEC_ARITH(bls12_377, BigElem<bls12_377_fr_params>, 8)
 DEFINE_VEC_ARITH(grumpkin, BigElem<bn254_fq_params>, 8)
 DEFINE_VEC_ARITH(stark252, BigElem<stark252_fr_params>, 8)
+DEFINE_VEC_ARITH(goldilocks, GoldElem, 2)

@@ -1,7 +1,7 @@
 """ntt() / domain management: mirror of wrappers/rust/icicle-core/src/ntt/mod.rs:113-119,285-355."""
 import ctypes
 import numpy as np
-from ._lib import lib, check, NTTConfigU32, NTTConfigU256, NTTInitDomainConfig, SCALAR_NTT_FIELDS
+from ._lib import lib, check, NTTConfigU32, NTTConfigU64, NTTConfigU256, NTTInitDomainConfig, SCALAR_NTT_FIELDS, GOLD
 from .runtime import DeviceVec
 
 FORWARD, INVERSE = 0, 1
@@ -18,7 +18,8 @@ def _ptr(x):
 
 
 def _is_big(field: str) -> bool:
-    return field in SCALAR_NTT_FIELDS
+    """multi-word elements: roots travel as word arrays (goldilocks reads / writes the first two of the eight)"""
+    return field in SCALAR_NTT_FIELDS or field == GOLD
 
 
 def _words(x: int):
@@ -64,7 +65,10 @@ def release_domain(field: str):
 
 def ntt(field: str, inp, direction: int, cfg=None, out=None, size: int = None, extension: bool = False):
     """Scalar-field NTT of a curve (field in SCALAR_NTT_FIELDS): elements are 8 u32 words, cfg is NTTConfigU256."""
-    if _is_big(field):
+    if field == GOLD:
+        cfg = cfg or NTTConfigU64.default()
+        lanes = 4 if extension else 2  # u32 words per element (quadratic extension: two components)
+    elif _is_big(field):
         assert not extension
         cfg = cfg or NTTConfigU256.default()
         lanes = 8

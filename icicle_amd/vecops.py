@@ -6,7 +6,8 @@ from ._lib import lib, check, VecOpsConfig
 from .runtime import DeviceVec
 
 # u32 words per scalar (a curve name stands for its scalar field) and per base-field coordinate of a point
-_WORDS = {"bn254": 8, "bls12_381": 8, "bls12_377": 8, "grumpkin": 8, "stark252": 8, "babybear": 1, "koalabear": 1}
+_WORDS = {"bn254": 8, "bls12_381": 8, "bls12_377": 8, "grumpkin": 8, "stark252": 8, "goldilocks": 2, "babybear": 1, "koalabear": 1}
+_EXT_DEGREE = {"babybear": 4, "koalabear": 4, "goldilocks": 2}
 _POINT_LIMBS = {"bn254": 8, "bls12_381": 12, "bls12_377": 12, "grumpkin": 8}
 
 def _ptr(x):
@@ -32,7 +33,7 @@ def _run(symbol, inp, count, to_montgomery, cfg, out):
 
 def scalar_convert_montgomery(field: str, inp, to_montgomery: bool, cfg=None, out=None, size=None, extension=False):
     """field in _WORDS (a curve name means its scalar field); `size` = elements per batch entry"""
-    words = _WORDS[field] * (4 if extension else 1)
+    words = _WORDS[field] * (_EXT_DEGREE[field] if extension else 1)
     if size is None:
         size = inp.size // words // max(1, (cfg.batch_size if cfg else 1))
     sym = f"{field}_extension_scalar_convert_montgomery" if extension else f"{field}_scalar_convert_montgomery"

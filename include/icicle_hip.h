@@ -384,8 +384,22 @@ icicle_error_t icicle_hip_bls12_381_g2_projective_convert_montgomery(const void*
  *              conversion, vector ops; the reference gives it no NTT  (curves/params/grumpkin.h)
  *   stark252   NTT + Montgomery conversion + vector ops over the 252-bit Stark field 2^251 + 17*2^192 + 1
  *              (fields/stark_fields/stark252.h; no curve)
- * bw6_761 (761-bit base field), goldilocks and m31 are not built.
+ *   goldilocks NTT, extension-field NTT (quadratic extension u^2 = 7: the two components are transformed with the base
+ *              field's twiddles), Montgomery conversion (x * 2^64), vector ops over 2^64 - 2^32 + 1
+ *              (fields/stark_fields/goldilocks.h; scalar_t = 2 words, so NTTConfig<scalar_t> is the 40-byte struct below)
+ * bw6_761 (761-bit base field) and m31 (no NTT in the reference) are not built.
  * ====================================================================================== */
+typedef struct {
+  icicleStreamHandle stream;      /* 0  */
+  uint32_t coset_gen[2];          /* 8   canonical, {1,0} = no coset */
+  int32_t batch_size;             /* 16 */
+  bool columns_batch;             /* 20 */
+  int32_t ordering;               /* 24  icicle_ntt_ordering_t */
+  bool are_inputs_on_device;      /* 28 */
+  bool are_outputs_on_device;     /* 29 */
+  bool is_async;                  /* 30 */
+  icicle_config_extension_t* ext; /* 32 */
+} icicle_ntt_config_u64_t;
 #define ICICLE_HIP_DECLARE_MSM(S)                                                                                      \
   icicle_error_t S##_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results); \
   icicle_error_t S##_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases); \
@@ -415,6 +429,23 @@ ICICLE_HIP_DECLARE_CONVERT(icicle_hip_stark252)
 ICICLE_HIP_DECLARE_VEC_ARITH(bls12_377)
 ICICLE_HIP_DECLARE_VEC_ARITH(grumpkin)
 ICICLE_HIP_DECLARE_VEC_ARITH(stark252)
+/* goldilocks: elements are 2 u32 words (extension elements 4) */
+icicle_error_t goldilocks_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u64_t* config, uint32_t* output);           /* src/ntt.cpp:11 */
+icicle_error_t goldilocks_extension_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u64_t* config, uint32_t* output); /* src/ntt.cpp:90 */
+icicle_error_t goldilocks_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config);
+icicle_error_t goldilocks_ntt_release_domain(void);
+icicle_error_t goldilocks_get_root_of_unity(uint64_t max_size, uint32_t* rou);
+icicle_error_t goldilocks_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);
+icicle_error_t icicle_hip_goldilocks_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u64_t* config, uint32_t* output);
+icicle_error_t icicle_hip_goldilocks_extension_ntt(const uint32_t* input, int size, int dir, const icicle_ntt_config_u64_t* config, uint32_t* output);
+icicle_error_t icicle_hip_goldilocks_ntt_init_domain(const uint32_t* primitive_root, const icicle_ntt_init_domain_config_t* config);
+icicle_error_t icicle_hip_goldilocks_ntt_release_domain(void);
+icicle_error_t icicle_hip_goldilocks_get_root_of_unity_from_domain(uint64_t logn, uint32_t* rou);
+ICICLE_HIP_DECLARE_CONVERT(goldilocks)
+ICICLE_HIP_DECLARE_CONVERT(icicle_hip_goldilocks)
+icicle_error_t goldilocks_extension_scalar_convert_montgomery(const void* input, uint64_t size, bool is_to_montgomery, const icicle_vec_ops_config_t* config, void* output);
+icicle_error_t icicle_hip_goldilocks_extension_scalar_convert_montgomery(const void* input, uint64_t size, bool is_to_montgomery, const icicle_vec_ops_config_t* config, void* output);
+ICICLE_HIP_DECLARE_VEC_ARITH(goldilocks)
 
 #ifdef __cplusplus
 }

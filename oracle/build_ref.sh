@@ -9,7 +9,7 @@
 # Source lists mirror icicle/cmake/target_editor.cmake:4-12,36-49,60-68 and
 # icicle/backend/cpu/CMakeLists.txt:43-81 with only the NTT / EXT_FIELD / MSM features on.
 #
-# Usage: oracle/build_ref.sh [device|bn254|bls12_381|bls12_377|grumpkin|babybear|koalabear|stark252 ...]   (default: all)
+# Usage: oracle/build_ref.sh [device|bn254|bls12_381|bls12_377|grumpkin|babybear|koalabear|stark252|goldilocks ...]   (default: all)
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 R="${ICICLE_REFERENCE_DIR:-/root/reference}/icicle"
@@ -83,7 +83,7 @@ build_curve_msm_only() {
 }
 
 targets=("$@")
-[ ${#targets[@]} -eq 0 ] && targets=(device bn254 bls12_381 bls12_377 grumpkin babybear koalabear stark252)
+[ ${#targets[@]} -eq 0 ] && targets=(device bn254 bls12_381 bls12_377 grumpkin babybear koalabear stark252 goldilocks)
 build_device
 for t in "${targets[@]}"; do
   case $t in
@@ -93,6 +93,7 @@ for t in "${targets[@]}"; do
     bls12_377) build_field bls12_377 3 "" & ;;
     grumpkin) build_field_no_ntt grumpkin 5 & ;;
     stark252) build_field stark252 1002 "" & ;;
+    goldilocks) build_field goldilocks 1005 "-DEXT_FIELD=ON" & ;;
     babybear) build_field babybear 1001 "-DEXT_FIELD=ON" & ;;
     koalabear) build_field koalabear 1004 "-DEXT_FIELD=ON" & ;;
     *) echo "unknown target $t" >&2; exit 1 ;;

@@ -6,7 +6,7 @@
 #   test_device_api                      icicle/tests/test_device_api.cpp
 #   test_curve_api_{bn254,bls12_381,bls12_377}  icicle/tests/test_curve_api.cpp  (-DMSM -DG2_ENABLED -DECNTT, no PAIRING)
 #   test_curve_api_grumpkin              the same source with -DMSM only
-#   test_modarith_{babybear,koalabear,bn254,bls12_381,bls12_377,stark252}  icicle/tests/test_mod_arithmetic_api.h via oracle/shim/tests/modarith_main.cpp
+#   test_modarith_{babybear,koalabear,goldilocks,bn254,bls12_381,bls12_377,stark252}  icicle/tests/test_mod_arithmetic_api.h via oracle/shim/tests/modarith_main.cpp
 #   example_msm, example_ntt             examples/c++/{msm,ntt}/example.cpp (bn254), run as `example_msm HIP`
 #   example_best_practice_ntt            examples/c++/best-practice-ntt/example.cpp (three streams)
 # Run with ICICLE_BACKEND_INSTALL_DIR=oracle/_ref/backend so that the reference runtime loads the HIP plugin and makes
@@ -42,7 +42,7 @@ newer "$OUT/test_curve_api_grumpkin" || { echo "[ref-tests] test_curve_api_grump
 newer "$OUT/test_modarith_stark252" || { echo "[ref-tests] test_modarith_stark252"
   $CXX $FLAGS -DFIELD_ID=1002 -DFIELD=stark252 -DICICLE_FFI_PREFIX=stark252 -DNTT=ON \
     "$HERE/shim/tests/modarith_main.cpp" -L"$REF" -licicle_field_stark252 -licicle_device $RP -o "$OUT/test_modarith_stark252" & }
-for spec in babybear:1001 koalabear:1004; do
+for spec in babybear:1001 koalabear:1004 goldilocks:1005; do
   f=${spec%%:*}; id=${spec##*:}
   newer "$OUT/test_modarith_$f" || { echo "[ref-tests] test_modarith_$f"
     $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$f -DICICLE_FFI_PREFIX=$f -DNTT=ON -DEXT_FIELD=ON \

@@ -304,7 +304,10 @@ STARK252 = NttField(
     0x005282DB87529CFA3F0464519C8B0FA5AD187148E11A61616070024F42F8EF94,
     192,
 )
+# goldilocks, 2^64 - 2^32 + 1 (fields/stark_fields/goldilocks.h:206-276); quadratic extension u^2 = 7, NTT lane-wise
+GOLDILOCKS = NttField("goldilocks", 0xFFFFFFFF00000001, 0x185629DCDA58878C, 32)
 NTT_FIELDS = {
+    "goldilocks": GOLDILOCKS,
     "babybear": BABYBEAR,
     "koalabear": KOALABEAR,
     "bn254": BN254_FR,

@@ -68,6 +68,14 @@ class NTTConfigU256(ctypes.Structure):  # the same struct for the curves' 32-byt
     ]
 
 
+class NTTConfigU64(ctypes.Structure):  # goldilocks: scalar_t = storage<2>
+    _fields_ = [
+        ("stream", ctypes.c_void_p), ("coset_gen", ctypes.c_uint32 * 2), ("batch_size", ctypes.c_int),
+        ("columns_batch", ctypes.c_bool), ("ordering", ctypes.c_int), ("are_inputs_on_device", ctypes.c_bool),
+        ("are_outputs_on_device", ctypes.c_bool), ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p),
+    ]
+
+
 class NTTInitDomainConfig(ctypes.Structure):
     _fields_ = [("stream", ctypes.c_void_p), ("is_async", ctypes.c_bool), ("ext", ctypes.c_void_p)]
 
@@ -355,6 +363,54 @@ class RefScalarNttField:
         cfg = NTTConfigU256(None, _w8(coset_gen), batch, columns_batch, ordering, False, False, False, None)
         out = np.zeros_like(inp)
         fn = getattr(self.lib, f"{self.name}_ntt")
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        rc = fn(_p(inp), size, direction, ctypes.byref(cfg), _p(out))
+        assert rc == 0, f"reference ntt failed rc={rc}"
+        return out
+
+
+class RefGoldField:
+    """goldilocks through the reference's C ABI on "CPU" (src/ntt.cpp compiled with FIELD_ID 1005, EXT_FIELD): elements
+    are 2 u32 words, extension elements (quadratic, u^2 = 7) 4; roots and coset generators are Python ints."""
+
+    name = "goldilocks"
+
+    def __init__(self):
+        _load("device")
+        self.lib = _load(self.name)
+
+    @staticmethod
+    def _w2(x: int):
+        return (ctypes.c_uint32 * 2)(x & 0xFFFFFFFF, (x >> 32) & 0xFFFFFFFF)
+
+    def get_root_of_unity(self, max_size: int) -> int:
+        w = (ctypes.c_uint32 * 2)()
+        fn = self.lib.goldilocks_get_root_of_unity
+        fn.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+        assert fn(max_size, w) == 0
+        return int(w[0]) | (int(w[1]) << 32)
+
+    def init_domain(self, root: int):
+        cfg = NTTInitDomainConfig(None, False, None)
+        fn = self.lib.goldilocks_ntt_init_domain
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        assert fn(self._w2(root), ctypes.byref(cfg)) == 0
+
+    def release_domain(self):
+        assert self.lib.goldilocks_ntt_release_domain() == 0
+
+    def get_root_of_unity_from_domain(self, logn: int) -> int:
+        w = (ctypes.c_uint32 * 2)()
+        fn = self.lib.goldilocks_get_root_of_unity_from_domain
+        fn.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+        assert fn(logn, w) == 0
+        return int(w[0]) | (int(w[1]) << 32)
+
+    def ntt(self, inp: np.ndarray, size: int, direction: int, batch=1, columns_batch=False, ordering=0, coset_gen=1,
+            extension=False) -> np.ndarray:
+        cfg = NTTConfigU64(None, self._w2(coset_gen), batch, columns_batch, ordering, False, False, False, None)
+        out = np.zeros_like(inp)
+        fn = self.lib.goldilocks_extension_ntt if extension else self.lib.goldilocks_ntt
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         rc = fn(_p(inp), size, direction, ctypes.byref(cfg), _p(out))
         assert rc == 0, f"reference ntt failed rc={rc}"

@@ -41,6 +41,9 @@ for spec in bn254:1 bls12_381:2 bls12_377:3 stark252:1002; do   # 256-bit fields
   $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$f -DICICLE_FFI_PREFIX=$f -DNTT=ON -DHIP_PLUGIN_SCALAR_FIELD_256 "$HERE/hip_backend_field.cpp" \
     -L"$REF" -licicle_field_$f -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_field_$f.so"
 done
+echo "[plugin] field goldilocks"
+$CXX $FLAGS -DFIELD_ID=1005 -DFIELD=goldilocks -DICICLE_FFI_PREFIX=goldilocks -DNTT=ON -DEXT_FIELD=ON -DHIP_PLUGIN_SCALAR_FIELD_64 "$HERE/hip_backend_field.cpp" \
+  -L"$REF" -licicle_field_goldilocks -licicle_device -L"$HIPLIB" -licicle_hip $RP -o "$OUT/libicicle_backend_hip_field_goldilocks.so"
 for spec in babybear:1001 koalabear:1004; do
   f=${spec%%:*}; id=${spec##*:}
   echo "[plugin] field $f"

@@ -2,6 +2,7 @@
 // Compile once per field with -DFIELD_ID=<n> -DICICLE_FFI_PREFIX=<field> -DNTT=ON (icicle/cmake/field.cmake:42-79):
 //   31-bit fields (babybear, koalabear): add -DEXT_FIELD=ON, the extension-field NTT is registered too;
 //   256-bit fields (the scalar fields of bn254, bls12_381, bls12_377; stark252): add -DHIP_PLUGIN_SCALAR_FIELD_256;
+//   goldilocks (8-byte elements, quadratic extension): add -DEXT_FIELD=ON -DHIP_PLUGIN_SCALAR_FIELD_64;
 //   a field the reference gives no NTT (grumpkin's scalar field): leave -DNTT out, only the vector ops are registered.
 // Registers all four members of the NTT API family (a missing member makes the reference dispatcher
 // THROW through its extern "C" shim) plus the extension-field NTT, with the
@@ -74,6 +75,9 @@ REGISTER_BIT_REVERSE_BACKEND("HIP", hip_bit_reverse);
 #ifdef HIP_PLUGIN_SCALAR_FIELD_256
 typedef hip_ntt_config_u256_t hip_ntt_config_t;
 static_assert(sizeof(scalar_t) == 32, "HIP_PLUGIN_SCALAR_FIELD_256 is for the curves' scalar fields");
+#elif defined(HIP_PLUGIN_SCALAR_FIELD_64)
+typedef hip_ntt_config_u64_t hip_ntt_config_t;
+static_assert(sizeof(scalar_t) == 8, "HIP_PLUGIN_SCALAR_FIELD_64 is for goldilocks");
 #else
 typedef hip_ntt_config_u32_t hip_ntt_config_t;
 static_assert(sizeof(scalar_t) == 4, "31-bit field expected");

@@ -35,6 +35,16 @@ typedef struct {
 
 typedef struct {
   void* stream;
+  uint32_t coset_gen[2];
+  int batch_size;
+  bool columns_batch;
+  int ordering;
+  bool are_inputs_on_device, are_outputs_on_device, is_async;
+  void* ext;
+} hip_ntt_config_u64_t; // == icicle_ntt_config_u64_t == icicle::NTTConfig<goldilocks::scalar_t> (40 bytes)
+
+typedef struct {
+  void* stream;
   bool is_async;
   void* ext;
 } hip_ntt_init_domain_config_t;
@@ -115,6 +125,14 @@ HIP_DECLARE_VEC_ARITH(bls12_381)
 HIP_DECLARE_VEC_ARITH(bls12_377)
 HIP_DECLARE_VEC_ARITH(grumpkin)
 HIP_DECLARE_VEC_ARITH(stark252)
+HIP_DECLARE_VEC_ARITH(goldilocks)
+HIP_DECLARE_CONVERT(goldilocks)
+int icicle_hip_goldilocks_extension_scalar_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
+int icicle_hip_goldilocks_ntt(const uint32_t*, int, int, const hip_ntt_config_u64_t*, uint32_t*);
+int icicle_hip_goldilocks_extension_ntt(const uint32_t*, int, int, const hip_ntt_config_u64_t*, uint32_t*);
+int icicle_hip_goldilocks_ntt_init_domain(const uint32_t*, const hip_ntt_init_domain_config_t*);
+int icicle_hip_goldilocks_ntt_release_domain(void);
+int icicle_hip_goldilocks_get_root_of_unity_from_domain(uint64_t, uint32_t*);
 int icicle_hip_bn254_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 int icicle_hip_bls12_381_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);
 int icicle_hip_bls12_377_ecntt(const void*, int, int, const hip_ntt_config_u256_t*, void*);

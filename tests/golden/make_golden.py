@@ -81,6 +81,43 @@ def ntt_fixture(fname, seed):
     return out
 
 
+def gold_fixture(seed):
+    """goldilocks: 8-byte elements, quadratic extension (the reference built with FIELD_ID 1005, EXT_FIELD)"""
+    F = pyref.GOLDILOCKS
+    rf = ref.RefGoldField()
+    rng = np.random.default_rng(seed)
+    logn, batch = 10, 2
+    n = 1 << logn
+    root = rf.get_root_of_unity(1 << 12)
+    assert root == pyref.omega(F, 12)
+    rf.init_domain(root)
+
+    def elems(count):
+        vals = rand_scalars(rng, count, F.p)
+        return np.ascontiguousarray(to_words(vals, 2).reshape(-1)), vals
+
+    x, xv = elems(n * batch)
+    g = rand_scalars(rng, 1, F.p)[0]
+    out = {"x": x, "domain_root": to_words([root], 2)[0], "coset_gen": to_words([g], 2)[0]}
+    out["fwd_NN"] = rf.ntt(x, n, 0, batch=batch)
+    out["inv_NN"] = rf.ntt(x, n, 1, batch=batch)
+    out["fwd_NR_coset"] = rf.ntt(x, n, 0, batch=batch, ordering=1, coset_gen=g)
+    out["inv_RN_coset"] = rf.ntt(x, n, 1, batch=batch, ordering=2, coset_gen=g)
+    out["fwd_RR"] = rf.ntt(x, n, 0, batch=batch, ordering=3)
+    out["fwd_columns"] = rf.ntt(x, n, 0, batch=batch, columns_batch=True)
+    xe, xev = elems(64 * 2)
+    out["x_ext"] = xe
+    out["fwd_ext"] = rf.ntt(xe, 64, 0, extension=True)
+    # the definition: one small row, and the extension transform component by component
+    small, sv = elems(16)
+    assert [int(v) for v in rf.ntt(small, 16, 0).view("<u8")] == pyref.ntt_naive(F, sv, pyref.omega(F, 4))
+    for k in range(2):
+        comp = pyref.ntt_naive(F, xev[k::2], pyref.omega(F, 6))
+        assert [int(v) for v in out["fwd_ext"].view("<u8")[k::2]] == comp
+    rf.release_domain()
+    return out
+
+
 def g2_fixture(cname, seed):
     """G2 MSM (reference built with G2_ENABLED): inputs, affine results"""
     C = pyref.G2_CURVES[cname]
@@ -172,6 +209,7 @@ def main():
         save(f"msm_g2_{c}.npz", lambda: g2_fixture(c, 31 + i))
         save(f"scalar_ntt_{c}.npz", lambda: scalar_ntt_fixture(c, 41 + i))
     save("scalar_ntt_stark252.npz", lambda: scalar_ntt_fixture("stark252", 44, with_ec=False))
+    save("ntt_goldilocks.npz", lambda: gold_fixture(51))
     print("golden fixtures in", HERE)
 
 

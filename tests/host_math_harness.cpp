@@ -6,6 +6,7 @@
 #include <cstring>
 #include "../icicle_amd/csrc/ec.hpp"
 #include "../icicle_amd/csrc/smallfield.hpp"
+#include "../icicle_amd/csrc/goldfield.hpp"
 
 using namespace icicle_hip;
 
@@ -126,6 +127,7 @@ extern "C" int host_field_op(int field, int op, const uint32_t* a, const uint32_
   case 4: return field_op<bls12_377_fq_params>(op, a, b, out);
   case 5: return field_op<bls12_377_fr_params>(op, a, b, out);
   case 6: return field_op<stark252_fr_params>(op, a, b, out);
+  case 7: return field_op<goldilocks_params>(op, a, b, out);
   }
   return -1;
 }

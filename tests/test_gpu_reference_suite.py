@@ -10,7 +10,7 @@ test compares the two (ASSERT_EQ on group elements for MSM / ECNTT, memcmp for N
                                  bls12_377; the MSM part of it for grumpkin
   test_mod_arithmetic_api.h      ModArithTest.{ntt, montgomeryConversion} for the base and the extension field,
                                  {vectorVectorOps, bitReverse} for the base field, ModArithTestBase.scalarVectorOps,
-                                 for babybear, koalabear, stark252 and the three pairing curves' scalar fields
+                                 for babybear, koalabear, goldilocks, stark252 and the three pairing curves' scalar fields
 Each binary runs in its own process (the reference runtime owns the process-wide icicle_* symbols) and several times:
 the reference tests draw their sizes / orderings / cosets from a time-seeded generator."""
 import os
@@ -61,9 +61,9 @@ def test_reference_curve_api_suite(hip, curve):
         assert _ran(outs[0], f"CurveApiTest.{t}"), (t, outs[0][-3000:])
 
 
-@pytest.mark.parametrize("field", ["babybear", "koalabear", "bn254", "bls12_381", "bls12_377", "stark252"])
+@pytest.mark.parametrize("field", ["babybear", "koalabear", "goldilocks", "bn254", "bls12_381", "bls12_377", "stark252"])
 def test_reference_modarith_suite(hip, field):
-    ext = field in ("babybear", "koalabear")
+    ext = field in ("babybear", "koalabear", "goldilocks")
     flt = "ModArithTest/*.ntt:ModArithTest/*.montgomeryConversion:ModArithTest/0.vectorVectorOps:ModArithTest/0.bitReverse:ModArithTestBase.scalarVectorOps"
     outs = _run(f"test_modarith_{field}", flt, repeat=6)  # 6 random draws of (logn, batch, layout, ordering, coset, in-place)
     names = ["ModArithTest/0.ntt", "ModArithTest/0.montgomeryConversion", "ModArithTest/0.vectorVectorOps", "ModArithTest/0.bitReverse",

@@ -15,14 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "_build", "libhost_math.so")
 SRC = os.path.join(HERE, "host_math_harness.cpp")
 FIELDS = {0: pyref.BN254.q, 1: pyref.BN254.r, 2: pyref.BLS12_381.q, 3: pyref.BLS12_381.r,
-          4: pyref.BLS12_377.q, 5: pyref.BLS12_377.r, 6: pyref.STARK252.p}
-NL = {0: 8, 1: 8, 2: 12, 3: 8, 4: 12, 5: 8, 6: 8}
+          4: pyref.BLS12_377.q, 5: pyref.BLS12_377.r, 6: pyref.STARK252.p, 7: pyref.GOLDILOCKS.p}
+NL = {0: 8, 1: 8, 2: 12, 3: 8, 4: 12, 5: 8, 6: 8, 7: 2}
 
 
 @pytest.fixture(scope="module")
 def lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.hpp", "fq2.hpp", "ec.hpp", "smallfield.hpp", "field_consts.h")]
+    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.hpp", "fq2.hpp", "ec.hpp", "smallfield.hpp", "goldfield.hpp", "field_consts.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-DBIGFIELD_BOUNDS", "-fPIC", "-shared", SRC, "-o", SO])
     return ctypes.CDLL(SO)
@@ -36,11 +36,11 @@ def iv(a):
     return sum(int(v) << (32 * i) for i, v in enumerate(a))
 
 
-@pytest.mark.parametrize("f", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("f", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_field_ops(lib, f):
     p, n = FIELDS[f], NL[f]
     rnd = random.Random(f)
-    special = [0, 1, 2, 3, p - 1, p - 2, (1 << 29) - 1, 1 << 29, 1 << 58, p // 2, p // 2 + 1]
+    special = [0, 1, 2, 3, p - 1, p - 2, (1 << 29) - 1, 1 << 29, 1 << 58, p // 2, p // 2 + 1, (1 << 32) - 1, 1 << 32, p - (1 << 32)]
     r32 = 1 << (32 * n)
     for it in range(600):
         a = special[it % len(special)] if it < 2 * len(special) else rnd.randrange(p)

@@ -187,3 +187,24 @@ def test_reference_test_binaries_host_arithmetic_suite():
     lst = subprocess.run([exe, "--gtest_list_tests"], capture_output=True, text=True, timeout=60).stdout
     for name in ("CurveApiTest.msm", "CurveApiTest.msm_bitsize", "CurveApiTest.msmG2", "CurveApiTest.ecntt", "CurveSanity/1.ScalarMultTest"):
         assert name in lst
+
+
+def test_reference_goldilocks_matches_golden_and_definition():
+    """pins the goldilocks fixture (8-byte elements, quadratic extension transformed component by component) to the
+    reference build and to the O(N^2) definition"""
+    if not ref.available("goldilocks"):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    F = pyref.GOLDILOCKS
+    g = np.load(os.path.join(GOLD, "ntt_goldilocks.npz"))
+    rf = ref.RefGoldField()
+    rf.init_domain(int(g["domain_root"].view("<u8")[0]))
+    try:
+        cg = int(g["coset_gen"].view("<u8")[0])
+        assert np.array_equal(rf.ntt(g["x"], 1024, 0, batch=2), g["fwd_NN"])
+        assert np.array_equal(rf.ntt(g["x"], 1024, 1, batch=2, ordering=2, coset_gen=cg), g["inv_RN_coset"])
+        assert np.array_equal(rf.ntt(g["x_ext"], 64, 0, extension=True), g["fwd_ext"])
+        row = [int(v) for v in g["x"].view("<u8")[:1024]]
+        assert [int(v) for v in g["fwd_NN"].view("<u8")[:1024]] == pyref.ntt_naive(F, row, pyref.omega(F, 10))
+        assert [int(v) for v in g["inv_RN_coset"].view("<u8")[:1024]] == pyref.ntt_naive(F, row, pyref.omega(F, 10), inverse=True, coset_gen=cg, ordering="RN")
+    finally:
+        rf.release_domain()
