@@ -240,7 +240,7 @@ icicle_error_t bn254_g2_projective_convert_montgomery(const void* input, uint64_
 icicle_error_t bls12_381_g2_affine_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 icicle_error_t bls12_381_g2_projective_convert_montgomery(const void* input, uint64_t n, bool is_into, const icicle_vec_ops_config_t* config, void* output);
 
-/* Element-wise vector operations next to the NTT path, for the four NTT fields (src/vec_ops.cpp:71-84 vector_add,
+/* Element-wise vector operations next to the NTT path, for every NTT field (src/vec_ops.cpp:71-84 vector_add,
  * :136-149 vector_sub, :169-182 vector_mul, :362-366 scalar_mul_vec -- one scalar per batch entry --, :440-444
  * bit_reverse). `size` is per batch entry; config.batch_size / columns_batch as in the reference. */
 #define ICICLE_HIP_DECLARE_VEC_ARITH(F)                                                                                \
