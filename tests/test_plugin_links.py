@@ -18,6 +18,7 @@ def test_plugin_dsos_resolve_every_symbol():
                  "field_goldilocks", "field_bn254", "field_bls12_381", "field_bls12_377", "field_grumpkin", "field_stark252"):
         assert f"libicicle_backend_hip_{want}.so" in names, want
     for p in PLUGINS:
-        out = subprocess.run(["ldd", "-r", p], capture_output=True, text=True).stdout
+        r = subprocess.run(["ldd", "-r", p], capture_output=True, text=True)
+        out = r.stdout + r.stderr
         assert "not found" not in out, (p, out)
         assert "undefined symbol" not in out, (p, [l for l in out.splitlines() if "undefined" in l][:5])
