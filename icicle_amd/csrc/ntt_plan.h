@@ -45,6 +45,9 @@ namespace icicle_hip {
     // flagged "relative" holds only the current group (its row r lives at offset of row r - row0)
     uint32_t row0 = 0, nrows_launch = 0;
     int src_rel = 0, dst_rel = 0;
+    // lane-native tiles (ntt_fast.hpp, LN): `ltot` transforms interleaved word by word, a launch row = one slice of
+    // 2^lsh of them; `lanes` then counts the slices per row group: offset(r) = (r / lanes) * bs + ((r % lanes) << lsh)
+    uint32_t lsh = 0, ltot = 1;
   };
 
 #if defined(__HIPCC__)

@@ -67,6 +67,30 @@ def ntt_case(field, logn, batch):
     N.release_domain(field)
 
 
+def ntt_layout_case(field, logn, batch, layout, ordering=0):
+    """the interleaved layouts next to the row-major batch of the same byte count: layout = "rows" | "columns" (columns_batch,
+    element j of transform b at j * batch + b) | "ext" (batch rows of quartic-extension elements = 4 * batch lane transforms)"""
+    n = 1 << logn
+    N.init_domain(field, N.get_root_of_unity(field, n))
+    p = {"babybear": 0x78000001, "koalabear": 0x7F000001}[field]
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    lanes = 4 if layout == "ext" else 1
+    x = torch.randint(0, p, (batch * n * lanes,), dtype=torch.int32, device=dev, generator=g)
+    y = torch.empty_like(x)
+    cfg = NTTConfigU32.default()
+    cfg.batch_size = batch
+    cfg.is_async = True
+    cfg.columns_batch = layout == "columns"
+    cfg.ordering = ordering
+    row = []
+    for d in (N.FORWARD, N.INVERSE):
+        ms = time_it(lambda: N.ntt(field, x.data_ptr(), d, cfg, out=y.data_ptr(), size=n, extension=layout == "ext"))
+        row.append(f"{'fwd' if d == N.FORWARD else 'inv'} {ms:8.3f} ms {2 * x.numel() * 4 / ms / 1e6:6.0f} GB/s")
+    print(f"ntt {field:10s} 2^{logn:<2d} x {batch:<5d} {layout:8s} ordering {ordering}: " + ", ".join(row), flush=True)
+    N.release_domain(field)
+
+
 def ntt_scalar_case(field, logn, batch):
     """NTT over the curve's 256-bit scalar field; inputs are any words < 2^253 (valid canonical elements)"""
     n = 1 << logn
@@ -241,6 +265,17 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ntt":
         for logn, batch in ((12, 4096), (16, 1024), (20, 256), (22, 128), (24, 64), (24, 8), (25, 32), (26, 16), (27, 8), (27, 4)):
             ntt_case("babybear", logn, batch)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "layouts":  # interleaved layouts vs the row-major batch of the same bytes
+        for field, logn, b in (("koalabear", 22, 64), ("babybear", 22, 32), ("babybear", 16, 1024), ("babybear", 24, 16), ("babybear", 20, 100)):
+            ntt_layout_case(field, logn, b, "rows")
+            ntt_layout_case(field, logn, b, "columns")
+            if b % 4 == 0:
+                ntt_layout_case(field, logn, b // 4, "ext")
+        ntt_layout_case("babybear", 22, 8, "ext")
+        for layout in ("rows", "columns"):  # bit-reversed output / input
+            ntt_layout_case("babybear", 22, 64, layout, ordering=1)
+            ntt_layout_case("babybear", 22, 64, layout, ordering=2)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "criterion":
         criterion_sweep()
