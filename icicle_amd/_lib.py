@@ -200,6 +200,8 @@ API_SYMBOLS = (
     + [f"icicle_hip_{GOLD}_{s}" for s in ("ntt", "extension_ntt", "ntt_init_domain", "ntt_release_domain", "get_root_of_unity_from_domain")]
     + [f"{pre}{f}_{op}" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + BIG_VEC_FIELDS + [GOLD]
        for op in ("vector_add", "vector_sub", "vector_mul", "scalar_mul_vec", "scalar_add_vec", "scalar_sub_vec", "bit_reverse")]
+    + [f"{pre}{f}_matrix_transpose" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + BIG_VEC_FIELDS + [GOLD]]
+    + [f"{pre}{f}_extension_matrix_transpose" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + [GOLD]]
     + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
        "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_selftest_inplace_products", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
        "icicle_hip_msm_release_resident_bases", "icicle_hip_multi_stats", "icicle_hip_test_set_virtual_devices",
@@ -285,6 +287,8 @@ for _f in NTT_FIELDS + BIG_VEC_FIELDS + [GOLD]:
         getattr(lib, f"{_f}_{_op}").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
     getattr(lib, f"{_f}_bit_reverse").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
 for _n in API_SYMBOLS:
+    if _n.endswith("matrix_transpose"):
+        getattr(lib, _n).argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
     if _n.endswith("convert_montgomery"):
         getattr(lib, _n).argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_bool, ctypes.POINTER(VecOpsConfig), ctypes.c_void_p]
 lib.icicle_hip_kernel_timing.argtypes = [ctypes.c_int, ctypes.c_bool, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

@@ -196,6 +196,68 @@ namespace icicle_hip {
     return finish_out(out, d_out, cfg->is_result_on_device, cfg->is_async, bytes, st);
   }
 
+  // ---- matrix_transpose (icicle/src/matrix_ops.cpp:73-102, backend/cpu/src/field/cpu_matrix_ops.cpp:175-201,333-362) ----------
+  // out[b][c][r] = in[b][r][c] for batch_size row-major nof_rows x nof_cols matrices of W-word elements. 32 x 32-element
+  // tiles through LDS: both sides move runs of 32 * W contiguous words. The Rust NTT suite calls it on the main device
+  // around every columns_batch transform (wrappers/rust/icicle-core/src/ntt/tests.rs:311-335).
+  template <int W>
+  __global__ __launch_bounds__(256) void k_transpose(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t rows, uint32_t cols, uint32_t tiles_c, uint32_t batch)
+  {
+    constexpr uint32_t RW = 32 * W; // words per tile row
+    __shared__ uint32_t tile[32][RW + 1];
+    const uint32_t tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const uint32_t r0 = tr * 32, c0 = tc * 32;
+    const uint32_t nr = min(32u, rows - r0), nc = min(32u, cols - c0);
+    const uint64_t mat_words = (uint64_t)rows * cols * W;
+    for (uint32_t b = blockIdx.y; b < batch; b += gridDim.y) {
+      const uint32_t* pi = in + b * mat_words + ((uint64_t)r0 * cols + c0) * W;
+      uint32_t* po = out + b * mat_words + ((uint64_t)c0 * rows + r0) * W;
+#pragma unroll
+      for (uint32_t e = threadIdx.x; e < 32 * RW; e += 256) {
+        const uint32_t r = e / RW, k = e % RW;
+        if (r < nr && k < nc * W) tile[r][k] = pi[(uint64_t)r * cols * W + k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t e = threadIdx.x; e < 32 * RW; e += 256) {
+        const uint32_t c = e / RW, k = e % RW, r = k / W, w = k % W;
+        if (c < nc && r < nr) po[(uint64_t)c * rows * W + k] = tile[r][c * W + w];
+      }
+      __syncthreads();
+    }
+  }
+
+  template <int W>
+  static icicle_error_t transpose_run(const void* in, uint32_t rows, uint32_t cols, const icicle_vec_ops_config_t* cfg, void* out)
+  {
+    if (!cfg) return ICICLE_INVALID_POINTER;
+    if (!in || !out || rows == 0 || cols == 0) return ICICLE_INVALID_ARGUMENT; // cpu_matrix_ops.cpp:337-340
+    if (cfg->columns_batch) return ICICLE_INVALID_ARGUMENT;                    // :342-345
+    ICICLE_TRY(bind_current_device());
+    hipStream_t st = (hipStream_t)cfg->stream;
+    const uint32_t batch = (uint32_t)std::max(1, cfg->batch_size);
+    const size_t bytes = (size_t)rows * cols * batch * W * 4;
+    Staged si;
+    ICICLE_TRY(si.in(in, cfg->is_a_on_device, bytes, st));
+    TempBuf d_out_tmp;
+    uint32_t* d_out = (uint32_t*)out;
+    // out of place on the device; an in-place call (cpu_matrix_ops.cpp:348-359 supports it) goes through a temporary
+    const bool need_tmp = !cfg->is_result_on_device || (const void*)si.dev == (const void*)out;
+    if (need_tmp) {
+      HIP_TRY(d_out_tmp.alloc(bytes, st), ICICLE_ALLOCATION_FAILED);
+      d_out = d_out_tmp.as<uint32_t>();
+    }
+    const uint64_t tiles_r = ((uint64_t)rows + 31) / 32, tiles_c = ((uint64_t)cols + 31) / 32;
+    if (tiles_r * tiles_c > 0x7fffffffull) return ICICLE_INVALID_ARGUMENT;
+    k_transpose<W><<<dim3((unsigned)(tiles_r * tiles_c), std::min(batch, 65535u)), 256, 0, st>>>(si.dev, d_out, rows, cols, (uint32_t)tiles_c, batch);
+    LAUNCH_CHECK("k_transpose", st);
+    if (cfg->is_result_on_device && need_tmp) {
+      HIP_TRY(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToDevice, st), ICICLE_COPY_FAILED);
+      d_out = (uint32_t*)out;
+    }
+    return finish_out(out, d_out, cfg->is_result_on_device, cfg->is_async, bytes, st);
+  }
+
 } // namespace icicle_hip
 
 using namespace icicle_hip;
@@ -231,3 +293,19 @@ DEFINE_VEC_ARITH(bls12_377, BigElem<bls12_377_fr_params>, 8)
 DEFINE_VEC_ARITH(grumpkin, BigElem<bn254_fq_params>, 8)
 DEFINE_VEC_ARITH(stark252, BigElem<stark252_fr_params>, 8)
 DEFINE_VEC_ARITH(goldilocks, GoldElem, 2)
+
+// matrix_transpose / extension_matrix_transpose (icicle/src/matrix_ops.cpp:75-102): W = u32 words per element
+#define DEFINE_TRANSPOSE(NAME, SUFFIX, W)                                                                              \
+  extern "C" icicle_error_t NAME##_##SUFFIX(const void* i, uint32_t r, uint32_t c, const icicle_vec_ops_config_t* cfg, void* o) { GUARDED((transpose_run<W>(i, r, c, cfg, o))); } \
+  extern "C" icicle_error_t icicle_hip_##NAME##_##SUFFIX(const void* i, uint32_t r, uint32_t c, const icicle_vec_ops_config_t* cfg, void* o) { GUARDED((transpose_run<W>(i, r, c, cfg, o))); }
+DEFINE_TRANSPOSE(babybear, matrix_transpose, 1)
+DEFINE_TRANSPOSE(koalabear, matrix_transpose, 1)
+DEFINE_TRANSPOSE(babybear, extension_matrix_transpose, 4)
+DEFINE_TRANSPOSE(koalabear, extension_matrix_transpose, 4)
+DEFINE_TRANSPOSE(goldilocks, matrix_transpose, 2)
+DEFINE_TRANSPOSE(goldilocks, extension_matrix_transpose, 4)
+DEFINE_TRANSPOSE(bn254, matrix_transpose, 8)
+DEFINE_TRANSPOSE(bls12_381, matrix_transpose, 8)
+DEFINE_TRANSPOSE(bls12_377, matrix_transpose, 8)
+DEFINE_TRANSPOSE(grumpkin, matrix_transpose, 8)
+DEFINE_TRANSPOSE(stark252, matrix_transpose, 8)

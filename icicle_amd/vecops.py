@@ -91,3 +91,16 @@ def bit_reverse(field, inp, cfg=None, out=None, size=None):
     op_, cfg.is_result_on_device = _ptr(out)
     check(getattr(lib, f"{field}_bit_reverse")(ip, size, ctypes.byref(cfg), op_), f"{field}_bit_reverse")
     return out
+
+
+def matrix_transpose(field, inp, nof_rows: int, nof_cols: int, cfg=None, out=None, extension: bool = False):
+    """batch_size row-major nof_rows x nof_cols matrices -> their transposes (icicle/include/icicle/vec_ops.h:319,
+    src/matrix_ops.cpp:75-102); in place allowed, columns_batch rejected like the reference CPU backend does"""
+    cfg = cfg or VecOpsConfig.default()
+    ip, cfg.is_a_on_device = _ptr(inp)
+    if out is None:
+        out = np.zeros_like(inp)
+    op_, cfg.is_result_on_device = _ptr(out)
+    name = f"{field}_extension_matrix_transpose" if extension else f"{field}_matrix_transpose"
+    check(getattr(lib, name)(ip, nof_rows, nof_cols, ctypes.byref(cfg), op_), name)
+    return out

@@ -263,6 +263,25 @@ ICICLE_HIP_DECLARE_VEC_ARITH(koalabear)
 ICICLE_HIP_DECLARE_VEC_ARITH(bn254)
 ICICLE_HIP_DECLARE_VEC_ARITH(bls12_381)
 
+/* Matrix transpose of batch_size row-major nof_rows x nof_cols matrices (icicle/src/matrix_ops.cpp:75-102,
+ * include/icicle/vec_ops.h:319; CPU: backend/cpu/src/field/cpu_matrix_ops.cpp:333-362): in place allowed, columns_batch
+ * rejected. The Rust NTT suite calls it on the main device around every columns_batch transform
+ * (wrappers/rust/icicle-core/src/ntt/tests.rs:311-335). */
+#define ICICLE_HIP_DECLARE_TRANSPOSE(F, S)                                                                             \
+  icicle_error_t F##_##S(const void* mat_in, uint32_t nof_rows, uint32_t nof_cols, const icicle_vec_ops_config_t* config, void* mat_out); \
+  icicle_error_t icicle_hip_##F##_##S(const void* mat_in, uint32_t nof_rows, uint32_t nof_cols, const icicle_vec_ops_config_t* config, void* mat_out);
+ICICLE_HIP_DECLARE_TRANSPOSE(babybear, matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(koalabear, matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(babybear, extension_matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(koalabear, extension_matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(goldilocks, matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(goldilocks, extension_matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(bn254, matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(bls12_381, matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(bls12_377, matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(grumpkin, matrix_transpose)
+ICICLE_HIP_DECLARE_TRANSPOSE(stark252, matrix_transpose)
+
 /* ---- backend-specific helpers (not part of the reference ABI) ---- */
 const char* icicle_hip_version(void);
 /* The window plan msm() would use for this size / config: c = window bits, nwin = number of c-bit windows of a

@@ -9,7 +9,7 @@
 #   test_modarith_{babybear,koalabear,goldilocks,bn254,bls12_381,bls12_377,stark252}  icicle/tests/test_mod_arithmetic_api.h via oracle/shim/tests/modarith_main.cpp
 #   example_msm, example_ntt             examples/c++/{msm,ntt}/example.cpp (bn254), run as `example_msm HIP`
 #   example_best_practice_ntt            examples/c++/best-practice-ntt/example.cpp (three streams)
-# Run with ICICLE_BACKEND_INSTALL_DIR=oracle/_ref/backend so that the reference runtime loads the HIP plugin and makes
+# Run with ICICLE_BACKEND_INSTALL_DIR=plugin/lib/backend so that the reference runtime loads the HIP plugin and makes
 # "HIP" the main device (icicle/tests/test_base.h:37-46): tests/test_gpu_reference_suite.py.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -47,6 +47,13 @@ for spec in babybear:1001 koalabear:1004 goldilocks:1005; do
   newer "$OUT/test_modarith_$f" || { echo "[ref-tests] test_modarith_$f"
     $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$f -DICICLE_FFI_PREFIX=$f -DNTT=ON -DEXT_FIELD=ON \
       "$HERE/shim/tests/modarith_main.cpp" -L"$REF" -licicle_field_$f -licicle_device $RP -o "$OUT/test_modarith_$f" & }
+done
+# MatrixTest.matrixTranspose (tests/test_matrix_api.h:450-505) for one field of every element width
+for spec in babybear:1001:-DEXT_FIELD=ON koalabear:1004:-DEXT_FIELD=ON goldilocks:1005:-DEXT_FIELD=ON bn254:1:; do
+  f=${spec%%:*}; rest=${spec#*:}; id=${rest%%:*}; extra=${rest#*:}
+  newer "$OUT/test_matrix_$f" || { echo "[ref-tests] test_matrix_$f"
+    $CXX $FLAGS -DFIELD_ID=$id -DFIELD=$f -DICICLE_FFI_PREFIX=$f -DNTT=ON $extra \
+      "$HERE/shim/tests/matrix_main.cpp" -L"$REF" -licicle_field_$f -licicle_device $RP -o "$OUT/test_matrix_$f" & }
 done
 # the reference's C++ examples for this path, unmodified (examples/c++/msm/example.cpp, examples/c++/ntt/example.cpp):
 # `example_msm HIP` / `example_ntt HIP` select the device by name exactly as a user of the reference would

@@ -310,6 +310,16 @@ class RefNttField:
         assert rc == 0, f"reference ntt failed rc={rc}"
         return out
 
+    def matrix_transpose(self, inp: np.ndarray, nof_rows: int, nof_cols: int, batch=1, extension=False, inplace=False) -> np.ndarray:
+        """<field>_matrix_transpose / _extension_matrix_transpose (icicle/src/matrix_ops.cpp:75-102) on the active device"""
+        cfg = VecOpsConfig(None, False, False, False, False, batch, False, None)
+        out = inp if inplace else np.zeros_like(inp)
+        fn = getattr(self.lib, f"{self.name}_extension_matrix_transpose" if extension else f"{self.name}_matrix_transpose")
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        rc = fn(_p(inp), nof_rows, nof_cols, ctypes.byref(cfg), _p(out))
+        assert rc == 0, f"reference matrix_transpose failed rc={rc}"
+        return out
+
     def ntt_device(self, d_in, d_out, size: int, direction: int, batch=1, ordering=0, coset_gen=1) -> int:
         """device-resident operands allocated through the reference runtime (icicle_malloc)"""
         cfg = NTTConfigU32(None, coset_gen, batch, False, ordering, True, True, False, None)

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Builds the reference-runtime plugin DSOs (the drop-in form of this backend) against the reference
 # headers and the reference libraries built by oracle/build_ref.sh. Needs /root/reference; outputs
-# travel to the GPU box under oracle/_ref/backend/hip/ (git-ignored):
+# travel to the GPU box under plugin/lib/backend/hip/ (git-ignored; nothing the product ships lives under oracle/):
 #   libicicle_backend_hip_device.so           "HIP" DeviceAPI            (RTLD_GLOBAL by name)
 #   libicicle_backend_hip_curve_<c>.so        msm + msm_precompute_bases
 #   libicicle_backend_hip_field_<f>.so        ntt family + extension ntt
@@ -10,7 +10,8 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(dirname "$HERE")"
 R="${ICICLE_REFERENCE_DIR:-/root/reference}/icicle"
 REF="$ROOT/oracle/_ref"
-OUT="$REF/backend/hip"
+OUT="$HERE/lib/backend/hip"
+rm -rf "$REF/backend" # (rounds 1-3 installed the plugin inside the oracle tree)
 HIPLIB="$ROOT/icicle_amd/lib"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 if [ ! -d "$R" ]; then echo "build_plugin: $R not present -- using prebuilt plugin if any" >&2; exit 0; fi
@@ -18,7 +19,7 @@ if [ ! -d "$R" ]; then echo "build_plugin: $R not present -- using prebuilt plug
 mkdir -p "$OUT"
 FLAGS="-std=c++17 -O2 -fPIC -shared -w -I$R/include"
 CXX="${ORACLE_CXX:-/opt/rocm/lib/llvm/bin/clang++}"   # curve/field parts are plain C++ (no HIP headers)
-RP="-Wl,-rpath,\$ORIGIN/../..:\$ORIGIN/../../../../icicle_amd/lib"
+RP="-Wl,-rpath,\$ORIGIN/../../../../oracle/_ref:\$ORIGIN/../../../../icicle_amd/lib" # the reference runtime that loads us + libicicle_hip.so
 echo "[plugin] device"
 # host-only C++ against the HIP runtime API (no kernels here): plain clang++, the HIP headers need the platform define
 $CXX $FLAGS -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$HERE/hip_backend_device.cpp" -L"$REF" -licicle_device -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib $RP -o "$OUT/libicicle_backend_hip_device.so"

@@ -71,6 +71,29 @@ REGISTER_SCALAR_ADD_VEC_BACKEND("HIP", hip_scalar_add_vec);
 REGISTER_SCALAR_SUB_VEC_BACKEND("HIP", hip_scalar_sub_vec);
 REGISTER_BIT_REVERSE_BACKEND("HIP", hip_bit_reverse);
 
+// matrix_transpose (icicle/include/icicle/backend/vec_ops_backend.h:33-39,204-212; src/matrix_ops.cpp:73-85): the Rust NTT
+// suite transposes on the MAIN device around every columns_batch transform (wrappers/rust/icicle-core/src/ntt/tests.rs:311-335)
+static eIcicleError hip_matrix_transpose(const Device& device, const scalar_t* in, uint32_t nof_rows, uint32_t nof_cols, const VecOpsConfig& config, scalar_t* out)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  hip_vec_ops_config_t c;
+  std::memcpy(&c, &config, sizeof(c));
+  c.ext = nullptr;
+  return (eIcicleError)HIP_FN(matrix_transpose)(in, nof_rows, nof_cols, &c, out);
+}
+REGISTER_MATRIX_TRANSPOSE_BACKEND("HIP", hip_matrix_transpose);
+#ifdef EXT_FIELD
+static eIcicleError hip_ext_matrix_transpose(const Device& device, const extension_t* in, uint32_t nof_rows, uint32_t nof_cols, const VecOpsConfig& config, extension_t* out)
+{
+  if (icicle_hip_set_device(device.id) != 0) return eIcicleError::INVALID_DEVICE;
+  hip_vec_ops_config_t c;
+  std::memcpy(&c, &config, sizeof(c));
+  c.ext = nullptr;
+  return (eIcicleError)HIP_FN(extension_matrix_transpose)(in, nof_rows, nof_cols, &c, out);
+}
+REGISTER_MATRIX_TRANSPOSE_EXT_FIELD_BACKEND("HIP", hip_ext_matrix_transpose);
+#endif
+
 #ifdef NTT // (Grumpkin's scalar field has none: icicle/cmake/features.cmake:19)
 #ifdef HIP_PLUGIN_SCALAR_FIELD_256
 typedef hip_ntt_config_u256_t hip_ntt_config_t;

@@ -126,6 +126,18 @@ HIP_DECLARE_VEC_ARITH(bls12_377)
 HIP_DECLARE_VEC_ARITH(grumpkin)
 HIP_DECLARE_VEC_ARITH(stark252)
 HIP_DECLARE_VEC_ARITH(goldilocks)
+#define HIP_DECLARE_TRANSPOSE(F, S) int icicle_hip_##F##_##S(const void*, uint32_t, uint32_t, const hip_vec_ops_config_t*, void*);
+HIP_DECLARE_TRANSPOSE(babybear, matrix_transpose)
+HIP_DECLARE_TRANSPOSE(koalabear, matrix_transpose)
+HIP_DECLARE_TRANSPOSE(babybear, extension_matrix_transpose)
+HIP_DECLARE_TRANSPOSE(koalabear, extension_matrix_transpose)
+HIP_DECLARE_TRANSPOSE(goldilocks, matrix_transpose)
+HIP_DECLARE_TRANSPOSE(goldilocks, extension_matrix_transpose)
+HIP_DECLARE_TRANSPOSE(bn254, matrix_transpose)
+HIP_DECLARE_TRANSPOSE(bls12_381, matrix_transpose)
+HIP_DECLARE_TRANSPOSE(bls12_377, matrix_transpose)
+HIP_DECLARE_TRANSPOSE(grumpkin, matrix_transpose)
+HIP_DECLARE_TRANSPOSE(stark252, matrix_transpose)
 HIP_DECLARE_CONVERT(goldilocks)
 int icicle_hip_goldilocks_extension_scalar_convert_montgomery(const void*, uint64_t, bool, const hip_vec_ops_config_t*, void*);
 int icicle_hip_goldilocks_ntt(const uint32_t*, int, int, const hip_ntt_config_u64_t*, uint32_t*);

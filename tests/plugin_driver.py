@@ -22,7 +22,7 @@ def main():
     field = ref.RefNttField("babybear")
     koala = ref.RefNttField("koalabear")
     assert "HIP" not in rt.registered_devices()
-    assert rt.load_backend(os.path.join(ref.REF_DIR, "backend", "hip")) == 0
+    assert rt.load_backend(os.path.join(ROOT, "plugin", "lib", "backend", "hip")) == 0
     devs = rt.registered_devices()
     assert "HIP" in devs and "CPU" in devs, devs
 
@@ -118,6 +118,32 @@ def main():
         assert rt.set_device("CPU", 0) == 0
         cpu_res = [vec2(op, va, vb) for op in ("vector_add", "vector_sub", "vector_mul", "bit_reverse")]
         assert all(np.array_equal(h, c) for h, c in zip(hip_res, cpu_res))
+        assert rt.set_device("HIP", 0) == 0
+        # the Rust suite's check_ntt_batch (wrappers/rust/icicle-core/src/ntt/tests.rs:255-340), everything on the MAIN
+        # device: a batch == its single transforms, and transpose -> columns_batch transform -> transpose == the batch
+        assert rt.set_device("HIP", 0) == 0
+        for test_size in (1 << 4, 1 << 12):
+            for bsz in (1, 1 << 4, 100):
+                sc_in = rng.integers(0, F.p, size=test_size * bsz, dtype=np.uint32)
+                for coset in (1, int(rng.integers(2, F.p))):
+                    for direction in (1, 0):
+                        for ordering in range(6):
+                            batch_res = fobj.ntt(sc_in, test_size, direction, batch=bsz, ordering=ordering, coset_gen=coset)
+                            for i in (0, bsz // 2, bsz - 1):
+                                one = fobj.ntt(sc_in[i * test_size:(i + 1) * test_size].copy(), test_size, direction, ordering=ordering, coset_gen=coset)
+                                assert np.array_equal(batch_res[i * test_size:(i + 1) * test_size], one)
+                            t_in = fobj.matrix_transpose(sc_in, bsz, test_size)
+                            col_res = fobj.ntt(t_in, test_size, direction, batch=bsz, columns_batch=True, ordering=ordering, coset_gen=coset)
+                            back = fobj.matrix_transpose(col_res, test_size, bsz)
+                            assert np.array_equal(batch_res, back), (fobj.name, test_size, bsz, coset, direction, ordering)
+        # matrix_transpose itself: batched, in place, extension elements; "HIP" vs "CPU"
+        m = rng.integers(0, F.p, size=3 * 37 * 50 * 4, dtype=np.uint32)
+        hip_t = [fobj.matrix_transpose(m, 37, 200, batch=3), fobj.matrix_transpose(m.copy(), 64, 128, batch=1, inplace=True)[: 64 * 128],
+                 fobj.matrix_transpose(m, 37, 50, batch=3, extension=True)]
+        assert rt.set_device("CPU", 0) == 0
+        cpu_t = [fobj.matrix_transpose(m, 37, 200, batch=3), fobj.matrix_transpose(m.copy(), 64, 128, batch=1, inplace=True)[: 64 * 128],
+                 fobj.matrix_transpose(m, 37, 50, batch=3, extension=True)]
+        assert all(np.array_equal(h, c) for h, c in zip(hip_t, cpu_t))
         assert rt.set_device("HIP", 0) == 0
         rc, d_in = rt.malloc(x.nbytes)
         rc, d_out = rt.malloc(x.nbytes)

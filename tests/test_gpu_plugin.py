@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_reference_runtime_loads_hip_backend_and_matches_cpu(hip):
-    plug = os.path.join(ROOT, "oracle", "_ref", "backend", "hip", "libicicle_backend_hip_device.so")
+    plug = os.path.join(ROOT, "plugin", "lib", "backend", "hip", "libicicle_backend_hip_device.so")
     if not os.path.exists(plug):
         pytest.skip("plugin not built (plugin/build_plugin.sh needs /root/reference)")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "plugin_driver.py")], capture_output=True, text=True, timeout=900)

@@ -21,7 +21,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TESTS = os.path.join(ROOT, "oracle", "_ref", "tests")
-BACKEND = os.path.join(ROOT, "oracle", "_ref", "backend")
+BACKEND = os.path.join(ROOT, "plugin", "lib", "backend")
 
 
 def _run(binary, gfilter, repeat=1, timeout=900):
@@ -70,6 +70,16 @@ def test_reference_modarith_suite(hip, field):
              "ModArithTestBase.scalarVectorOps"] + (["ModArithTest/1.ntt", "ModArithTest/1.montgomeryConversion"] if ext else [])
     for t in names:
         assert _ran(outs[0], t), (t, outs[0][-3000:])
+
+
+@pytest.mark.parametrize("field", ["babybear", "koalabear", "goldilocks", "bn254"])
+def test_reference_matrix_transpose_suite(hip, field):
+    """MatrixTest.matrixTranspose (icicle/tests/test_matrix_api.h:450-505): 3 x (128 x 256) out of place and in place on every
+    registered device, memcmp'd with a host loop -- for scalar_t and, where the field has one, extension_t"""
+    out = _run(f"test_matrix_{field}", "MatrixTest/*.matrixTranspose")[0]
+    names = ["MatrixTest/0.matrixTranspose"] + (["MatrixTest/1.matrixTranspose"] if field != "bn254" else [])
+    for t in names:
+        assert _ran(out, t), (t, out[-3000:])
 
 
 @pytest.mark.parametrize("example", ["msm", "ntt", "best_practice_ntt"])

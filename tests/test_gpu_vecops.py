@@ -168,3 +168,42 @@ def test_polynomial_product_pipeline_on_device(hip):
         assert [int(v) for v in got] == [int(v) % F.p for v in exp]
     finally:
         N.release_domain("babybear")
+
+
+@pytest.mark.parametrize("field,words,ext_words", [("babybear", 1, 4), ("koalabear", 1, 4), ("goldilocks", 2, 4), ("bn254", 8, 0), ("stark252", 8, 0)])
+def test_matrix_transpose(hip, field, words, ext_words):
+    """<field>_matrix_transpose / _extension_matrix_transpose through the C ABI (icicle/src/matrix_ops.cpp:75-102): batches of
+    ragged and tile-aligned matrices, host and device operands, in place (cpu_matrix_ops.cpp:348-359), and the argument errors
+    of cpu_matrix_ops.cpp:337-345. Pure data movement: the expected bytes are numpy's transpose of the same words (the reference
+    CPU backend's own out-of-place loop, cpu_matrix_ops.cpp:184-196, is that definition; it is run on the same inputs through the
+    reference runtime in tests/plugin_driver.py)."""
+    from icicle_amd import vecops as V
+    from icicle_amd.runtime import DeviceVec
+
+    rng = np.random.default_rng(17)
+    for w, ext in ((words, False),) + (((ext_words, True),) if ext_words else ()):
+        for rows, cols, batch in ((1, 1, 1), (37, 200, 3), (128, 256, 3), (1000, 33, 2), (32, 32, 70000 if w == 1 else 5), (4096, 100, 1)):
+            x = rng.integers(0, 1 << 32, size=(batch, rows, cols, w), dtype=np.uint64).astype(np.uint32)
+            exp = np.ascontiguousarray(x.transpose(0, 2, 1, 3))
+            cfg = hip.VecOpsConfig.default()
+            cfg.batch_size = batch
+            got = V.matrix_transpose(field, x.reshape(-1), rows, cols, cfg, extension=ext)
+            assert np.array_equal(got, exp.reshape(-1)), (field, ext, rows, cols, batch)
+        # device operands: out of place, then in place
+        rows, cols, batch = 300, 77, 4
+        x = rng.integers(0, 1 << 32, size=(batch, rows, cols, w), dtype=np.uint64).astype(np.uint32)
+        exp = np.ascontiguousarray(x.transpose(0, 2, 1, 3)).reshape(-1)
+        cfg = hip.VecOpsConfig.default()
+        cfg.batch_size = batch
+        d_in, d_out = DeviceVec.from_host(x.reshape(-1)), DeviceVec.from_host(np.zeros(x.size, dtype=np.uint32))
+        V.matrix_transpose(field, d_in, rows, cols, cfg, out=d_out, extension=ext)
+        assert np.array_equal(d_out.to_host(), exp)
+        V.matrix_transpose(field, d_in, rows, cols, cfg, out=d_in, extension=ext)
+        assert np.array_equal(d_in.to_host(), exp)
+    x = np.zeros(64 * words, dtype=np.uint32)
+    cfg = hip.VecOpsConfig.default()
+    cfg.columns_batch = True
+    with pytest.raises(hip.IcicleError):  # cpu_matrix_ops.cpp:342-345
+        V.matrix_transpose(field, x, 8, 8, cfg)
+    with pytest.raises(hip.IcicleError):  # :337-340
+        V.matrix_transpose(field, x, 0, 8)

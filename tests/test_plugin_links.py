@@ -1,4 +1,4 @@
-"""CPU: every reference-runtime plugin DSO (plugin/build_plugin.sh -> oracle/_ref/backend/hip) resolves all of its symbols
+"""CPU: every reference-runtime plugin DSO (plugin/build_plugin.sh -> plugin/lib/backend/hip) resolves all of its symbols
 against libicicle_hip.so and the reference libraries it is linked to -- a missing `icicle_hip_<prefix>_*` alias for a curve or
 field would otherwise only surface at call time on the GPU box (lazy binding)."""
 import glob
@@ -8,7 +8,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PLUGINS = sorted(glob.glob(os.path.join(ROOT, "oracle", "_ref", "backend", "hip", "libicicle_backend_hip_*.so")))
+PLUGINS = sorted(glob.glob(os.path.join(ROOT, "plugin", "lib", "backend", "hip", "libicicle_backend_hip_*.so")))
 
 
 @pytest.mark.skipif(not PLUGINS, reason="plugin not built (needs /root/reference)")
