@@ -1042,38 +1042,93 @@ namespace icicle_hip {
     }
   }
 
-  // msm_precompute_bases: out[pf*i + j] = 2^(j*shift) * P_i  (cpu_msm.hpp:455-480), shift = c*wpf
+  // msm_precompute_bases: out[pf*i + j] = 2^(j*shift) * P_i  (cpu_msm.hpp:455-480), shift = c*wpf.
+  // One Jacobian doubling chain per base (dbl-2009-l, 2M + 5S) and ONE field inversion per thread: a thread walks `pt`
+  // bases, keeps the (pf-1)*pt Jacobian outputs (X, Y, Z and the running product of the Z's) in its scratch arrays and
+  // converts them with Montgomery's trick -- rounds 1-3 paid a Fermat inversion (~314 products, as much as 45 doublings) per
+  // OUTPUT point: 59 % of the kernel at pf = 8. What is left is the doublings themselves: ~254 (pf-1)/pf per base, ~960
+  // v_mad_u64_u32 each (profiles/r04_notes.md has the arithmetic: 2^24 bases x pf 4 = 3.1e12 mads = 135 ms at the issue roof).
+  constexpr int PRECOMP_MAX_OUT = 32; // outputs per thread held for the shared inversion
   template <class C>
-  __global__ __launch_bounds__(64) void k_precompute(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, int pf, int shift, bool refmont)
+  __device__ __forceinline__ void store_point_words(uint32_t* __restrict__ dst, const uint32_t* w)
+  {
+    constexpr int PW = 2 * EC<C>::N32; // 16 / 24 / 32 / 48 words: always a multiple of 4, points are PW*4-byte aligned
+#pragma unroll
+    for (int k = 0; k < PW; k += 4)
+      *reinterpret_cast<uint4*>(dst + k) = make_uint4(w[k], w[k + 1], w[k + 2], w[k + 3]);
+  }
+  template <class C>
+  __global__ __launch_bounds__(64) void k_precompute(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, int pf, int shift, bool refmont, int pt, bool aligned16)
   {
     using E = EC<C>;
     using F = typename E::F;
+    using fe = typename F::fe;
     constexpr int PW = 2 * E::N32;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t w[PW];
-    for (int k = 0; k < PW; k++) {
-      w[k] = in[(size_t)i * PW + k];
-      out[(size_t)i * pf * PW + k] = w[k];
-    }
-    typename E::Proj p;
-    if (E::words_are_zero(w)) {
-      p = E::proj_identity();
-    } else {
-      typename E::Aff a;
-      a.x = refmont ? F::from_refmont(w) : F::from_canonical(w);
-      a.y = refmont ? F::from_refmont(w + E::N32) : F::from_canonical(w + E::N32);
-      p = E::to_proj(a);
-    }
-    for (int j = 1; j < pf; j++) {
-      typename E::Jac jp = E::to_jac(p);
-      for (int s = 0; s < shift; s++)
-        jp = E::dbl_jac(jp);
-      p = E::from_jac(jp);
-      uint32_t o[PW];
-      store_affine<C>(o, p, refmont);
+    const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * pt;
+    if (i0 >= n) return;
+    fe xs[PRECOMP_MAX_OUT], ys[PRECOMP_MAX_OUT], zs[PRECOMP_MAX_OUT], pre[PRECOMP_MAX_OUT]; // (dynamically indexed: scratch)
+    int slot[PRECOMP_MAX_OUT];                                                              // output point index of entry k
+    int cnt = 0;
+    fe acc = F::one();
+    auto put = [&](long long idx, const uint32_t* w) {
+      uint32_t* dst = out + (size_t)idx * PW;
+      if (aligned16) {
+        store_point_words<C>(dst, w);
+      } else {
+        for (int k = 0; k < PW; k++)
+          dst[k] = w[k];
+      }
+    };
+    for (int q = 0; q < pt && i0 + q < n; q++) {
+      const long long i = i0 + q;
+      uint32_t w[PW];
       for (int k = 0; k < PW; k++)
-        out[((size_t)i * pf + j) * PW + k] = o[k];
+        w[k] = in[(size_t)i * PW + k];
+      put(i * pf, w);
+      const bool zero_in = E::words_are_zero(w);
+      typename E::Jac jp;
+      if (!zero_in) {
+        jp.x = refmont ? F::from_refmont(w) : F::from_canonical(w);
+        jp.y = refmont ? F::from_refmont(w + E::N32) : F::from_canonical(w + E::N32);
+        jp.z = F::one();
+      }
+      for (int j = 1; j < pf; j++) {
+        bool ident = zero_in;
+        if (!ident) {
+          for (int sft = 0; sft < shift; sft++)
+            jp = E::dbl_jac(jp);
+          ident = F::is_zero(jp.z); // a point of order two doubles to Z = 0 (and stays there)
+        }
+        if (ident) { // the identity is (0, 0) in the reference's affine layout
+          uint32_t zw[PW];
+          for (int k = 0; k < PW; k++)
+            zw[k] = 0;
+          put(i * pf + j, zw);
+          continue;
+        }
+        xs[cnt] = jp.x, ys[cnt] = jp.y, zs[cnt] = jp.z;
+        pre[cnt] = acc; // product of the Z's before this one
+        acc = F::mul(acc, jp.z);
+        slot[cnt] = q * pf + j;
+        cnt++;
+      }
+    }
+    if (cnt == 0) return;
+    fe inv = F::inv(acc);
+    for (int k = cnt - 1; k >= 0; k--) {
+      const fe zi = F::mul(inv, pre[k]); // 1 / Z_k
+      inv = F::mul(inv, zs[k]);
+      const fe zi2 = F::sqr(zi);
+      const fe x = F::mul(xs[k], zi2), y = F::mul(ys[k], F::mul(zi2, zi));
+      uint32_t o[PW];
+      if (refmont) {
+        F::to_refmont(o, x);
+        F::to_refmont(o + E::N32, y);
+      } else {
+        F::to_canonical(o, x);
+        F::to_canonical(o + E::N32, y);
+      }
+      put(i0 * pf + slot[k], o);
     }
   }
 
@@ -1623,7 +1678,7 @@ namespace icicle_hip {
     if (!in_v || !out_v) return ICICLE_INVALID_POINTER;
     ICICLE_TRY(bind_current_device());
     hipStream_t st = (hipStream_t)cfg->stream;
-    const MsmPlan pl = make_plan(n, C::fr::NBITS, *cfg);
+    const MsmPlan pl = make_plan(precompute_msm_size(n, *cfg), C::fr::NBITS, *cfg);
     const int pf = pl.pf;
     TempBuf d_in_tmp, d_out_tmp;
     const uint32_t* d_in = (const uint32_t*)in_v;
@@ -1638,7 +1693,14 @@ namespace icicle_hip {
       HIP_TRY(d_out_tmp.alloc((size_t)n * pf * PW * 4, st), ICICLE_ALLOCATION_FAILED);
       d_out = d_out_tmp.as<uint32_t>();
     }
-    k_precompute<C><<<(n + 63) / 64, 64, 0, st>>>(d_in, d_out, n, pf, pl.c * pl.wpf, cfg->are_points_montgomery_form);
+    // bases per thread sharing one inversion: as many as the scratch arrays hold, at most 4, and never so many that the
+    // grid no longer fills the chip
+    int pt = std::max(1, std::min(4, pf > 1 ? PRECOMP_MAX_OUT / (pf - 1) : 1));
+    while (pt > 1 && (long long)n / pt < 64 * 1024)
+      pt--;
+    if (pf - 1 > PRECOMP_MAX_OUT) return ICICLE_INVALID_ARGUMENT; // (the reference's sweeps stop at 23: docs/docs/api/cpp/msm.md:186-201)
+    const long long nthr = ((long long)n + pt - 1) / pt;
+    k_precompute<C><<<(unsigned)((nthr + 63) / 64), 64, 0, st>>>(d_in, d_out, n, pf, pl.c * pl.wpf, cfg->are_points_montgomery_form, pt, ((uintptr_t)d_out & 15) == 0);
     LAUNCH_CHECK("k_precompute", st);
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
     if (!cfg->are_results_on_device) {

@@ -42,6 +42,14 @@ namespace icicle_hip {
     uint32_t seg; // bucket-accumulation segment size: a bucket with more points is split across threads
   };
 
+  // the MSM size msm_precompute_bases(nof_bases, config) plans for: one MSM's bases when they are shared over the batch
+  // (or there is no batch), nof_bases / batch_size when every MSM of the batch brings its own
+  static inline int precompute_msm_size(int nof_bases, const icicle_msm_config_t& cfg)
+  {
+    const int b = std::max(1, cfg.batch_size);
+    return (!cfg.are_points_shared_in_batch && b > 1 && nof_bases % b == 0) ? nof_bases / b : nof_bases;
+  }
+
   static MsmPlan make_plan(int n, int scalar_bits, const icicle_msm_config_t& cfg)
   {
     MsmPlan p;
@@ -49,10 +57,15 @@ namespace icicle_hip {
     p.pf = std::max(1, cfg.precompute_factor);
     int c = cfg.c;
     // A precomputed base table fixes the doubling shift c * wpf, so msm_precompute_bases(nof_bases) and msm(msm_size)
-    // must agree on c. The reference derives it from the size on both sides (cpu_msm.hpp:466 vs :207), which only
-    // agrees when nof_bases == msm_size; here an unspecified c is size-independent whenever precompute_factor > 1,
-    // so shared and per-MSM base tables of any batch shape work (pass config.c on both calls to tune it).
-    if (c <= 0 && p.pf > 1) c = 16;
+    // must agree on c. Like the reference (cpu_msm.hpp:466 vs :207, get_optimal_c :103-119) both sides derive it from the
+    // size of ONE MSM, the scalar bits and precompute_factor -- and from nothing else: with precompute_factor > 1 the
+    // choice ignores batch_size (the two calls rarely carry the same one: the Rust suite precomputes shared bases with
+    // batch_size 1 and then runs batches of 1, 3 and 16 on the table, wrappers/rust/icicle-core/src/msm/tests.rs:96-134).
+    // msm_precompute_bases sees nof_bases: the size of one MSM for shared bases, batch_size of them otherwise
+    // (precompute_msm_size below; tests.rs:195-201). Rounds 1-3 used a fixed c = 16 here, which made every MSM from 2^20 up
+    // SLOWER with a table (16 windows against 13); now a table lowers the bucket count per window set by pf and the cost
+    // model moves c up with it, as docs/docs/api/cpp/msm.md:155-201 describes. Pass config.c on both calls to override.
+    const bool table = p.pf > 1;
     if (c <= 0) {
       // minimise  (#mixed adds) + (bucket-reduction work). Fitted to a measured sweep (profiles/r03_msm_csweep.txt):
       //  * a window size whose TOP window holds only 1-3 scalar bits is never chosen: that window has a handful of
@@ -65,7 +78,7 @@ namespace icicle_hip {
       //    (14 muls each) vs 10 muls per mixed add, weighted 8 for their poor parallelism (round 1's fit, still the best).
       // (a batch runs as ONE launch sequence with batch x the bucket threads and batch x the reduction work: round 1's
       //  weights stay the better fit there -- 16 x 2^16: 3.5 ms against 4.5 ms with the single-MSM fit)
-      const bool mid = n >= (1 << 16) && std::max(1, cfg.batch_size) == 1;
+      const bool mid = n >= (1 << 16) && (table || std::max(1, cfg.batch_size) == 1);
       double best = 1e300;
       for (int cc = 2; cc <= 21; cc++) {
         const int w = (p.bits + 1 + cc - 1) / cc;
@@ -73,7 +86,7 @@ namespace icicle_hip {
         if (w > 1 && p.bits + 1 - cc * (w - 1) <= 3 && p.bits > 8) continue; // tiny top window
         // batches of small MSMs: the one-level sort (c <= 11) beats the two-level one by far while the windows are small
         // (128 x 2^17: c = 11 29.2 ms, c = 12 / 13 36.4 / 34.8; 1024 x 2^12: c = 12 77 ms against 16) -- profiles/r03_notes.md 11
-        if (cfg.batch_size > 1 && n <= (1 << 17) && cc > 11) continue;
+        if (!table && cfg.batch_size > 1 && n <= (1 << 17) && cc > 11) continue;
         const double nbk = (double)wpf * (double)(1u << (cc - 1));
         double cost;
         if (mid) {

@@ -92,7 +92,7 @@ extern "C" int split_shape_check(void)
 }
 
 // the window plan msm() picks: window size inside the sort's range, never a top window of 1-3 scalar bits, batches of
-// small MSMs on the one-level sort, a caller-set c honoured, precompute tables on the size-independent c
+// small MSMs on the one-level sort, a caller-set c honoured, precompute tables on a c that ignores batch_size
 extern "C" int msm_plan_check(void)
 {
   for (int bits : {254, 255, 64, 128})
@@ -109,7 +109,15 @@ extern "C" int msm_plan_check(void)
           if (p.nwin != (p.bits + 1 + p.c - 1) / p.c || p.wpf != (p.nwin + pf - 1) / pf || p.nb != (1u << (p.c - 1))) return tag * 10 + 2;
           if (pf == 1 && p.nwin > 1 && p.bits > 8 && p.bits + 1 - p.c * (p.nwin - 1) <= 3) return tag * 10 + 3; // tiny top window
           if (pf == 1 && batch > 1 && logn <= 17 && p.c > 11) return tag * 10 + 4;
-          if (pf > 1 && p.c != 16) return tag * 10 + 5;
+          if (pf > 1) { // a base table: msm_precompute_bases and msm must agree whatever batch_size either call carries
+            icicle_msm_config_t c1 = cfg;
+            c1.batch_size = 1;
+            if (make_plan(n, bits, c1).c != p.c) return tag * 10 + 5;
+            c1.batch_size = 3, c1.are_points_shared_in_batch = false; // per-MSM tables: nof_bases = 3 n
+            if (precompute_msm_size(3 * n, c1) != n) return tag * 10 + 8;
+            c1.are_points_shared_in_batch = true;
+            if (precompute_msm_size(n, c1) != n) return tag * 10 + 9;
+          }
           cfg.c = 13;
           if (make_plan(n, bits, cfg).c != 13) return tag * 10 + 6;
           if (p.seg < 64 || (p.seg & (p.seg - 1)) != 0) return tag * 10 + 7;

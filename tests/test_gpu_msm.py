@@ -227,8 +227,10 @@ def test_msm_precompute(hip, cname):
 
 @pytest.mark.parametrize("cname", CURVES)
 def test_msm_precompute_non_shared_batch(hip, cname):
-    """per-MSM base tables: msm_precompute_bases over batch * n bases, msm with are_points_shared_in_batch = false
-    (nof_bases != msm_size: the window size must not depend on either), plus a different msm_size on the same table"""
+    """per-MSM base tables as the Rust suite builds them (wrappers/rust/icicle-core/src/msm/tests.rs:195-220):
+    msm_precompute_bases over batch * n bases with batch_size / are_points_shared_in_batch = false set on BOTH calls (the
+    window size follows the size of one MSM on both sides, like cpu_msm.hpp:466 vs :207); and a different msm_size on the
+    same table with config.c pinned on both calls"""
     from icicle_amd import msm as M
 
     C = pyref.CURVES[cname]
@@ -240,14 +242,17 @@ def test_msm_precompute_non_shared_batch(hip, cname):
     exp = refc.to_affine(refc.msm(sc, bases, batch=batch, shared=False))
     cfg = hip.MSMConfig.default()
     cfg.precompute_factor = pf
-    pre = M.precompute_bases(cname, bases, cfg)  # nof_bases = batch * n
     cfg.batch_size = batch
     cfg.are_points_shared_in_batch = False
+    pre = M.precompute_bases(cname, bases, cfg)  # nof_bases = batch * n
     got = M.msm(cname, sc, pre, cfg)
     assert np.array_equal(refc.to_affine(got), exp)
-    # the first 100 bases of the same table, as a single MSM of a different size
+    # the first 100 bases of a table built with an explicit c, as a single MSM of a different size
+    cfg.c = 9
+    pre = M.precompute_bases(cname, bases, cfg)
     cfg1 = hip.MSMConfig.default()
     cfg1.precompute_factor = pf
+    cfg1.c = 9
     got1 = M.msm(cname, np.ascontiguousarray(sc[:100]), np.ascontiguousarray(pre[: 100 * pf]), cfg1)
     assert np.array_equal(refc.to_affine(got1), refc.to_affine(refc.msm(np.ascontiguousarray(sc[:100]), np.ascontiguousarray(bases[:100]))))
 
