@@ -307,6 +307,6 @@ lib.icicle_hip_test_inject_failure.argtypes = [ctypes.c_int, ctypes.c_int]
 
 def multi_stats(reset=False):
     """dict of the multi-device / pipelined-path counters (icicle_hip_multi_stats)"""
-    out = (ctypes.c_uint64 * 5)()
+    out = (ctypes.c_uint64 * 6)()
     check(lib.icicle_hip_multi_stats(out, reset), "multi_stats")
-    return dict(zip(("staged_base_bytes", "staged_scalar_bytes", "exchanged_bucket_bytes", "resident_base_hits", "threaded_calls"), [int(v) for v in out]))
+    return dict(zip(("staged_base_bytes", "staged_scalar_bytes", "exchanged_bucket_bytes", "resident_base_hits", "threaded_calls", "exchange_messages"), [int(v) for v in out]))

@@ -189,7 +189,7 @@ namespace icicle_hip {
   bool test_failure_armed(int slot, int stage);
   // per-process counters of what the multi-device / pipelined paths moved (icicle_hip_multi_stats)
   struct MultiStats {
-    std::atomic<uint64_t> staged_base_bytes{0}, staged_scalar_bytes{0}, exchanged_bucket_bytes{0}, resident_base_hits{0}, threaded_calls{0};
+    std::atomic<uint64_t> staged_base_bytes{0}, staged_scalar_bytes{0}, exchanged_bucket_bytes{0}, resident_base_hits{0}, threaded_calls{0}, exchange_messages{0};
   };
   MultiStats& multi_stats();
   // a long-lived non-blocking side stream of the calling thread's device (operand staging runs beside the compute stream)
@@ -206,9 +206,10 @@ namespace icicle_hip {
     const void* bases;
     size_t row_bytes_total; // bytes of one row of the caller's base array (n * pf * point bytes)
     int rows, G, g, device, slot;
+    int generation = 0; // caller's content id ("hip_bases_generation"): bump it when the bytes at `bases` change
     bool operator<(const ResidentKey& o) const
     {
-      return std::tie(bases, row_bytes_total, rows, G, g, device, slot) < std::tie(o.bases, o.row_bytes_total, o.rows, o.G, o.g, o.device, o.slot);
+      return std::tie(bases, row_bytes_total, rows, G, g, device, slot, generation) < std::tie(o.bases, o.row_bytes_total, o.rows, o.G, o.g, o.device, o.slot, o.generation);
     }
   };
   struct ResidentShard {

@@ -21,7 +21,11 @@
 //                                    staged (keyed on pointer, size, precompute factor, shard cut), so the second and
 //                                    later calls move scalars only -- SURVEY.md 8(e) "bases stay resident per GPU;
 //                                    scalars streamed" (the reference's own vehicle for it is are_points_on_device,
-//                                    include/icicle/msm.h:39-47, which names ONE device).
+//                                    include/icicle/msm.h:39-47, which names ONE device). The copies are keyed on the
+//                                    POINTER: memory from icicle_malloc releases them when it is freed; for any other
+//                                    memory (host buffers, another allocator's device memory) the release call is
+//                                    MANDATORY before the address can be reused, or the contents are versioned with
+//   "hip_bases_generation"     int   a caller-chosen id that is part of the cache key: a new value = new copies.
 //   "hip_force_rccl"           bool  use the RCCL exchange even with one device slot (size-1 communicator): test hook.
 //
 // Operand staging is a two-stage pipeline per device: while shard j runs on the compute stream, the operands of shard
@@ -53,7 +57,8 @@ namespace icicle_hip {
   struct BucketExchange : MsmBucketHook<C> {
     using Proj = typename EC<C>::Proj;
     int nshards = 1, seen = 0, P = 1, p = 0;
-    TempBuf acc, recv;
+    TempBuf acc, recv, send;
+    bool self_exchange = false; // "hip_force_rccl" with one device slot
     void* comm = nullptr;
     GateTicket* ticket = nullptr; // used (once) right before the slice exchange
 
@@ -90,10 +95,32 @@ namespace icicle_hip {
       slice(p, &lo, &hi, &blo, &bhi);
       *seg_lo = lo;
       *nsegr = hi - lo;
-      if (P == 1) return ICICLE_SUCCESS;
+      // One device slot: nothing to exchange -- unless "hip_force_rccl" asks for the exchange anyway: the slot then sends its
+      // slice to ITSELF through the size-1 communicator (ncclSend / ncclRecv to the own rank inside a group is legal) and
+      // REPLACES the slice with what arrived, so that the real librccl point-to-point calls run on a single-GPU box and a
+      // mis-delivered byte shows up in the MSM result.
+      if (P == 1 && !self_exchange) return ICICLE_SUCCESS;
       const RcclApi* api = rccl_api();
       const size_t mine = bhi - blo; // buckets of my slice per window
-      bool ready = api != nullptr && recv.alloc(std::max<size_t>(1, (size_t)P * tw * mine) * sizeof(Proj), st) == hipSuccess;
+      // ONE message per peer: the tw window slices a peer owns are packed into a contiguous send buffer first (a strided
+      // device copy), and arrive contiguously ([peer][window][mine]) -- rounds 2-3 issued tw x (P - 1) Send / Recv pairs per
+      // device (91 at c = 20, G = 8)
+      std::vector<size_t> soff(P + 1, 0);
+      for (int q = 0; q < P; q++) {
+        uint32_t qlo, qhi;
+        size_t qblo, qbhi;
+        slice(q, &qlo, &qhi, &qblo, &qbhi);
+        soff[q + 1] = soff[q] + ((q == p && !self_exchange) ? 0 : tw * (qbhi - qblo));
+      }
+      bool ready = api != nullptr && recv.alloc(std::max<size_t>(1, (size_t)P * tw * mine) * sizeof(Proj), st) == hipSuccess &&
+                   send.alloc(std::max<size_t>(1, soff[P]) * sizeof(Proj), st) == hipSuccess;
+      for (int q = 0; q < P && ready; q++) {
+        uint32_t qlo, qhi;
+        size_t qblo, qbhi;
+        slice(q, &qlo, &qhi, &qblo, &qbhi);
+        if (soff[q + 1] == soff[q]) continue;
+        ready = hipMemcpy2DAsync(send.as<Proj>() + soff[q], (qbhi - qblo) * sizeof(Proj), buckets + qblo, (size_t)nb * sizeof(Proj), (qbhi - qblo) * sizeof(Proj), tw, hipMemcpyDeviceToDevice, st) == hipSuccess;
+      }
       if (test_failure_armed(p, 2)) ready = false;
       const bool all_ready = ticket ? ticket->arrive(ready) : ready; // a peer (or this device) cannot take part: nobody enters the collective
       if (!ready) return api ? ICICLE_ALLOCATION_FAILED : ICICLE_API_NOT_IMPLEMENTED;
@@ -103,23 +130,24 @@ namespace icicle_hip {
       bool ok = true; // a failed call must not leave the group open: GroupEnd is always reached
       size_t sent = 0;
       for (int q = 0; q < P && ok; q++) {
-        if (q == p) continue;
-        uint32_t qlo, qhi;
-        size_t qblo, qbhi;
-        slice(q, &qlo, &qhi, &qblo, &qbhi);
-        for (size_t w = 0; w < tw && ok; w++) {
-          if (qbhi > qblo) {
-            ok = api->Send(buckets + w * nb + qblo, (qbhi - qblo) * PWORDS, RCCL_UINT32, q, comm, st) == 0;
-            sent += (qbhi - qblo) * sizeof(Proj);
-          }
-          if (ok && mine) ok = api->Recv(recv.as<Proj>() + ((size_t)q * tw + w) * mine, mine * PWORDS, RCCL_UINT32, q, comm, st) == 0;
+        if (q == p && !self_exchange) continue;
+        const size_t cnt = soff[q + 1] - soff[q];
+        if (cnt) {
+          ok = api->Send(send.as<Proj>() + soff[q], cnt * PWORDS, RCCL_UINT32, q, comm, st) == 0;
+          sent += cnt * sizeof(Proj);
+          multi_stats().exchange_messages++;
         }
+        if (ok && mine) ok = api->Recv(recv.as<Proj>() + (size_t)q * tw * mine, tw * mine * PWORDS, RCCL_UINT32, q, comm, st) == 0;
       }
       if (api->GroupEnd() != 0 || !ok) return ICICLE_COPY_FAILED;
       multi_stats().exchanged_bucket_bytes += sent;
       if (mine) {
         for (int q = 0; q < P; q++) {
-          if (q == p) continue;
+          if (q == p) {
+            if (self_exchange) // my own slice, back from the round trip through the communicator
+              HIP_TRY(hipMemcpy2DAsync(buckets + blo, (size_t)nb * sizeof(Proj), recv.as<Proj>() + (size_t)q * tw * mine, mine * sizeof(Proj), mine * sizeof(Proj), tw, hipMemcpyDeviceToDevice, st), ICICLE_COPY_FAILED);
+            continue;
+          }
           for (size_t w = 0; w < tw; w++) {
             k_bucket_add<C><<<(unsigned)((mine + 127) / 128), 128, 0, st>>>(buckets + w * nb + blo, recv.as<Proj>() + ((size_t)q * tw + w) * mine, mine);
             LAUNCH_CHECK("k_bucket_add(slice)", st);
@@ -134,6 +162,7 @@ namespace icicle_hip {
     int G = 1;
     int max_slots = 0; // > 0: use at most this many device slots (1 = pipeline the shards on the calling device only)
     bool exchange_buckets = false, force_rccl = false, bases_resident = false;
+    int bases_generation = 0;
   };
 
   template <class C>
@@ -225,6 +254,7 @@ namespace icicle_hip {
           HIP_TRY(partials.alloc((size_t)std::max(1, ns_p) * batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
           HIP_TRY(devpart.alloc((size_t)batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
           hook.nshards = ns_p, hook.P = P, hook.p = p, hook.comm = cset ? cset->comms[p] : nullptr;
+          hook.self_exchange = P == 1 && opt.force_rccl && cset != nullptr;
           hook.ticket = &t_exchange;
           icicle_msm_config_t c2 = sub;
           c2.stream = st;
@@ -260,7 +290,7 @@ namespace icicle_hip {
               if (opt.bases_resident) {
                 // first use: stage the shard into memory that stays (filled on the side stream right here, under the
                 // lock, so that a concurrent call never sees an entry whose copy has not been enqueued yet)
-                const ResidentKey key{bases_v, (size_t)n * pf * PW * 4, brows, G, mine[j], ds.devs[p], p};
+                const ResidentKey key{bases_v, (size_t)n * pf * PW * 4, brows, G, mine[j], ds.devs[p], p, opt.bases_generation};
                 std::lock_guard<std::mutex> g(resident_mtx());
                 auto& m = resident_map();
                 auto it = m.find(key);
@@ -269,6 +299,14 @@ namespace icicle_hip {
                   rs.bytes = row * brows;
                   HIP_TRY(hipMalloc(&rs.ptr, rs.bytes), ICICLE_ALLOCATION_FAILED);
                   const uint32_t* src = (const uint32_t*)bases_v + (size_t)s.lo * pf * PW;
+                  // the copy runs on the side stream: it must come BEHIND whatever the caller queued on the compute stream
+                  // (bases still being written there would otherwise be cached stale, for good -- ADVICE r03)
+                  hipEvent_t before = ring_event();
+                  if (!before || hipEventRecord(before, st) != hipSuccess || hipStreamWaitEvent(cs, before, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    (void)hipFree(rs.ptr);
+                    return ICICLE_SYNCHRONIZATION_FAILED;
+                  }
                   if (hipEventCreateWithFlags(&rs.ready, hipEventDisableTiming) != hipSuccess ||
                       hipMemcpy2DAsync(rs.ptr, row, src, (size_t)n * pf * PW * 4, row, brows, hipMemcpyDefault, cs) != hipSuccess ||
                       hipEventRecord(rs.ready, cs) != hipSuccess) {
@@ -406,6 +444,7 @@ namespace icicle_hip {
       opt.exchange_buckets = e->get_bool("hip_msm_exchange_buckets", false);
       opt.force_rccl = e->get_bool("hip_force_rccl", false);
       opt.bases_resident = e->get_bool("hip_bases_resident", false);
+      opt.bases_generation = e->get_int("hip_bases_generation", 0);
     }
     if (opt.G >= 1) return msm_multi_run<C>(scalars_v, bases_v, n, cfg, results_v, opt);
     // Host-resident scalars on one GPU (the wrappers' default HostSlice): cut the MSM into chunks so that the

@@ -267,6 +267,7 @@ namespace icicle_hip {
       log_max++;
     }
     if (x != S::one()) return ICICLE_INVALID_ARGUMENT; // not a 2^k-th root of unity
+    if (log_max > 36) return ICICLE_INVALID_ARGUMENT;  // (same guard as ntt_big.hip; 31-bit fields stop at 2^27)
     hipStream_t st = (hipStream_t)cfg->stream;
     const size_t n = (size_t)1 << log_max;
     uint32_t* tw = nullptr;
@@ -401,7 +402,8 @@ namespace icicle_hip {
         ICICLE_TRY(ntt_init_domain_run<PR>(&root, &ic));
         std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
         auto& d = DomainStore<PR>::map()[current_device_id()];
-        if (d.owner < 0) d.owner = home; // brought up on behalf of `home`: goes when home's domain goes
+        if (d.root != root) return ICICLE_INVALID_ARGUMENT; // a peer with a domain of another root: other twiddles
+        if (d.owner < 0 && current_device_id() != home) d.owner = home; // brought up on behalf of `home`: goes when home's domain goes
         return ICICLE_SUCCESS;
       });
   }
@@ -413,10 +415,12 @@ namespace icicle_hip {
     if (!cfg) return ICICLE_INVALID_POINTER;
     if (cfg->ext && !cfg->columns_batch) {
       const int G = reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_num_devices", 0);
+      // "hip_force_rccl" with ONE device: the split transform's exchanges as sends to the own rank (the real librccl on a 1-GPU box)
+      const bool force = reinterpret_cast<const ConfigExt*>(cfg->ext)->get_bool("hip_force_rccl", false) && G == 1;
       if (G >= 1) {
         // fewer transforms than devices: cut every transform itself over the device slots (four-step, all-to-all
         // exchanges: ntt_split.hpp) when its shape allows; otherwise (and for every batch >= G) rows over devices
-        if (std::max(1, cfg->batch_size) < G && lanes == 1 && cfg->ordering == ICICLE_kNN && cfg->coset_gen == 1 && size > 0 && (size & (size - 1)) == 0 && input && output &&
+        if ((std::max(1, cfg->batch_size) < G || force) && lanes == 1 && cfg->ordering == ICICLE_kNN && cfg->coset_gen == 1 && size > 0 && (size & (size - 1)) == 0 && input && output &&
             (dir == ICICLE_NTT_FORWARD || dir == ICICLE_NTT_INVERSE)) {
           DeviceSlots ds;
           ICICLE_TRY(make_device_slots(G, &ds));
@@ -424,7 +428,7 @@ namespace icicle_hip {
           while ((1 << logn) < size)
             logn++;
           SplitShape shp;
-          if (ds.P == G && split_shape(logn, ds.P, &shp)) return ntt_split_run<PR>(input, size, dir, cfg, output, ds, shp);
+          if (ds.P == G && split_shape(logn, ds.P, &shp, force)) return ntt_split_run<PR>(input, size, dir, cfg, output, ds, shp, force);
         }
         return ntt_multi_run<PR>(input, size, dir, cfg, output, lanes, G, 0);
       }

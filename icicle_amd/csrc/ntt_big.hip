@@ -184,6 +184,9 @@ namespace icicle_hip {
       log_max++;
     }
     if (!F::eq(x, F::one())) return ICICLE_INVALID_ARGUMENT; // not a 2^k-th root of unity
+    // the table holds 2^log_max elements: a root of an order no device memory can hold (stark252 has two-adicity 192, the
+    // shift below would be undefined from 64 on) is refused here, cleanly, like the reference's failed allocation
+    if (log_max > 36) return ICICLE_INVALID_ARGUMENT;
     hipStream_t st = (hipStream_t)cfg->stream;
     const size_t n = (size_t)1 << log_max;
     uint32_t* tw = nullptr;
@@ -299,7 +302,10 @@ namespace icicle_hip {
         ICICLE_TRY(big_init_domain_run<PR>(root, &ic));
         std::lock_guard<std::mutex> g(BigDomainStore<PR>::mtx());
         auto& d = BigDomainStore<PR>::map()[current_device_id()];
-        if (d.owner < 0) d.owner = home;
+        // "already initialised" is a silent success: a peer that holds a domain of a DIFFERENT root would transform its
+        // row shards with other twiddles
+        if (memcmp(d.root, root, PR::NL32 * 4) != 0) return ICICLE_INVALID_ARGUMENT;
+        if (d.owner < 0 && current_device_id() != home) d.owner = home;
         return ICICLE_SUCCESS;
       });
   }

@@ -83,7 +83,8 @@ namespace icicle_hip {
           if (threaded || !job.is_async) HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
           return ICICLE_SUCCESS;
         }
-        hipStream_t cin = side_stream(threaded ? 100 + 2 * p : 98), cout = side_stream(threaded ? 101 + 2 * p : 99);
+        // (disjoint id ranges: uploads 1000 + p, downloads 2000 + p, compute 200 + p -- ADVICE r03: 100 + 2p met 200 + p at p = 50)
+        hipStream_t cin = side_stream(threaded ? 1000 + p : 98), cout = side_stream(threaded ? 2000 + p : 99);
         if (!cin || !cout) return ICICLE_STREAM_CREATION_FAILED;
         struct Slot {
           TempBuf buf;

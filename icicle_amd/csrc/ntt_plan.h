@@ -118,14 +118,14 @@ namespace icicle_hip {
   struct SplitShape {
     int P, logn, a, b; // N1 = 2^a, N2 = 2^b
   };
-  static inline bool split_shape(int logn, int P, SplitShape* s)
-  {
-    if (P < 2 || (P & (P - 1)) != 0) return false;
+  static inline bool split_shape(int logn, int P, SplitShape* s, bool allow_one = false)
+  { // (P = 1: the "hip_force_rccl" rehearsal of the exchanges on a single device slot)
+    if (P < (allow_one ? 1 : 2) || (P & (P - 1)) != 0) return false;
     int lp = 0;
     while ((1 << lp) < P)
       lp++;
     const int a = std::max((logn + 1) / 2, lp), b = logn - a;
-    if (b < lp) return false;
+    if (b < lp || (P == 1 && b < 1)) return false;
     *s = {P, logn, a, b};
     return true;
   }

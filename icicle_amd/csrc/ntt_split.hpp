@@ -31,8 +31,10 @@ static __global__ __launch_bounds__(256) void k_transpose_u32(const uint32_t* __
 }
 
 template <class PR>
-static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, const DeviceSlots& ds, const SplitShape& sh)
+static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, const icicle_ntt_config_u32_t* cfg, uint32_t* output, const DeviceSlots& ds, const SplitShape& sh, bool self_exchange = false)
 {
+  // self_exchange ("hip_force_rccl", one slot): the slot's own block travels through the communicator as well (a send to the
+  // own rank inside the group), so the real ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd run on a single-GPU box
   const int P = sh.P, home = ds.home, batch = std::max(1, cfg->batch_size);
   const uint64_t n = (uint64_t)size, n1 = (uint64_t)1 << sh.a, n2 = (uint64_t)1 << sh.b;
   const uint64_t chunk = n / P; // words per slot
@@ -58,9 +60,20 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
 
   PhaseGate gate;
   gate.expected = P;
+  // one more gate in front of EVERY exchange (3 per transform): a slot that failed after the first gate -- a launch, a
+  // copy, a sub-transform -- leaves through its unused tickets ("failed"), and its peers skip the collective instead of
+  // waiting in ncclRecv for a block that will never come
+  const size_t ngates = (size_t)3 * batch;
+  std::unique_ptr<PhaseGate[]> xgates(new PhaseGate[ngates]);
+  for (size_t i = 0; i < ngates; i++)
+    xgates[i].expected = P;
   std::vector<icicle_error_t> rcs(P, ICICLE_SUCCESS);
   auto worker = [&](int p) -> icicle_error_t {
     GateTicket ticket(&gate);
+    std::vector<std::unique_ptr<GateTicket>> xt;
+    for (size_t i = 0; i < ngates; i++)
+      xt.emplace_back(new GateTicket(&xgates[i]));
+    size_t xi = 0;
     if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED;
     ICICLE_TRY(icicle_hip_set_device(ds.devs[p]));
     if (ds.devs[p] != home) {
@@ -80,7 +93,8 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
         if (ready) {
           std::lock_guard<std::mutex> g(DomainStore<PR>::mtx());
           auto& d = DomainStore<PR>::map()[current_device_id()];
-          if (d.owner < 0) d.owner = home;
+          ready = d.root == root; // (a peer that already holds a domain of another root: see ntt_multi_run)
+          if (ready && d.owner < 0) d.owner = home;
         }
       }
       if (!ticket.arrive(ready) || !ready) return ICICLE_ALLOCATION_FAILED; // all slots or none enter the exchanges
@@ -101,16 +115,19 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
         k_transpose_u32<<<dim3((unsigned)((C + 31) / 32), (unsigned)((rl + 31) / 32)), 256, 0, st>>>(src, T, (uint32_t)rl, (uint32_t)C); // T[c][r], block q = rows [q cl, (q + 1) cl)
         LAUNCH_CHECK("k_transpose_u32", st);
         uint32_t* recv = const_cast<uint32_t*>(src); // the source is dead once it is transposed
+        const bool inject = xi == 1 && test_failure_armed(p, 2); // (rehearsal: this slot fails between two exchanges)
+        if (!xt[xi++]->arrive(!inject) || inject) return ICICLE_COPY_FAILED; // every slot enters this exchange, or none does
         bool ok = api->GroupStart() == 0;
         for (int q = 0; q < P && ok; q++) {
-          if (q == p) continue;
+          if (q == p && !self_exchange) continue;
           ok = api->Send(T + (size_t)q * cl * rl, cl * rl, RCCL_UINT32, q, comm, st) == 0;
           ok = ok && api->Recv(recv + (size_t)q * cl * rl, cl * rl, RCCL_UINT32, q, comm, st) == 0;
+          multi_stats().exchange_messages++;
         }
         if (api->GroupEnd() != 0 || !ok) return ICICLE_COPY_FAILED;
-        multi_stats().exchanged_bucket_bytes += (uint64_t)(P - 1) * cl * rl * 4;
+        multi_stats().exchanged_bucket_bytes += (uint64_t)(self_exchange ? P : P - 1) * cl * rl * 4;
         for (int q = 0; q < P; q++) { // block of sender q: [cl][rl] -> columns [q rl, (q + 1) rl) of dst [cl][R]
-          const uint32_t* blk = q == p ? T + (size_t)q * cl * rl : recv + (size_t)q * cl * rl;
+          const uint32_t* blk = (q == p && !self_exchange) ? T + (size_t)q * cl * rl : recv + (size_t)q * cl * rl;
           HIP_TRY(hipMemcpy2DAsync(dst + (size_t)q * rl, R * 4, blk, rl * 4, rl * 4, cl, hipMemcpyDeviceToDevice, st), ICICLE_COPY_FAILED);
         }
         return ICICLE_SUCCESS;

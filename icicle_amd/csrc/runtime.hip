@@ -503,6 +503,7 @@ icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset)
 {
   MultiStats& m = multi_stats();
   if (out5) {
+    out5[5] = m.exchange_messages.load();
     out5[0] = m.staged_base_bytes.load();
     out5[1] = m.staged_scalar_bytes.load();
     out5[2] = m.exchanged_bucket_bytes.load();
@@ -515,6 +516,7 @@ icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset)
     m.exchanged_bucket_bytes = 0;
     m.resident_base_hits = 0;
     m.threaded_calls = 0;
+    m.exchange_messages = 0;
   }
   return ICICLE_SUCCESS;
 }

@@ -328,14 +328,19 @@ icicle_error_t icicle_hip_workspace_bytes(size_t* bytes);
  *   "hip_num_devices"          int   msm + ntt: cut the work into this many shards over min(G, visible GPUs) devices
  *   "hip_msm_exchange_buckets" bool  msm: exchange bucket slices (grouped send / recv) instead of partial results
  *   "hip_bases_resident"       bool  msm: keep the per-device copies of the base shards between calls (the caller
- *                                    promises the bases at that pointer do not change); released by the function below
- *   "hip_force_rccl"           bool  msm: take the RCCL exchange even with one device (test hook)
+ *                                    promises the bases at that pointer do not change); released by the function below --
+ *                                    MANDATORY before the address is reused unless the memory came from icicle_malloc
+ *                                    (icicle_free releases the copies) --, or versioned with
+ *   "hip_bases_generation"     int   msm: caller's content id, part of the cache key (a new value stages fresh copies)
+ *   "hip_force_rccl"           bool  msm, ntt: take the RCCL exchanges even with one device slot -- all-gather, and the grouped
+ *                                    ncclSend / ncclRecv of the bucket exchange and of the split transform as sends to
+ *                                    the own rank of a size-1 communicator (test hook: the real librccl on one GPU)
  * icicle_hip_msm_release_resident_bases(bases) frees the resident copies made for `bases` (NULL: for every pointer);
  * icicle_free / icicle_free_async of a device allocation release the copies made for it as well. */
 icicle_error_t icicle_hip_msm_release_resident_bases(const void* bases);
-/* Counters of what the multi-device / pipelined paths moved since the last reset, out[5] = { base bytes staged to a
- * device, scalar bytes staged, bucket bytes sent by the bucket exchange, resident-base hits (shards NOT staged again),
- * calls that ran one host thread per device slot }. */
+/* Counters of what the multi-device / pipelined paths moved since the last reset, out[6] = { base bytes staged to a
+ * device, scalar bytes staged, bytes sent by the bucket exchange / the split transform's all-to-all, resident-base hits
+ * (shards NOT staged again), calls that ran one host thread per device slot, point-to-point messages sent }. */
 icicle_error_t icicle_hip_multi_stats(uint64_t* out, bool reset);
 /* Rehearsal hooks for the multi-device code on a box with fewer GPUs than device slots (tests only; see
  * icicle_amd/csrc/rccl_loopback.hip): K virtual device slots mapped round-robin onto the physical GPUs, an in-process

@@ -53,3 +53,4 @@ def test_bench_inprocess_leg_rehearsed_on_virtual_slots():
     assert out["wire_bytes_per_call"]["bases"] == 0 and out["wire_bytes_per_call"]["scalars"] == 3 * (1 << 16) * 32  # three remote slots
     assert out["resident_base_hits_per_call"] == 3
     assert out["ntt"]["roundtrip_ok"] is True
+    assert out["result_ok"] is True  # the timed result equals the sum of plain single-GPU MSMs over the shards

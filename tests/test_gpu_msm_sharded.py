@@ -205,11 +205,52 @@ def test_rccl_binding_with_size_one_communicator(hip):
     try:
         lib.config_extension_set_int(ext, b"hip_num_devices", 3)  # 3 logical shards on the one device
         lib.config_extension_set_bool(ext, b"hip_force_rccl", True)
+        from icicle_amd._lib import multi_stats
+
         for xb in (False, True):
             lib.config_extension_set_bool(ext, b"hip_msm_exchange_buckets", xb)
             cfg = hip.MSMConfig.default()
             cfg.ext = ext
+            multi_stats(reset=True)
             got = M.msm("bn254", sc, bases, cfg)
             assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(sc, bases))), xb
+            st = multi_stats()
+            if xb:  # the bucket exchange ran as ONE send to the own rank: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd of the real librccl
+                assert st["exchange_messages"] == 1 and st["exchanged_bucket_bytes"] > 0, st
     finally:
         lib.destroy_config_extension(ext)
+
+
+@pytest.mark.parametrize("fname,logn,batch", [("babybear", 12, 1), ("babybear", 17, 2), ("koalabear", 20, 1)])
+def test_split_ntt_exchanges_on_the_real_rccl_with_one_device(hip, fname, logn, batch):
+    """"hip_force_rccl" with hip_num_devices = 1: the split transform (icicle_amd/csrc/ntt_split.hpp) runs its three all-to-all
+    exchanges as grouped ncclSend / ncclRecv to the own rank of a size-1 communicator of the REAL librccl.so -- everything of
+    the P > 1 exchange a single-GPU box can execute. memcmp with the reference CPU backend."""
+    from icicle_amd import ntt as N
+    from icicle_amd._lib import lib, multi_stats
+
+    F = pyref.NTT_FIELDS[fname]
+    n = 1 << logn
+    rng = np.random.default_rng(logn)
+    rf = ref.RefNttField(fname)
+    root = N.get_root_of_unity(fname, n)
+    rf.init_domain(root)
+    N.init_domain(fname, root)
+    ext = lib.create_config_extension()
+    try:
+        lib.config_extension_set_int(ext, b"hip_num_devices", 1)
+        lib.config_extension_set_bool(ext, b"hip_force_rccl", True)
+        x = rng.integers(0, F.p, size=batch * n, dtype=np.uint32)
+        cfg = hip.NTTConfigU32.default()
+        cfg.batch_size = batch
+        cfg.ext = ext
+        multi_stats(reset=True)
+        y = N.ntt(fname, x, N.FORWARD, cfg)
+        st = multi_stats()
+        assert st["exchange_messages"] == 3 * batch and st["exchanged_bucket_bytes"] == 3 * batch * n * 4, st
+        assert np.array_equal(y, rf.ntt(x, n, 0, batch=batch))
+        assert np.array_equal(N.ntt(fname, y, N.INVERSE, cfg), x)
+    finally:
+        lib.destroy_config_extension(ext)
+        N.release_domain(fname)
+        rf.release_domain()

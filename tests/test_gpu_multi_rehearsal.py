@@ -96,6 +96,7 @@ def test_msm_on_p_device_slots(hip, slots, cname, P, G, mode):
         assert st["threaded_calls"] == 1 and st["staged_scalar_bytes"] == n * 32
         if mode == "bucket_exchange":
             assert st["exchanged_bucket_bytes"] > 0, "the grouped send / recv of the bucket exchange did not run"
+            assert st["exchange_messages"] == P * (P - 1), st  # ONE message per ordered peer pair (round 3: one per window too)
         # device-resident operands on the calling device, batch of 2 with shared bases: slots > 0 copy from slot 0's device
         sc2 = np.vstack([sc, to_words(rand_scalars(rng, n, C.r), 8)])
         d_sc, d_b = DeviceVec.from_host(sc2), DeviceVec.from_host(bases)
@@ -398,6 +399,37 @@ def test_single_ntt_split_over_device_slots(hip, slots, fname, P, logn):
         rf.release_domain()
 
 
+@pytest.mark.parametrize("victim", [0, 3])
+def test_split_ntt_slot_failure_between_two_exchanges(hip, slots, victim):
+    """a slot that fails AFTER the first gate of the split transform -- here right before its second all-to-all
+    -- must not leave its peers waiting in ncclRecv: every exchange has its own gate, the call returns an error, and the
+    same call without the fault succeeds."""
+    from icicle_amd import ntt as N
+    from icicle_amd._lib import IcicleError, lib, check
+
+    fname, F, logn, P = "babybear", pyref.BABYBEAR, 12, 4
+    n = 1 << logn
+    rng = np.random.default_rng(victim)
+    rf = ref.RefNttField(fname)
+    root = N.get_root_of_unity(fname, n)
+    rf.init_domain(root)
+    N.init_domain(fname, root)
+    ext = _ext(hip_num_devices=P)
+    try:
+        slots(P)
+        x = rng.integers(0, F.p, size=n, dtype=np.uint32)
+        cfg = hip.NTTConfigU32.default()
+        cfg.ext = ext
+        check(lib.icicle_hip_test_inject_failure(victim, 2))
+        with pytest.raises(IcicleError):
+            N.ntt(fname, x, N.FORWARD, cfg)
+        assert np.array_equal(N.ntt(fname, x, N.FORWARD, cfg), rf.ntt(x, n, 0))  # one-shot fault: gone
+    finally:
+        lib.destroy_config_extension(ext)
+        N.release_domain(fname)
+        rf.release_domain()
+
+
 def test_two_host_threads_call_the_multi_device_msm_at_once(hip, slots):
     """collectives of two calls on one communicator set must not interleave -- the per-set mutex serialises
     host threads that enter a multi-device msm() on the same devices at the same time (ctypes drops the GIL in the call)."""
@@ -465,4 +497,36 @@ def test_resident_copies_die_with_the_allocation(hip, slots):
         assert np.array_equal(refc.to_affine(got2), refc.to_affine(refc.msm(sc, bases2))), ("stale resident copy served", d2.ptr == addr)
         assert st["staged_base_bytes"] > 0 and st["resident_base_hits"] == 0, st
     finally:
+        lib.destroy_config_extension(ext)
+
+
+def test_resident_copies_versioned_by_the_callers_generation(hip, slots):
+    """memory that does not come from icicle_malloc (here: a host array rewritten IN PLACE) cannot tell the cache
+    that its contents changed -- "hip_bases_generation" is part of the key, so a new value stages fresh copies, and the old
+    value keeps serving the old ones until they are released."""
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib, multi_stats
+
+    C, rng, bases, sc = _inputs("bn254", 2500, 6161)
+    refc = ref.RefCurve("bn254")
+    buf = bases.copy()
+    exp1 = refc.to_affine(refc.msm(sc, buf))
+    slots(4)
+    ext = _ext(hip_num_devices=4, hip_bases_resident=True, hip_bases_generation=1)
+    try:
+        cfg = hip.MSMConfig.default()
+        cfg.ext = ext
+        assert np.array_equal(refc.to_affine(M.msm("bn254", sc, buf, cfg)), exp1)
+        buf[:] = bases[::-1]  # same address, other points
+        exp2 = refc.to_affine(refc.msm(sc, buf))
+        lib.config_extension_set_int(ext, b"hip_bases_generation", 2)
+        multi_stats(reset=True)
+        assert np.array_equal(refc.to_affine(M.msm("bn254", sc, buf, cfg)), exp2)
+        st = multi_stats()
+        assert st["staged_base_bytes"] == buf.nbytes and st["resident_base_hits"] == 0, st
+        multi_stats(reset=True)
+        assert np.array_equal(refc.to_affine(M.msm("bn254", sc, buf, cfg)), exp2)  # generation 2 again: served from the copies
+        assert multi_stats()["staged_base_bytes"] == 0
+    finally:
+        lib.icicle_hip_msm_release_resident_bases(None)
         lib.destroy_config_extension(ext)
