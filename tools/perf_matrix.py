@@ -67,6 +67,34 @@ def ntt_case(field, logn, batch):
     N.release_domain(field)
 
 
+def msm_distribution_case(dist, logn):
+    """BN254 MSM under the reference's input distributions (tests/test_gpu_msm_distributions.py make_inputs): uniform,
+    period-100 bases (projective.h:43-53), the Rust suite's skewed scalars (msm/tests.rs:256-276); phase split from the
+    library's event timers"""
+    import ctypes
+    from tests.test_gpu_msm_distributions import make_inputs
+
+    n = 1 << logn
+    sc, bases = make_inputs(dist, logn, dev)
+    res = torch.empty((1, 24), dtype=torch.int32, device=dev)
+    cfg = MSMConfig.default()
+    cfg.is_async = True
+    run = lambda: M.msm("bn254", sc.data_ptr(), bases.data_ptr(), cfg, results=res.data_ptr(), msm_size=n)
+    ms = time_it(run)
+    lib.icicle_hip_enable_kernel_timing(True)
+    tot, cnt = ctypes.c_double(), ctypes.c_int()
+    for which in (0, 2, 3):
+        lib.icicle_hip_kernel_timing(which, True, ctypes.byref(tot), ctypes.byref(cnt))
+    run()
+    torch.cuda.synchronize()
+    ph = []
+    for which, name in ((2, "digits+sort"), (0, "accumulate"), (3, "reduce+combine")):
+        lib.icicle_hip_kernel_timing(which, True, ctypes.byref(tot), ctypes.byref(cnt))
+        ph.append(f"{name} {tot.value:7.2f}")
+    lib.icicle_hip_enable_kernel_timing(False)
+    print(f"msm bn254 2^{logn:<2d} {dist:10s} {ms:9.3f} ms   [{', '.join(ph)} ms]", flush=True)
+
+
 def ntt_layout_case(field, logn, batch, layout, ordering=0):
     """the interleaved layouts next to the row-major batch of the same byte count: layout = "rows" | "columns" (columns_batch,
     element j of transform b at j * batch + b) | "ext" (batch rows of quartic-extension elements = 4 * batch lane transforms)"""
@@ -109,7 +137,7 @@ def ntt_scalar_case(field, logn, batch):
     N.release_domain(field)
 
 
-def msm_precompute_case(curve, logn, pf, batch=1):
+def msm_precompute_case(curve, logn, pf, batch=1, c=0):
     """the reference's precompute sweep (docs/docs/api/cpp/msm.md:186-201, wrappers/rust/icicle-core/src/msm/mod.rs:386-470):
     msm_precompute_bases once, then timed msm() calls with precompute_factor = pf (shared bases over the batch)"""
     n = 1 << logn
@@ -125,6 +153,7 @@ def msm_precompute_case(curve, logn, pf, batch=1):
     cfg.batch_size = batch
     cfg.is_async = True
     cfg.precompute_factor = pf
+    cfg.c = c
     table = bases
     t_pre = 0.0
     if pf > 1:
@@ -134,7 +163,10 @@ def msm_precompute_case(curve, logn, pf, batch=1):
         torch.cuda.synchronize()
         t_pre = (time.perf_counter() - t0) * 1e3
     ms = time_it(lambda: M.msm(curve, sc.data_ptr(), table.data_ptr(), cfg, results=res.data_ptr(), msm_size=n))
-    print(f"msm {curve:10s} 2^{logn:<2d} batch {batch:<4d} precompute_factor {pf}  {ms:9.3f} ms  (precompute_bases {t_pre:8.2f} ms)", flush=True)
+    import ctypes
+    pc, pw = ctypes.c_int(), ctypes.c_int()
+    check(lib.icicle_hip_msm_plan(n, 254, ctypes.byref(cfg), ctypes.byref(pc), ctypes.byref(pw)))
+    print(f"msm {curve:10s} 2^{logn:<2d} batch {batch:<4d} precompute_factor {pf} c = {pc.value:<2d}{' (forced)' if c else '         '} {ms:9.3f} ms  (precompute_bases {t_pre:8.2f} ms)", flush=True)
 
 
 def ecntt_case(curve, logn, batch=1):
@@ -265,6 +297,18 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ntt":
         for logn, batch in ((12, 4096), (16, 1024), (20, 256), (22, 128), (24, 64), (24, 8), (25, 32), (26, 16), (27, 8), (27, 4)):
             ntt_case("babybear", logn, batch)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pfsweep":  # window size against precompute_factor: the fit behind msm_plan.h
+        for logn, cs in ((16, (11, 12, 13, 15, 16)), (18, (13, 15, 16, 17)), (20, (15, 16, 17, 19, 20)), (22, (16, 17, 19, 20)), (24, (17, 19, 20))):
+            for pf in (4, 8):
+                msm_precompute_case("bn254", logn, pf)
+                for c in cs:
+                    msm_precompute_case("bn254", logn, pf, c=c)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "distributions":
+        for logn in (22, 26):
+            for dist in ("uniform", "period100", "skewed"):
+                msm_distribution_case(dist, logn)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "layouts":  # interleaved layouts vs the row-major batch of the same bytes
         for field, logn, b in (("koalabear", 22, 64), ("babybear", 22, 32), ("babybear", 16, 1024), ("babybear", 24, 16), ("babybear", 20, 100)):
