@@ -107,7 +107,11 @@ namespace icicle_hip {
     p.wpf = (p.nwin + p.pf - 1) / p.pf;
     p.nb = 1u << (c - 1);
     {
-      const double avg = (double)n * p.pf * ((double)p.nwin / p.wpf) / (double)p.nb; // points per bucket
+      // points per bucket: the nwin windows of a scalar land in wpf bucket sets. (Rounds 1-3 had one more factor pf here: with
+      // a base table the segments came out pf times too long, and the handful of buckets that take the whole short top window
+      // -- n / 2^(top bits - 1) points each -- were walked by a few threads in chains of thousands of additions: pf = 8, c = 19
+      // at 2^24 took 49.9 ms against 19.9 ms at c = 20, profiles/r04_precompute_sweep.txt.)
+      const double avg = (double)n * ((double)p.nwin / p.wpf) / (double)p.nb;
       uint32_t sgm = 64;
       while ((double)sgm < 2.0 * avg)
         sgm <<= 1;
