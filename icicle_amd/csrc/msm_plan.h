@@ -91,7 +91,10 @@ namespace icicle_hip {
         double cost;
         if (mid) {
           const double occupancy = std::max(1.0, 2.5 * 65536.0 / nbk); // bucket threads per SIMD lane slot
-          cost = (double)w * n * occupancy + (n >= (1 << 22) ? 4.0 : 2.0) * nbk; // (below 2^22 the reduction is latency-, not throughput-bound)
+          // (below 2^22 the reduction is latency-, not throughput-bound -- but with a base table there are few bucket sets, and a
+          //  wider window buys them at the full price: fitted to profiles/r04_precompute_csweep.txt, e.g. 2^18, pf 8: c = 17 1.96 ms,
+          //  c = 19 2.29 ms)
+          cost = (double)w * n * occupancy + ((table || n >= (1 << 22)) ? 4.0 : 2.0) * nbk;
         } else {
           cost = (double)w * n + 8.0 * nbk;
         }

@@ -622,7 +622,8 @@ namespace icicle_hip {
         const size_t lds_bytes = (size_t)2 * L * (tw + 1) * 4;
         // rows of the batch handled by one block (twiddles are loaded once per block): aim for >= 4096 blocks
         const uint64_t total_blocks = (uint64_t)pd.ntiles * nlp.nrows_launch;
-        const uint32_t rpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nlp.nrows_launch, total_blocks / 4096));
+        static const uint64_t min_blocks = getenv("ICICLE_HIP_NTT_MIN_BLOCKS") ? std::max(1, atoi(getenv("ICICLE_HIP_NTT_MIN_BLOCKS"))) : 4096;
+        const uint32_t rpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nlp.nrows_launch, total_blocks / min_blocks));
         const uint32_t gy = (nlp.nrows_launch + rpb - 1) / rpb;
         // the coset factors touch the first pass (forward) or the last one (inverse) only
         const bool cvar = nl.coset && (nl.inverse ? pd.is_last != 0 : p == 0);

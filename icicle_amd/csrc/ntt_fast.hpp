@@ -184,6 +184,7 @@ namespace icicle_hip {
       // takes 2^16 distinct values shared by every block -- both live in L2 / Infinity Cache.
       const uint64_t jnext = ((uint64_t)ct * TC + cB) / pd.cprime;
       const uint32_t wa = (pd.pidx == 0) ? 0u : tw_load(jnext * a * pd.tw_stride);
+#if defined(NTT_WIP_LOADS) // (rounds 1-3, kept for A/B builds: every factor loaded from the table)
 #pragma unroll
       for (int m = 0; m < E; m++) {
         const uint32_t k = (NR == 1) ? (uint32_t)m : baseT + ((uint32_t)m << QT);
@@ -192,6 +193,20 @@ namespace icicle_hip {
         else
           wip[m] = S::mul(wa, tw_load(jnext * pd.n0 * k * pd.tw_stride));
       }
+#else
+      // The thread's E rows k = baseT + (m << QT) form an arithmetic progression, so its factors form a geometric one:
+      // two table reads and E - 1 products instead of E reads. In pass 1 those reads are 4-byte gathers, a 64-byte sector each
+      // and 8192 of them per block: with few batch rows per block to spread them over (small batches, the lane-native
+      // tiles of columns_batch) they were MORE traffic than the data -- 512 KB against 64 KB per row at 2^24 x 8.
+      // Exact: table entries are exact powers, so the products are the same field elements, stored canonically.
+      const uint64_t kfac = (pd.pidx == 0) ? 1u : (uint64_t)pd.n0;
+      const uint32_t step = tw_load(jnext * kfac * ((uint64_t)1 << QT) * pd.tw_stride);
+      const uint32_t first = tw_load(jnext * kfac * baseT * pd.tw_stride);
+      wip[0] = (pd.pidx == 0) ? first : S::mul(wa, first);
+#pragma unroll
+      for (int m = 1; m < E; m++)
+        wip[m] = S::mul(wip[m - 1], step);
+#endif
     }
 
     // ---- coset factors, once per block (they do not depend on the batch row) ------------------------
