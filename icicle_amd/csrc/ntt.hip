@@ -620,9 +620,11 @@ namespace icicle_hip {
         }
         const unsigned threads = (unsigned)(tw * (L / epb));
         const size_t lds_bytes = (size_t)2 * L * (tw + 1) * 4;
-        // rows of the batch handled by one block (twiddles are loaded once per block): aim for >= 4096 blocks
+        // rows of the batch handled by one block (twiddles are loaded once per block): aim for >= 1024 blocks = two rounds of
+        // the 2 x 256 resident ones (4096 through round 3; same box, profiles/r04_ntt_twiddle_ab.txt: 2^20 x 256 1.39 -> 1.32 ms,
+        // 2^16 x 1024 0.272 -> 0.244, 2^24 x 64 5.50 -> 5.45; the per-block twiddle prologue is what the extra rows amortise)
         const uint64_t total_blocks = (uint64_t)pd.ntiles * nlp.nrows_launch;
-        static const uint64_t min_blocks = getenv("ICICLE_HIP_NTT_MIN_BLOCKS") ? std::max(1, atoi(getenv("ICICLE_HIP_NTT_MIN_BLOCKS"))) : 4096;
+        static const uint64_t min_blocks = getenv("ICICLE_HIP_NTT_MIN_BLOCKS") ? std::max(1, atoi(getenv("ICICLE_HIP_NTT_MIN_BLOCKS"))) : 1024;
         const uint32_t rpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nlp.nrows_launch, total_blocks / min_blocks));
         const uint32_t gy = (nlp.nrows_launch + rpb - 1) / rpb;
         // the coset factors touch the first pass (forward) or the last one (inverse) only

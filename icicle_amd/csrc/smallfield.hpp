@@ -25,12 +25,20 @@ namespace icicle_hip {
     static SF_HD uint32_t add(uint32_t a, uint32_t b)
     {
       uint32_t s = a + b;
+#if defined(NTT_EXP_NO_CORRECTION) // WHAT-IF build only (wrong results): how much of a pass is the add/sub correction work?
+      return s;
+#else
       return umin(s, s - P);
+#endif
     }
     static SF_HD uint32_t sub(uint32_t a, uint32_t b)
     {
       uint32_t d = a - b;
+#if defined(NTT_EXP_NO_CORRECTION)
+      return d;
+#else
       return umin(d, d + P);
+#endif
     }
     static SF_HD uint32_t neg(uint32_t a) { return sub(0, a); }
     // t < p * 2^32  ->  t / 2^32 mod p, in [0,p)
