@@ -200,6 +200,88 @@ namespace icicle_hip {
 #endif
   }
 
+  // ---- radix-2^r "matrix form" stages: r radix-2 stages for the LATENCY of one scalar multiplication -----------------
+  // A stage's time is the latency of one k * P chain (~1 ms), whatever the number of butterflies, as long as they fit the
+  // chip -- and a transform of 2^10 .. 2^13 points has far fewer butterflies than the chip has lanes. So r stages are taken
+  // at once: with L = 2^q0, R = 2^r, M = L R, the R sub-transforms A_j (memory order j, i.e. residue rev_r(j) mod R)
+  // combine as            Y[pos + L k] = sum_j  w_M^(rev(j) (pos + L k)) A_j[pos],        k = 0 .. R-1,
+  // and EVERY product of that sum is computed at the same time, one DPP quad each (k_ecntt_terms), followed by a
+  // short chain of additions (k_ecntt_sums). Only u = k mod R/2 needs a product of its own: w_M^(rev(j) L R/2) = (-1)^rev(j),
+  // so Y[u + R/2] takes the terms of the odd residues (j >= R/2) with a minus sign. n (R - 1) / 2 scalar multiplications per
+  // stage instead of n / 2 -- (R - 1) times the work for 1 / r of the latency: 2^10 points run as 5 + 5 (2 chains instead of
+  // 10), 2^12 as 3 + 3 + 3 + 3; where the work would no longer fit one round of quads (2^14 and up) r falls back to 1.
+  // The R / 2 quads that multiply the same A_j share its 16-entry table in LDS (they build identical copies of it).
+  struct EcStage {
+    int q0, r; // covers the radix-2 stages q0 .. q0 + r - 1
+  };
+  template <class C>
+  __global__ __launch_bounds__(64) void k_ecntt_terms(const typename EC<C>::Proj* __restrict__ work, typename EC<C>::Proj* __restrict__ terms, const uint32_t* __restrict__ tw, EcLayout lay, EcStage sg)
+  {
+    using T = EcNtt<C>;
+    using E = typename T::E;
+    extern __shared__ uint32_t tabs_raw[]; // [16 / hr tables][16 multiples]: quads with the same (group, j) share a table
+    typename E::Proj* tabs = reinterpret_cast<typename E::Proj*>(tabs_raw);
+    const uint32_t role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+    const uint32_t R = 1u << sg.r, hr = R >> 1;         // hr = products per (group, j)
+    const uint64_t L = (uint64_t)1 << sg.q0;
+    const uint64_t ngroups = (lay.n >> sg.r) * lay.batch; // (transform, block of M, pos)
+    const uint64_t nitems = ngroups * (R - 1) * hr;
+    const uint64_t item0 = (blockIdx.x * (uint64_t)16 + quad);
+    const bool live = item0 < nitems;
+    const uint64_t item = live ? item0 : nitems - 1; // (a quad past the end redoes the last item and stores nothing)
+    const uint32_t u = (uint32_t)(item % hr);
+    const uint64_t pair = item / hr;
+    const uint32_t j = (uint32_t)(pair % (R - 1)) + 1;
+    const uint64_t grp = pair / (R - 1);
+    const uint64_t per_t = lay.n >> sg.r; // groups per transform
+    const uint64_t b = grp / per_t, g = grp % per_t;
+    const uint64_t pos = g & (L - 1), blk = g >> sg.q0;
+    const typename E::Proj a = work[b * lay.n + (blk << (sg.q0 + sg.r)) + (uint64_t)j * L + pos];
+    // exponent rev_r(j) * (pos + L u) mod M, as an index into the domain table (w_max^i)
+    const uint32_t rj = __brev(j) >> (32 - sg.r);
+    const uint64_t Mmask = ((uint64_t)1 << (sg.q0 + sg.r)) - 1;
+    const uint64_t e = ((uint64_t)rj * (pos + L * u)) & Mmask;
+    const uint64_t max_mask = ((uint64_t)1 << lay.log_max) - 1;
+    uint64_t idx = e << (lay.log_max - (uint32_t)(sg.q0 + sg.r));
+    if (lay.inverse) idx = (((uint64_t)1 << lay.log_max) - idx) & max_mask;
+    uint32_t k[8];
+    T::canonical_from_mont(k, tw + idx * 8); // (w^0 = 1 is in the table: k = 1, one table read and no doubling)
+    const typename E::Proj t = T::mul_words_quad(a, k, role, tabs + (size_t)(quad / hr) * 16);
+    if (live && role == 0) terms[item] = t;
+  }
+  // Y[u] = A_0 + sum_{j < R/2} T_j + sum_{j >= R/2} T_j ,  Y[u + R/2] = A_0 + sum_{j < R/2} T_j - sum_{j >= R/2} T_j ; one quad per pair
+  template <class C>
+  __global__ __launch_bounds__(64) void k_ecntt_sums(const typename EC<C>::Proj* __restrict__ work, const typename EC<C>::Proj* __restrict__ terms, typename EC<C>::Proj* __restrict__ next, EcLayout lay, EcStage sg)
+  {
+    using T = EcNtt<C>;
+    using E = typename T::E;
+    const uint32_t role = threadIdx.x & 3u;
+    const uint32_t R = 1u << sg.r, hr = R >> 1;
+    const uint64_t L = (uint64_t)1 << sg.q0;
+    const uint64_t per_t = lay.n >> sg.r;
+    const uint64_t ngroups = per_t * lay.batch;
+    const uint64_t nout = ngroups * hr;
+    const uint64_t o0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 2;
+    const bool live = o0 < nout;
+    const uint64_t o = live ? o0 : nout - 1;
+    const uint32_t u = (uint32_t)(o % hr);
+    const uint64_t grp = o / hr;
+    const uint64_t b = grp / per_t, g = grp % per_t;
+    const uint64_t pos = g & (L - 1), blk = g >> sg.q0;
+    const uint64_t base = b * lay.n + (blk << (sg.q0 + sg.r)) + pos;
+    const typename E::Proj* tg = terms + (grp * (R - 1)) * hr + u; // term (j, u) at tg[(j - 1) * hr]
+    typename E::Proj ev = work[base], od = tg[(size_t)(hr - 1) * hr]; // A_0 ; T_{R/2}
+    for (uint32_t j = 1; j < hr; j++)
+      ev = E::add_quad(ev, tg[(size_t)(j - 1) * hr], role);
+    for (uint32_t j = hr + 1; j < R; j++)
+      od = E::add_quad(od, tg[(size_t)(j - 1) * hr], role);
+    const typename E::Proj y0 = E::add_quad(ev, od, role), y1 = E::add_quad(ev, T::neg(od), role);
+    if (live && role == 0) {
+      next[base + (uint64_t)u * L] = y0;
+      next[base + (uint64_t)(u + hr) * L] = y1;
+    }
+  }
+
   // out[slot(k)] = (1/N * g^-k on the inverse) * work[b][k], in the reference's projective_t layout
   template <class C>
   __global__ __launch_bounds__(64) void k_ecntt_store(const typename EC<C>::Proj* __restrict__ work, uint32_t* __restrict__ out, const uint32_t* __restrict__ coset_pow, BigWords ninv_canonical, EcLayout lay)
@@ -254,7 +336,7 @@ namespace icicle_hip {
     constexpr size_t PWB = (size_t)3 * E::N32 * 4; // bytes per projective_t
     const size_t bytes = (size_t)n * batch * PWB;
 
-    TempBuf d_in_tmp, d_out_tmp, d_pw, d_work;
+    TempBuf d_in_tmp, d_out_tmp, d_pw, d_work, d_terms, d_next; // (d_terms / d_next: the matrix-form stages; alive until the store kernel is queued)
     const uint32_t* d_in = (const uint32_t*)input_v;
     uint32_t* d_out = (uint32_t*)output_v;
     if (!cfg->are_inputs_on_device) {
@@ -301,9 +383,45 @@ namespace icicle_hip {
     Proj* work = d_work.as<Proj>();
     k_ecntt_load<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(d_in, work, d_pw.as<uint32_t>(), lay);
     LAUNCH_CHECK("k_ecntt_load", st);
-    for (int q = 0; q < logn; q++) {
-      k_ecntt_stage<C><<<(unsigned)((tot / 2 * 4 + 63) / 64), 64, 0, st>>>(work, dom.tw, lay, q);
-      LAUNCH_CHECK("k_ecntt_stage", st);
+    // stage radix: the largest r <= 5 whose n (R - 1) / 2 products still fit one round of quads on the chip (the budget is
+    // a measured knee, not a hard limit: beyond it a stage simply takes a second round); ICICLE_HIP_ECNTT_RADIX_LOG forces r
+    static const int forced_r = getenv("ICICLE_HIP_ECNTT_RADIX_LOG") ? atoi(getenv("ICICLE_HIP_ECNTT_RADIX_LOG")) : 0;
+    static const uint64_t budget = getenv("ICICLE_HIP_ECNTT_QUADS") ? (uint64_t)atoll(getenv("ICICLE_HIP_ECNTT_QUADS")) : 16384;
+    int rmax = 1;
+    if (forced_r > 0) {
+      rmax = std::min(5, forced_r);
+    } else {
+      while (rmax < 5 && tot * ((2ull << rmax) - 1) / 2 <= budget)
+        rmax++;
+    }
+    rmax = std::max(1, std::min(rmax, logn));
+    if (rmax == 1) {
+      for (int q = 0; q < logn; q++) {
+        k_ecntt_stage<C><<<(unsigned)((tot / 2 * 4 + 63) / 64), 64, 0, st>>>(work, dom.tw, lay, q);
+        LAUNCH_CHECK("k_ecntt_stage", st);
+      }
+    } else if (logn > 0) {
+      const int nst = (logn + rmax - 1) / rmax; // stages, their widths as even as possible
+      const uint64_t max_items = tot * ((1ull << rmax) - 1) / 2; // n (R - 1) / 2 products of the widest stage
+      HIP_TRY(d_terms.alloc((size_t)max_items * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(d_next.alloc((size_t)tot * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
+      Proj* cur = work;
+      Proj* nxt = d_next.as<Proj>();
+      int q0 = 0;
+      for (int si = 0; si < nst; si++) {
+        const int r = logn / nst + (si < logn % nst ? 1 : 0);
+        const EcStage sg{q0, r};
+        const uint64_t items = (tot >> r) * ((1ull << r) - 1) * (1ull << (r - 1));
+        const size_t tab_bytes = (size_t)std::max(1, 16 >> (r - 1)) * 16 * sizeof(Proj); // 16 / (R / 2) tables per 16-quad block
+        k_ecntt_terms<C><<<(unsigned)((items + 15) / 16), 64, tab_bytes, st>>>(cur, d_terms.as<Proj>(), dom.tw, lay, sg);
+        LAUNCH_CHECK("k_ecntt_terms", st);
+        const uint64_t nout = tot >> 1;
+        k_ecntt_sums<C><<<(unsigned)((nout * 4 + 63) / 64), 64, 0, st>>>(cur, d_terms.as<Proj>(), nxt, lay, sg);
+        LAUNCH_CHECK("k_ecntt_sums", st);
+        std::swap(cur, nxt);
+        q0 += r;
+      }
+      work = cur;
     }
     k_ecntt_store<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(work, d_out, d_pw.as<uint32_t>(), ninv, lay);
     LAUNCH_CHECK("k_ecntt_store", st);

@@ -107,9 +107,50 @@ def test_ecntt_device_and_errors(env, hip):
         N.ecntt(cname, x, N.FORWARD, size=1 << (DOMAIN_LOG + 1))  # larger than the domain
 
 
+@pytest.mark.parametrize("radix_log", [1, 2, 3, 4, 5])
+def test_ecntt_every_stage_radix_vs_reference(hip, radix_log):
+    """the radix-2^r matrix-form stages (icicle_amd/csrc/ecntt.hip: k_ecntt_terms / k_ecntt_sums) with r forced through
+    ICICLE_HIP_ECNTT_RADIX_LOG (read once per process, hence a child process): 2^7 and 2^9 points -- uneven stage widths, e.g.
+    r = 4: 4 + 3 and 3 + 3 + 3 -- forward and inverse, a batch, bit-reversed orderings and a coset, against the reference CPU backend"""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import icicle_amd as hip
+from icicle_amd import ntt as N, runtime
+from oracle import pyref, ref
+from tests.util import to_words
+runtime.set_device(0)
+cname = "bn254"
+C, F = pyref.CURVES[cname], pyref.NTT_FIELDS[cname]
+refc, sf = ref.RefCurve(cname), ref.RefScalarNttField(cname)
+root = N.get_root_of_unity(cname, 1 << 9)
+N.init_domain(cname, root); sf.init_domain(root)
+L = C.limbs_q
+for logn, batch, columns, ordering, direction, coset in ((7, 1, False, 0, 0, 1), (7, 3, True, 3, 1, 5), (9, 1, False, 1, 1, 1), (9, 2, False, 2, 0, 11)):
+    n = 1 << logn
+    base = refc.generate_affine_points(n * batch)
+    x = np.ascontiguousarray(np.concatenate([base, np.tile(to_words([1], L), (n * batch, 1))], axis=1).astype(np.uint32)).reshape(-1)
+    cfg = hip.NTTConfigU256.default()
+    cfg.batch_size, cfg.columns_batch, cfg.ordering = batch, columns, ordering
+    cfg.set_coset_gen(coset)
+    got = N.ecntt(cname, x, direction, cfg)
+    exp = refc.ecntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset)
+    assert np.array_equal(refc.to_affine(got.reshape(-1, 3 * L)), refc.to_affine(exp.reshape(-1, 3 * L))), (logn, batch, columns, ordering, direction, coset)
+print("RADIX OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["ICICLE_HIP_ECNTT_RADIX_LOG"] = str(radix_log)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RADIX OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_ecntt_timing_vs_reference_cpu(hip):
-    """ECNTT 2^10 / 2^12 timed on the GPU and on the reference CPU backend (the box's host cores),
-    results equal as group elements; the numbers are appended to gpurun_out/ecntt_timing.txt (copied into profiles/)."""
+    """ECNTT 2^10 .. 2^16 timed on the GPU and on the reference CPU backend (the box's host
+    cores), results equal as group elements; the numbers are appended to gpurun_out/ecntt_timing.txt (copied into profiles/)."""
     import os
     import time
 
@@ -120,12 +161,12 @@ def test_ecntt_timing_vs_reference_cpu(hip):
     L = C.limbs_q
     refc = ref.RefCurve(cname)
     sf = ref.RefScalarNttField(cname)
-    root = N.get_root_of_unity(cname, 1 << 12)
+    root = N.get_root_of_unity(cname, 1 << 16)
     N.init_domain(cname, root)
     sf.init_domain(root)
     lines = []
     try:
-        for logn in (10, 12):
+        for logn in (10, 12, 14, 16):
             n = 1 << logn
             base = refc.generate_affine_points(n)
             x = np.ascontiguousarray(np.concatenate([base, np.tile(to_words([1], L), (n, 1))], axis=1).astype(np.uint32)).reshape(-1)

@@ -330,7 +330,7 @@ if __name__ == "__main__":
                 msm_precompute_case("bn254", logn, pf, batch)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ecntt":
-        for logn in (10, 12, 14):
+        for logn in (8, 10, 11, 12, 13, 14, 16):
             ecntt_case("bn254", logn)
         ecntt_case("bls12_381", 10)
         ecntt_case("bn254", 10, batch=8)
