@@ -562,7 +562,8 @@ namespace icicle_hip {
     for (uint32_t tile0 = r0; tile0 < r1; tile0 += SORT_TS) {
       uint32_t nxt[SORT_EPT];
       fetch(tile0 + SORT_TS, nxt); // past the end of the run every lane is predicated off (zeros)
-      if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
+      for (uint32_t k = threadIdx.x; k < D; k += 1024) // (D = 2048 bins at c = 22: two per thread)
+        t.cnt[k] = 0;
       // source block (scalar chunk) of an element = last bsrc with boffs[bsrc] <= pos. One binary search per
       // 64 consecutive positions (256 threads, once per tile); an element then starts from its group's answer
       // and walks forward (pieces are ~64 elements long, so 0-2 steps) instead of 10 dependent LDS reads each.
@@ -600,11 +601,21 @@ namespace icicle_hip {
         }
       }
       __syncthreads();
-      const uint32_t mycnt = threadIdx.x < D ? t.cnt[threadIdx.x] : 0;
-      const uint32_t toff = block_exscan(mycnt, t.wsum);
-      if (threadIdx.x < D) {
-        t.cnt[threadIdx.x] = toff;
-        t.gbase[threadIdx.x] = mycnt ? atomicAdd(&cw[threadIdx.x], mycnt) : 0u; // reserve the run in the bucket list
+      if (D <= 1024) {
+        const uint32_t mycnt = threadIdx.x < D ? t.cnt[threadIdx.x] : 0;
+        const uint32_t toff = block_exscan(mycnt, t.wsum);
+        if (threadIdx.x < D) {
+          t.cnt[threadIdx.x] = toff;
+          t.gbase[threadIdx.x] = mycnt ? atomicAdd(&cw[threadIdx.x], mycnt) : 0u; // reserve the run in the bucket list
+        }
+      } else { // 2048 bins (lb = 11, window size 22): bins 2 tid and 2 tid + 1
+        const uint32_t k0 = 2 * threadIdx.x;
+        const uint32_t m0 = t.cnt[k0], m1 = t.cnt[k0 + 1];
+        const uint32_t toff = block_exscan(m0 + m1, t.wsum);
+        t.cnt[k0] = toff;
+        t.cnt[k0 + 1] = toff + m0;
+        t.gbase[k0] = m0 ? atomicAdd(&cw[k0], m0) : 0u;
+        t.gbase[k0 + 1] = m1 ? atomicAdd(&cw[k0 + 1], m1) : 0u;
       }
       __syncthreads();
 #pragma unroll
@@ -1283,8 +1294,8 @@ namespace icicle_hip {
       // windows (kb <= 10) need a single level: pass A already produces the bucket lists
       int hb = kb <= 10 ? kb : (kb + 1) / 2;
       if (const char* e = getenv("ICICLE_HIP_MSM_HB")) hb = atoi(e);
-      hb = std::max(kb - 10, std::min(std::min(kb, 10), hb));
-      if (hb < 0 || hb > 10 || kb - hb > 10) return ICICLE_INVALID_ARGUMENT;
+      hb = std::max(kb - 11, std::min(std::min(kb, 10), hb)); // pass A: at most 2^10 partitions; pass B: up to 2^11 bins (c = 22)
+      if (hb < 0 || hb > 10 || kb - hb > 11) return ICICLE_INVALID_ARGUMENT;
       sp.hb = hb;
       sp.lb = kb - hb;
       sp.jb = 0;

@@ -104,7 +104,10 @@ namespace icicle_hip {
         }
       }
     }
-    c = std::min(21, std::max(2, c)); // two-level sort: 2^hb partitions (pass A) x 2^lb bins (pass B), hb, lb <= 10
+    // two-level sort: 2^hb partitions (pass A, hb <= 10) x 2^lb bins (pass B, lb <= 11). The model above stops at 21: a caller-set
+    // 22 runs (12 windows of a 254-bit scalar instead of 13, four times the buckets of c = 20) and was measured slower at 2^26
+    // (profiles/r04_msm_csweep.txt)
+    c = std::min(22, std::max(2, c));
     p.c = c;
     p.nwin = (p.bits + 1 + c - 1) / c;
     p.wpf = (p.nwin + p.pf - 1) / p.pf;

@@ -400,3 +400,22 @@ def test_inplace_asm_products_with_aliased_and_constant_operands(hip, curve_id):
     bad = ctypes.c_int(-1)
     check(lib.icicle_hip_selftest_inplace_products(curve_id, ctypes.byref(bad)), "selftest")
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_msm_window_size_22_forced(hip, cname):
+    """config.c = 22 (12 windows of a 254 / 255-bit scalar; pass B of the sort then ranks into 2^11 bins, two per thread):
+    never chosen by the plan -- it measured slower, profiles/r04_msm_csweep.txt -- but a caller may ask for it. 2^18 uniform
+    scalars plus the skewed mix (two hot buckets -> overflow segments) against the reference CPU backend."""
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(2222)
+    n = (1 << 18) - 7
+    bases = M.generate_affine_points(cname, n, k0=31337)
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    _check(hip, cname, sc, bases, refc, c=22)
+    sc[: n // 2, 1:] = 0
+    sc[: n // 2, 0] = rng.integers(1, 3, size=n // 2)
+    _check(hip, cname, sc, bases, refc, c=22)

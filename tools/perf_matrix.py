@@ -241,7 +241,7 @@ def criterion_sweep():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "csweep":
         sweep = ((10, (7, 8, 9, 10, 11)), (12, (8, 9, 10, 11, 12)), (14, (9, 10, 11, 12, 13, 14)), (16, (10, 11, 12, 13, 14, 15)), (18, (12, 13, 14, 15, 16, 17)), (20, (14, 15, 16, 17, 18)),
-                 (21, (15, 16, 17, 18, 19)), (22, (15, 16, 17, 18, 19)), (23, (16, 17, 18, 19, 20)), (24, (17, 18, 19, 20, 21)), (25, (18, 19, 20, 21)), (26, (19, 20, 21)))
+                 (21, (15, 16, 17, 18, 19)), (22, (15, 16, 17, 18, 19)), (23, (16, 17, 18, 19, 20)), (24, (17, 18, 19, 20, 21)), (25, (18, 19, 20, 21, 22)), (26, (19, 20, 21, 22)))
         if len(sys.argv) > 2:
             sweep = tuple(x for x in sweep if x[0] == int(sys.argv[2]))
         for logn, cs in sweep:
