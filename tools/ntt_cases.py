@@ -29,12 +29,12 @@ for spec in sys.argv[1:]:
     cfg.batch_size, cfg.is_async, cfg.columns_batch = batch, True, cols
     res = []
     for d in (N.FORWARD, N.INVERSE):
-        for _ in range(3):
+        for _ in range(int(os.environ.get("NTT_CASES_WARM", "3"))):  # (a long warm-up separates clock ramp-up from the kernel's own cost)
             N.ntt("babybear", x.data_ptr(), d, cfg, out=y.data_ptr(), size=n)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        reps = 8
+        reps = int(os.environ.get("NTT_CASES_REPS", "8"))
         for _ in range(reps):
             N.ntt("babybear", x.data_ptr(), d, cfg, out=y.data_ptr(), size=n)
         e1.record()

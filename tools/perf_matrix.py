@@ -19,13 +19,25 @@ TOP = {"bn254": 0x30644E72, "bls12_381": 0x73EDA753, "bls12_377": 0x12AB655E, "g
 
 
 def time_it(fn, reps=3):
+    """ms per call. Warm-up runs for >= 40 ms of back-to-back calls: after an idle gap the first milliseconds of work run at
+    ramping clocks (2^24 x 8 BabyBear: 0.89 ms after 3 warm-up calls, 0.71 ms after 100 -- profiles/r04_notes.md), which rounds
+    1-3 booked against every sub-millisecond row of this matrix; then >= `reps` calls and >= 40 ms are timed."""
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(reps):
+    one = None
+    while time.perf_counter() - t0 < 0.04:
+        fn()
+        if one is None:
+            torch.cuda.synchronize()
+            one = max(1e-5, time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    n = max(reps, min(200, int(0.04 / one) + 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e3
+    return (time.perf_counter() - t0) / n * 1e3
 
 
 def msm_case(curve, logn, batch=1, pf=1, g2=False, c=0):
