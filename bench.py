@@ -360,7 +360,7 @@ def main():
     # run rocprofv3 on itself); only attached when the workload matches the profiled one. FETCH_SIZE is calibrated on
     # a kernel with the same access pattern and a known byte count (icicle_hip_ubench_gather under the same counter).
     pmc = {}
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)

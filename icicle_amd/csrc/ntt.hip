@@ -599,12 +599,24 @@ namespace icicle_hip {
       uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (big ? 1024 : 512) * epb / L));
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
         tmax >>= 1;
-      // lane-native: the tile's tmax word-columns are (tmax >> lsh) logical columns x 2^lsh interleaved transforms
+      // lane-native: the tile's tmax word-columns are (tmax >> lsh) logical columns x 2^lsh interleaved transforms. A lane count
+      // that is not a multiple of the widest slice runs as two launches: the full slices, then the remaining lanes on a
+      // narrower slice (100 columns = 3 x 32 + one launch of 4-lane tiles) instead of a last slice with most lanes masked off
+      struct LanePart {
+        uint32_t lane0, count;
+      };
+      LanePart lparts[2] = {{0, ltot}, {0, 0}};
+      if (lane_native && ltot > tmax && ltot % tmax != 0) {
+        lparts[0] = {0, ltot - ltot % tmax};
+        lparts[1] = {ltot - ltot % tmax, ltot % tmax};
+      }
+      PassDesc pd{};
+      for (int lp = 0; lp < 2 && lparts[lp].count > 0; lp++) {
       uint32_t lsh = 0;
       if (lane_native)
-        while ((2u << lsh) <= tmax && (1u << lsh) < ltot)
+        while ((2u << lsh) <= tmax && (1u << lsh) < lparts[lp].count)
           lsh++;
-      PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax >> lsh);
+      pd = make_pass(parts, P, p, n, dom.log_max, tmax >> lsh);
       const uint32_t tw = (uint32_t)pd.T << lsh; // word-columns per tile
       static const bool xcd_on = !(getenv("ICICLE_HIP_NTT_XCD") && atoi(getenv("ICICLE_HIP_NTT_XCD")) == 0);
       pd.xcd_remap = (xcd_on && fast && tw < 32 && pd.ntiles >= 64 && pd.ntiles % 8 == 0) ? 1 : 0;
@@ -612,8 +624,9 @@ namespace icicle_hip {
         NttLaunch nlp = nl;
         if (lane_native) { // launch rows = slices of 2^lsh transforms
           nlp.lsh = lsh;
-          nlp.ltot = ltot;
-          nlp.lanes = (ltot + (1u << lsh) - 1) >> lsh;
+          nlp.ltot = lparts[lp].count;
+          nlp.lane0 = lparts[lp].lane0;
+          nlp.lanes = (lparts[lp].count + (1u << lsh) - 1) >> lsh;
           nlp.bs = n * lanes;
           nlp.row0 = 0;
           nlp.nrows_launch = row_groups * nlp.lanes;
@@ -637,7 +650,9 @@ namespace icicle_hip {
         if (!fn) return ICICLE_INVALID_ARGUMENT;
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
         fn<<<dim3(pd.ntiles, gy), threads, lds_bytes, st>>>(src, dst, dom.tw, d_ctab.as<uint32_t>(), pd, nlp, rpb);
-      } else {
+      }
+      } // lane parts
+      if (!fast) {
         const uint32_t tot = (uint32_t)(L * pd.T);
         const unsigned threads = std::max(64u, std::min(1024u, tot / 2));
         HIP_TRY(hipFuncSetAttribute((const void*)k_ntt_pass_generic<PR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);

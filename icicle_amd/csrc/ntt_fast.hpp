@@ -249,7 +249,7 @@ namespace icicle_hip {
     const uint32_t rloc0 = blockIdx.y * rows_per_block;
     auto row_offset = [&](uint32_t rloc, bool rel) -> uint64_t {
       const uint32_t r = rel ? rloc : nl.row0 + rloc; // row inside this launch's group / absolute row
-      return (uint64_t)(r / nl.lanes) * nl.bs + ((uint64_t)(r % nl.lanes) << lsh);
+      return (uint64_t)(r / nl.lanes) * nl.bs + ((uint64_t)(r % nl.lanes) << lsh) + (LN ? nl.lane0 : 0u);
     };
     // LN: lanes of this row's slice that exist (a partial last slice when ltot is not a multiple of TL)
     auto lane_limit = [&](uint32_t rloc) -> uint32_t { return nl.ltot - (((nl.row0 + rloc) % nl.lanes) << lsh); };

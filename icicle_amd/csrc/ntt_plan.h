@@ -48,6 +48,7 @@ namespace icicle_hip {
     // lane-native tiles (ntt_fast.hpp, LN): `ltot` transforms interleaved word by word, a launch row = one slice of
     // 2^lsh of them; `lanes` then counts the slices per row group: offset(r) = (r / lanes) * bs + ((r % lanes) << lsh)
     uint32_t lsh = 0, ltot = 1;
+    uint32_t lane0 = 0; // first interleaved transform of this launch (a ragged lane count runs as full 32-lane slices + a narrower tail launch)
   };
 
 #if defined(__HIPCC__)
