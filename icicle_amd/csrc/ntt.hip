@@ -600,13 +600,15 @@ namespace icicle_hip {
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
         tmax >>= 1;
       // lane-native: the tile's tmax word-columns are (tmax >> lsh) logical columns x 2^lsh interleaved transforms. A lane count
-      // that is not a multiple of the widest slice runs as two launches: the full slices, then the remaining lanes on a
-      // narrower slice (100 columns = 3 x 32 + one launch of 4-lane tiles) instead of a last slice with most lanes masked off
+      // that is not a multiple of the widest slice keeps a masked last slice: running the remainder as a second launch on
+      // narrower slices (100 columns = 3 x 32 + a launch of 4-lane tiles; ICICLE_HIP_NTT_LANE_TAIL=1) was built and measured
+      // SLOWER -- 2^20 x 100: 0.79 -> 0.99 ms -- because the tail's logical columns are es * 4 bytes apart: 16-byte runs.
       struct LanePart {
         uint32_t lane0, count;
       };
       LanePart lparts[2] = {{0, ltot}, {0, 0}};
-      if (lane_native && ltot > tmax && ltot % tmax != 0) {
+      static const bool lane_tail = getenv("ICICLE_HIP_NTT_LANE_TAIL") && atoi(getenv("ICICLE_HIP_NTT_LANE_TAIL")) != 0;
+      if (lane_tail && lane_native && ltot > tmax && ltot % tmax != 0) {
         lparts[0] = {0, ltot - ltot % tmax};
         lparts[1] = {ltot - ltot % tmax, ltot % tmax};
       }
