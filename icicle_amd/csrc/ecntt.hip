@@ -141,8 +141,13 @@ namespace icicle_hip {
 
   // stage q: pairs (i, i + 2^q) inside blocks of 2^(q+1); twiddle w_n^(pos * n / 2^(q+1)).
   // Four lanes (one DPP quad) per butterfly: see EcNtt::mul_words<QUAD>. All four lanes load the same pair, lane 0 stores.
+  // gtabs != nullptr: the quads' 16-entry tables live in global memory (L2-resident: one 108 / 168-byte entry is read per
+  // window, ~6 % of a chain's latency) instead of LDS. LDS holds 16 tables per 64-thread block = 27.6 / 43 KB, i.e. 5 / 3 waves
+  // per CU = 20480 / 12288 butterflies in flight; a stage with more than that (2^16 points: 32768) took three rounds of
+  // ~1 ms. With the tables out of LDS the registers bound the occupancy (2 waves per SIMD = 32768 quads): 2^16 46.6 -> see
+  // profiles/r04_ecntt.txt.
   template <class C>
-  __global__ __launch_bounds__(64) void k_ecntt_stage(typename EC<C>::Proj* __restrict__ work, const uint32_t* __restrict__ tw, EcLayout lay, int q)
+  __global__ __launch_bounds__(64) void k_ecntt_stage(typename EC<C>::Proj* __restrict__ work, const uint32_t* __restrict__ tw, EcLayout lay, int q, typename EC<C>::Proj* __restrict__ gtabs)
   {
     using T = EcNtt<C>;
     using E = typename T::E;
@@ -172,7 +177,8 @@ namespace icicle_hip {
     }
 #else
     {
-      __shared__ typename E::Proj tabs[16][16]; // [quad][multiple]
+      extern __shared__ uint32_t stage_tabs_raw[]; // [quad][multiple] when the tables are in LDS (dynamic size: 0 otherwise)
+      typename E::Proj* tab = gtabs ? gtabs + (size_t)(lane >> 2) * 16 : reinterpret_cast<typename E::Proj*>(stage_tabs_raw) + (size_t)(threadIdx.x >> 2) * 16;
       const uint64_t max_mask = ((uint64_t)1 << lay.log_max) - 1;
       uint64_t idx = (pos << (lay.logn - 1 - q)) << (lay.log_max - lay.logn);
       if (lay.inverse) idx = (((uint64_t)1 << lay.log_max) - idx) & max_mask;
@@ -183,7 +189,7 @@ namespace icicle_hip {
         for (int w = 0; w < 8; w++)
           k[w] = w == 0 ? 1u : 0u;
       }
-      v = T::mul_words_quad(v, k, role, tabs[threadIdx.x >> 2]);
+      v = T::mul_words_quad(v, k, role, tab);
     }
 #endif
 #ifdef ECNTT_NOQUADADD
@@ -396,8 +402,17 @@ namespace icicle_hip {
     }
     rmax = std::max(1, std::min(rmax, logn));
     if (rmax == 1) {
+      // more butterflies per stage than LDS-resident tables allow in flight: tables in global memory (see k_ecntt_stage)
+      static const int gtab_mode = getenv("ICICLE_HIP_ECNTT_GTABS") ? atoi(getenv("ICICLE_HIP_ECNTT_GTABS")) : -1; // 0 / 1 force, -1 auto
+      const uint64_t nquads = ((tot / 2 * 4 + 63) / 64) * 16; // quads launched per stage (incl. the padding of the last block)
+      const bool gtab = gtab_mode >= 0 ? gtab_mode != 0 : tot / 2 > (uint64_t)(sizeof(Proj) > 120 ? 12288 : 20480);
+      Proj* gt = nullptr;
+      if (gtab) {
+        HIP_TRY(d_terms.alloc((size_t)nquads * 16 * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
+        gt = d_terms.as<Proj>();
+      }
       for (int q = 0; q < logn; q++) {
-        k_ecntt_stage<C><<<(unsigned)((tot / 2 * 4 + 63) / 64), 64, 0, st>>>(work, dom.tw, lay, q);
+        k_ecntt_stage<C><<<(unsigned)((tot / 2 * 4 + 63) / 64), 64, gtab ? 0 : (size_t)16 * 16 * sizeof(Proj), st>>>(work, dom.tw, lay, q, gt);
         LAUNCH_CHECK("k_ecntt_stage", st);
       }
     } else if (logn > 0) {
