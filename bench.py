@@ -152,7 +152,7 @@ def inproc_main(args):
     rehearsal = os.environ.get("ICICLE_BENCH_INPROC_VIRTUAL", "0") == "1"  # this leg's own code on a box with fewer GPUs: virtual slots + loopback collectives
     if rehearsal:
         check(lib.icicle_hip_test_set_virtual_devices(G), "virtual devices")
-        check(lib.icicle_hip_test_use_loopback_rccl(True), "loopback")
+        check(lib.icicle_hip_set_collectives_library(os.path.join(ROOT, "tests", "_build", "libnccl_loopback.so").encode()), "loopback collectives")
     elif have < G:
         print(json.dumps({"error": f"needs {G} devices, {have} visible"}))
         return

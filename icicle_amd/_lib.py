@@ -205,7 +205,7 @@ API_SYMBOLS = (
     + ["icicle_hip_msm_plan", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
        "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_selftest_inplace_products", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
        "icicle_hip_msm_release_resident_bases", "icicle_hip_multi_stats", "icicle_hip_test_set_virtual_devices",
-       "icicle_hip_test_use_loopback_rccl", "icicle_hip_test_inject_failure",
+       "icicle_hip_set_collectives_library", "icicle_hip_test_inject_failure",
        "icicle_hip_create_config_extension", "icicle_hip_destroy_config_extension", "icicle_hip_config_extension_set_int",
        "icicle_hip_config_extension_set_bool"]
     + [f"icicle_hip_{c}_{s}" for c in CURVES for s in ("msm", "msm_precompute_bases")]
@@ -301,7 +301,7 @@ lib.icicle_hip_selftest_inplace_products.argtypes = [ctypes.c_int, ctypes.POINTE
 lib.icicle_hip_msm_release_resident_bases.argtypes = [ctypes.c_void_p]
 lib.icicle_hip_multi_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_bool]
 lib.icicle_hip_test_set_virtual_devices.argtypes = [ctypes.c_int]
-lib.icicle_hip_test_use_loopback_rccl.argtypes = [ctypes.c_bool]
+lib.icicle_hip_set_collectives_library.argtypes = [ctypes.c_char_p]
 lib.icicle_hip_test_inject_failure.argtypes = [ctypes.c_int, ctypes.c_int]
 
 

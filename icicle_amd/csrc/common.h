@@ -156,9 +156,7 @@ namespace icicle_hip {
     int (*GroupEnd)();
     const char* (*GetErrorString)(int);
   };
-  const RcclApi* rccl_api(); // nullptr when no RCCL can be loaded; the loopback stand-in when that was asked for
-  const RcclApi* rccl_loopback_api(); // rccl_loopback.hip: in-process rehearsal stand-in (never picked unless asked for)
-  bool rccl_is_loopback();
+  const RcclApi* rccl_api(); // entry points of the selected NCCL-ABI library (default librccl.so); nullptr when it cannot be loaded
   // One communicator per device slot of `devs` (ncclCommInitAll), created once per device list and cached. Collectives
   // on one communicator set must not interleave between two host-side calls, so the set comes with a mutex that the
   // multi-device entry points hold from their first to their last collective (two host threads calling a multi-device

@@ -224,25 +224,47 @@ namespace icicle_hip {
   }
 
   // ---- RCCL loader ------------------------------------------------------------------------------
-  static std::atomic<int> g_loopback{-1}; // -1: not decided yet (environment), 0 / 1: set
-  bool rccl_is_loopback()
+  // The collectives come from a library with the NCCL C ABI, bound with dlopen: librccl.so by default (a copy already in the
+  // process -- PyTorch's -- first), or the library named with icicle_hip_set_collectives_library(path) / ICICLE_HIP_RCCL_LIB
+  // (another RCCL build, an MSCCL fork, or the in-process stand-in the rehearsal tests build from tests/loopback/).
+  static std::mutex g_coll_mtx;
+  static std::string g_coll_path;        // "" = default
+  static bool g_coll_env_read = false;
+  static std::string collectives_path()
   {
-    int v = g_loopback.load();
-    if (v < 0) {
-      const char* e = getenv("ICICLE_HIP_RCCL");
-      v = (e && strcmp(e, "loopback") == 0) ? 1 : 0;
-      g_loopback.store(v);
+    std::lock_guard<std::mutex> g(g_coll_mtx);
+    if (!g_coll_env_read) {
+      g_coll_env_read = true;
+      if (const char* e = getenv("ICICLE_HIP_RCCL_LIB")) g_coll_path = e;
     }
-    return v == 1;
+    return g_coll_path;
   }
 
-  static const RcclApi* rccl_real_api()
+  static bool bind_nccl(void* h, RcclApi& api)
   {
-    static RcclApi api;
-    static const bool ok = []() {
-      void* h = nullptr;
-      // prefer a copy already in the process (PyTorch's), then the ROCm one
-      for (const char* name : {"librccl.so", "librccl.so.1"}) {
+    auto sym = [&](const char* n) { return dlsym(h, n); };
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    return api.CommInitAll && api.AllGather && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
+  }
+
+  const RcclApi* rccl_api()
+  {
+    static std::mutex mtx;
+    static std::map<std::string, std::unique_ptr<RcclApi>> loaded; // path -> bound entry points (nullptr: not loadable); never unloaded
+    const std::string path = collectives_path();
+    std::lock_guard<std::mutex> g(mtx);
+    auto it = loaded.find(path);
+    if (it != loaded.end()) return it->second.get();
+    void* h = nullptr;
+    if (path.empty()) {
+      for (const char* name : {"librccl.so", "librccl.so.1"}) { // prefer a copy already in the process (PyTorch's), then the ROCm one
         h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         if (h) break;
       }
@@ -251,31 +273,23 @@ namespace icicle_hip {
           h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
           if (h) break;
         }
-      if (!h) return false;
-      auto sym = [&](const char* n) { return dlsym(h, n); };
-      api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
-      api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
-      api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
-      api.Send = (decltype(api.Send))sym("ncclSend");
-      api.Recv = (decltype(api.Recv))sym("ncclRecv");
-      api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
-      api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
-      api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
-      return api.CommInitAll && api.AllGather && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
-    }();
-    return ok ? &api : nullptr;
+    } else {
+      h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (!h) fprintf(stderr, "[icicle_hip] collectives library %s: %s\n", path.c_str(), dlerror());
+    }
+    std::unique_ptr<RcclApi> api(new RcclApi{});
+    if (!h || !bind_nccl(h, *api)) api.reset();
+    return loaded.emplace(path, std::move(api)).first->second.get();
   }
-
-  const RcclApi* rccl_api() { return rccl_is_loopback() ? rccl_loopback_api() : rccl_real_api(); }
 
   icicle_error_t rccl_comms_for(const std::vector<int>& devs, RcclCommSet** set)
   {
     static std::mutex mtx;
-    static std::map<std::pair<bool, std::vector<int>>, RcclCommSet*> cache; // sets live as long as the process
+    static std::map<std::pair<std::string, std::vector<int>>, RcclCommSet*> cache; // per collectives library and device list; sets live as long as the process
     const RcclApi* api = rccl_api();
     if (!api || !set) return ICICLE_API_NOT_IMPLEMENTED;
     std::lock_guard<std::mutex> g(mtx);
-    const auto key = std::make_pair(rccl_is_loopback(), devs);
+    const auto key = std::make_pair(collectives_path(), devs);
     auto it = cache.find(key);
     if (it == cache.end()) {
       auto* cs = new RcclCommSet;
@@ -487,9 +501,11 @@ icicle_error_t icicle_hip_test_set_virtual_devices(int slots)
   g_virtual_slots.store(slots);
   return ICICLE_SUCCESS;
 }
-icicle_error_t icicle_hip_test_use_loopback_rccl(bool on)
+icicle_error_t icicle_hip_set_collectives_library(const char* path)
 {
-  g_loopback.store(on ? 1 : 0);
+  (void)collectives_path(); // (the environment is read once, before an explicit choice overrides it)
+  std::lock_guard<std::mutex> g(g_coll_mtx);
+  g_coll_path = path ? path : "";
   return ICICLE_SUCCESS;
 }
 icicle_error_t icicle_hip_test_inject_failure(int slot, int stage)

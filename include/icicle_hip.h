@@ -342,13 +342,17 @@ icicle_error_t icicle_hip_msm_release_resident_bases(const void* bases);
  * device, scalar bytes staged, bytes sent by the bucket exchange / the split transform's all-to-all, resident-base hits
  * (shards NOT staged again), calls that ran one host thread per device slot, point-to-point messages sent }. */
 icicle_error_t icicle_hip_multi_stats(uint64_t* out, bool reset);
-/* Rehearsal hooks for the multi-device code on a box with fewer GPUs than device slots (tests only; see
- * icicle_amd/csrc/rccl_loopback.hip): K virtual device slots mapped round-robin onto the physical GPUs, an in-process
- * stand-in for the RCCL calls (real RCCL refuses one GPU twice in a communicator; ICICLE_HIP_RCCL=loopback in the
- * environment selects it as well), and a one-shot failure of device slot `slot` at stage 1 (worker set-up), 2 (right
- * before the bucket-exchange gate) or 3 (right before the result-gather gate); stage 0 disarms. */
+/* The multi-device paths take their collectives from a library with the NCCL C ABI (ncclCommInitAll, ncclCommDestroy,
+ * ncclAllGather, ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd, ncclGetErrorString), bound with dlopen: librccl.so by default,
+ * or the library at `path` (NULL / "" = default again; ICICLE_HIP_RCCL_LIB in the environment does the same) -- another RCCL
+ * build, or the in-process stand-in the rehearsal tests build from tests/loopback/ (real RCCL refuses one GPU twice in a
+ * communicator). Communicators are cached per library and device list. */
+icicle_error_t icicle_hip_set_collectives_library(const char* path);
+/* Rehearsal hooks for the multi-device code on a box with fewer GPUs than device slots (tests only): K virtual device slots
+ * mapped round-robin onto the physical GPUs, and a one-shot failure of device slot `slot` at stage 1 (worker set-up), 2 (right
+ * before the bucket-exchange gate / the split transform's second exchange) or 3 (right before the result-gather gate); stage 0
+ * disarms. */
 icicle_error_t icicle_hip_test_set_virtual_devices(int slots);
-icicle_error_t icicle_hip_test_use_loopback_rccl(bool on);
 icicle_error_t icicle_hip_test_inject_failure(int slot, int stage);
 
 /* ---- collision-free aliases used by the reference-runtime plugin (plugin/):

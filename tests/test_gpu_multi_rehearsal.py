@@ -17,6 +17,7 @@ Here icicle_hip_test_set_virtual_devices(K) maps K device slots onto GPU 0 and t
   * chunked host-scalar MSM (the single-GPU HostSlice path) against the device-resident call.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -34,14 +35,18 @@ def slots(hip):
     """yields a function that switches to K virtual slots + loopback collectives; always restored afterwards"""
     from icicle_amd._lib import lib, check
 
+    loopback = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libnccl_loopback.so")
+    if not os.path.exists(loopback):
+        pytest.skip("tests/_build/libnccl_loopback.so not built (__graft_entry__.build())")
+
     def use(k):
         check(lib.icicle_hip_test_set_virtual_devices(k))
-        check(lib.icicle_hip_test_use_loopback_rccl(k > 0))
+        check(lib.icicle_hip_set_collectives_library(loopback.encode() if k > 0 else None))
 
     yield use
     lib.icicle_hip_test_inject_failure(-1, 0)
     lib.icicle_hip_test_set_virtual_devices(0)
-    lib.icicle_hip_test_use_loopback_rccl(False)
+    lib.icicle_hip_set_collectives_library(None)
     lib.icicle_hip_msm_release_resident_bases(None)
 
 
