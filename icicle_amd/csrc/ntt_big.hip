@@ -78,6 +78,44 @@ namespace icicle_hip {
     const uint32_t lstride_log = nl.log_max - pd.s;
     auto stage_tw = [&](int q, uint32_t pos) -> fe { return tw_load(((uint64_t)pos << (pd.s - 1 - q)) << lstride_log); };
     int q = 0;
+    if constexpr (B::W == 2) {
+      // 8-byte elements with exact arithmetic (goldilocks): FOUR stages per LDS round trip on 16 elements per thread -- with a
+      // product this cheap the pass was bound by its LDS round trips (two stages each: 0.71 ms at 2^24, four times its HBM
+      // traffic floor). Element m of the group sits at row i + m h; in stage q + j it is the lower / upper end of a butterfly
+      // by bit j of m, and its block position is pos + (m mod 2^j) h.
+      for (; q + 3 < pd.s; q += 4) {
+        const uint32_t h = 1u << q;
+        for (uint32_t id = threadIdx.x; id < tot / 16; id += blockDim.x) {
+          const uint32_t t = id % T, bf = id / T;
+          const uint32_t pos = bf & (h - 1);
+          const uint32_t i = ((bf >> q) << (q + 4)) + pos;
+          fe x[16];
+#pragma unroll
+          for (int m = 0; m < 16; m++)
+            x[m] = tile[(i + (uint32_t)m * h) * T + t];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            fe w[8]; // twiddles of stage q + j: one per value of (m mod 2^j)
+#pragma unroll
+            for (int lo = 0; lo < (1 << j); lo++)
+              w[lo] = stage_tw(q + j, pos + (uint32_t)lo * h);
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+              if (m & (1 << j)) continue;
+              const int lo = m & ((1 << j) - 1);
+              const fe u = x[m];
+              const fe v = (q == 0 && lo == 0) ? x[m + (1 << j)] : F::mul(x[m + (1 << j)], w[lo]); // (q = 0, lo = 0: w^0 = 1)
+              x[m] = F::add(u, v);
+              x[m + (1 << j)] = F::template sub<2>(u, v);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < 16; m++)
+            tile[(i + (uint32_t)m * h) * T + t] = x[m];
+        }
+        __syncthreads();
+      }
+    }
     for (; q + 1 < pd.s; q += 2) {
       const uint32_t h = 1u << q;
       for (uint32_t id = threadIdx.x; id < tot / 4; id += blockDim.x) {
@@ -427,7 +465,8 @@ namespace icicle_hip {
         tmax >>= 1;
       const PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax);
       const uint32_t tot = (uint32_t)(L * pd.T);
-      const unsigned threads = std::max(64u, std::min(512u, tot / 4)); // one thread per 4-element group of a stage pair
+      // one thread per 4-element group of a stage pair; goldilocks: per 16-element group of four stages (when the pass has four)
+      const unsigned threads = std::max(64u, std::min(512u, tot / ((PR::NL32 == 2 && parts[p] >= 4) ? 16 : 4)));
       for (uint32_t r0 = 0; r0 < nl.nbatch; r0 += 65535) {
         NttLaunch ns = nl;
         ns.row0 = r0;
