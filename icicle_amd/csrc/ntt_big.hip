@@ -168,16 +168,35 @@ namespace icicle_hip {
     }
 
     // ---- store
+    // 8-byte elements (goldilocks): a thread's rows k = tid / T + it * (blockDim / T) are an arithmetic progression at a fixed
+    // column, so its inter-pass factors are a geometric one -- two table reads and a product per element instead of a gather per
+    // element (in pass 1 every gather is a 64-byte sector for 8 bytes; same idea as ntt_fast.hpp). Needs blockDim % T == 0 (T and
+    // blockDim are powers of two, T <= 16 <= 64 <= blockDim). The 256-bit fields keep the reads: a product costs them 163 mads.
+    fe ip_cur = F::one(), ip_ratio = F::one();
+    if constexpr (B::W == 2) {
+      if (!pd.is_last) {
+        const uint32_t t = threadIdx.x % T, k0 = threadIdx.x / T, kstep = blockDim.x / T;
+        const uint64_t jnext = ((uint64_t)ct * T + t) / pd.cprime;
+        const uint64_t A = (pd.pidx == 0) ? 0u : (uint64_t)a, Bf = (pd.pidx == 0) ? 1u : (uint64_t)pd.n0;
+        ip_cur = tw_load(jnext * (A + Bf * k0) * pd.tw_stride);
+        ip_ratio = tw_load(jnext * Bf * kstep * pd.tw_stride);
+      }
+    }
     for (uint32_t e = threadIdx.x; e < tot; e += blockDim.x) {
       const uint32_t t = e % T, k = e / T;
       fe v = tile[k * T + t];
       uint64_t oaddr;
       if (!pd.is_last) {
         oaddr = in_base + (uint64_t)k * pd.in_sk + (uint64_t)t * pd.in_st;
-        const uint64_t c = (uint64_t)ct * T + t;
-        const uint64_t jnext = c / pd.cprime;
-        const uint64_t K = (pd.pidx == 0) ? (uint64_t)k : ((uint64_t)a + (uint64_t)pd.n0 * k);
-        v = F::mul(v, tw_load(jnext * K * pd.tw_stride));
+        if constexpr (B::W == 2) {
+          v = F::mul(v, ip_cur);
+          ip_cur = F::mul(ip_cur, ip_ratio);
+        } else {
+          const uint64_t c = (uint64_t)ct * T + t;
+          const uint64_t jnext = c / pd.cprime;
+          const uint64_t K = (pd.pidx == 0) ? (uint64_t)k : ((uint64_t)a + (uint64_t)pd.n0 * k);
+          v = F::mul(v, tw_load(jnext * K * pd.tw_stride));
+        }
       } else {
         uint64_t K0;
         if (pd.pidx <= 1) {
