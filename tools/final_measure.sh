@@ -23,7 +23,6 @@ find "$O/prof" -name '*.db' -delete
 head -16 "$O/kernel_stats.txt"
 bash "$R/tools/pmc_traffic.sh" > "$O/pmc_traffic.txt" 2>&1; cat "$O/pmc_traffic.txt"
 cd "$R"
-{ python tools/perf_matrix.py; python tools/perf_matrix.py g2; python tools/perf_matrix.py scalar-ntt; python tools/perf_matrix.py ecntt; python tools/perf_matrix.py precompute; python tools/perf_matrix.py criterion; python tools/perf_matrix.py curves; python tools/ntt_gold_time.py; } 2>/dev/null | grep -v amdgpu.ids > "$O/perf_matrix.txt"
+{ python tools/perf_matrix.py; python tools/perf_matrix.py ntt; python tools/perf_matrix.py layouts; python tools/perf_matrix.py midsize; python tools/perf_matrix.py distributions; python tools/perf_matrix.py g2; python tools/perf_matrix.py scalar-ntt; python tools/perf_matrix.py ecntt; python tools/perf_matrix.py precompute; python tools/perf_matrix.py criterion; python tools/perf_matrix.py curves; python tools/ntt_gold_time.py; } 2>/dev/null | grep -v amdgpu.ids > "$O/perf_matrix.txt"
 cat "$O/perf_matrix.txt"
-timeout 120 python tools/exp_clock.py 2>/dev/null | grep -v amdgpu.ids > "$O/clock.txt"; cat "$O/clock.txt"
 tail -20 "$O/gpu_pytest.txt" 2>/dev/null
