@@ -244,9 +244,7 @@ namespace icicle_hip {
     const uint64_t pos = g & (L - 1), blk = g >> sg.q0;
     const typename E::Proj a = work[b * lay.n + (blk << (sg.q0 + sg.r)) + (uint64_t)j * L + pos];
     // exponent rev_r(j) * (pos + L u) mod M, as an index into the domain table (w_max^i)
-    const uint32_t rj = __brev(j) >> (32 - sg.r);
-    const uint64_t Mmask = ((uint64_t)1 << (sg.q0 + sg.r)) - 1;
-    const uint64_t e = ((uint64_t)rj * (pos + L * u)) & Mmask;
+    const uint64_t e = ecntt_term_exponent(sg.q0, sg.r, j, u, pos);
     const uint64_t max_mask = ((uint64_t)1 << lay.log_max) - 1;
     uint64_t idx = e << (lay.log_max - (uint32_t)(sg.q0 + sg.r));
     if (lay.inverse) idx = (((uint64_t)1 << lay.log_max) - idx) & max_mask;
@@ -393,14 +391,9 @@ namespace icicle_hip {
     // a measured knee, not a hard limit: beyond it a stage simply takes a second round); ICICLE_HIP_ECNTT_RADIX_LOG forces r
     static const int forced_r = getenv("ICICLE_HIP_ECNTT_RADIX_LOG") ? atoi(getenv("ICICLE_HIP_ECNTT_RADIX_LOG")) : 0;
     static const uint64_t budget = getenv("ICICLE_HIP_ECNTT_QUADS") ? (uint64_t)atoll(getenv("ICICLE_HIP_ECNTT_QUADS")) : 16384;
-    int rmax = 1;
-    if (forced_r > 0) {
-      rmax = std::min(5, forced_r);
-    } else {
-      while (rmax < 5 && tot * ((2ull << rmax) - 1) / 2 <= budget)
-        rmax++;
-    }
-    rmax = std::max(1, std::min(rmax, logn));
+    int widths[64];
+    const int nst = ecntt_stage_plan(logn, tot, budget, forced_r, widths);
+    const int rmax = nst ? widths[0] : 1; // (widths are non-increasing)
     if (rmax == 1) {
       // more butterflies per stage than LDS-resident tables allow in flight: tables in global memory (see k_ecntt_stage)
       static const int gtab_mode = getenv("ICICLE_HIP_ECNTT_GTABS") ? atoi(getenv("ICICLE_HIP_ECNTT_GTABS")) : -1; // 0 / 1 force, -1 auto
@@ -416,7 +409,6 @@ namespace icicle_hip {
         LAUNCH_CHECK("k_ecntt_stage", st);
       }
     } else if (logn > 0) {
-      const int nst = (logn + rmax - 1) / rmax; // stages, their widths as even as possible
       const uint64_t max_items = tot * ((1ull << rmax) - 1) / 2; // n (R - 1) / 2 products of the widest stage
       HIP_TRY(d_terms.alloc((size_t)max_items * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
       HIP_TRY(d_next.alloc((size_t)tot * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
@@ -424,7 +416,7 @@ namespace icicle_hip {
       Proj* nxt = d_next.as<Proj>();
       int q0 = 0;
       for (int si = 0; si < nst; si++) {
-        const int r = logn / nst + (si < logn % nst ? 1 : 0);
+        const int r = widths[si];
         const EcStage sg{q0, r};
         const uint64_t items = (tot >> r) * ((1ull << r) - 1) * (1ull << (r - 1));
         const size_t tab_bytes = (size_t)std::max(1, 16 >> (r - 1)) * 16 * sizeof(Proj); // 16 / (R / 2) tables per 16-quad block

@@ -131,4 +131,37 @@ namespace icicle_hip {
     return true;
   }
 
+  // ---- ECNTT stage plan (ecntt.hip): radix-2^r "matrix form" stages ---------------------------------------------------
+  // r = the largest value <= 5 whose tot (2^r - 1) / 2 scalar multiplications per stage stay within `budget` quads (one round
+  // of quads on the chip); forced_r > 0 overrides. widths[] receives the stage widths (as even as possible, sum = logn),
+  // returns their count; r = 1 everywhere means the plain radix-2 kernel.
+  static inline int ecntt_stage_plan(int logn, uint64_t tot, uint64_t budget, int forced_r, int* widths)
+  {
+    int rmax = 1;
+    if (forced_r > 0) {
+      rmax = std::min(5, forced_r);
+    } else {
+      while (rmax < 5 && tot * ((2ull << rmax) - 1) / 2 <= budget)
+        rmax++;
+    }
+    rmax = std::max(1, std::min(rmax, std::max(1, logn)));
+    const int nst = logn > 0 ? (logn + rmax - 1) / rmax : 0;
+    for (int si = 0; si < nst; si++)
+      widths[si] = logn / nst + (si < logn % nst ? 1 : 0);
+    return nst;
+  }
+  // exponent (mod M = 2^(q0 + r)) of the twiddle that term (j, u) of a radix-2^r stage at q0 multiplies A_j[pos] with:
+  // Y[pos + L k] = sum_j w_M^(rev_r(j) (pos + L k)) A_j[pos], k = u or u + R/2 (the latter with the sign (-1)^rev_r(j))
+#if defined(__HIPCC__)
+  __host__ __device__
+#endif
+  static inline uint64_t ecntt_term_exponent(int q0, int r, uint32_t j, uint32_t u, uint64_t pos)
+  {
+    uint32_t rj = 0;
+    for (int b = 0; b < r; b++)
+      rj |= ((j >> b) & 1u) << (r - 1 - b);
+    const uint64_t L = (uint64_t)1 << q0, Mmask = ((uint64_t)1 << (q0 + r)) - 1;
+    return ((uint64_t)rj * (pos + L * u)) & Mmask;
+  }
+
 } // namespace icicle_hip

@@ -124,3 +124,78 @@ extern "C" int msm_plan_check(void)
         }
   return 0;
 }
+
+// ECNTT stage plan + the index algebra of the radix-2^r matrix-form stages (ecntt.hip k_ecntt_terms / k_ecntt_sums), simulated
+// over the integers mod a small prime with "points" = residues and "scalar multiplication" = modular product: a transform
+// computed stage by stage with ecntt_term_exponent() must equal the O(n^2) definition for every width plan.
+static uint64_t mpow(uint64_t b, uint64_t e, uint64_t p)
+{
+  uint64_t r = 1;
+  b %= p;
+  while (e) {
+    if (e & 1) r = r * b % p;
+    b = b * b % p;
+    e >>= 1;
+  }
+  return r;
+}
+extern "C" int ecntt_plan_check(void)
+{
+  const uint64_t p = 7681; // 7681 - 1 = 2^9 * 15: roots of unity up to order 512
+  const uint64_t g = 17;   // a primitive root mod 7681
+  for (int logn = 0; logn <= 9; logn++)
+    for (int forced = 0; forced <= 5; forced++)
+      for (uint64_t budget : {(uint64_t)16384, (uint64_t)64}) {
+        const uint64_t n = (uint64_t)1 << logn;
+        int widths[64];
+        const int nst = ecntt_stage_plan(logn, n, budget, forced, widths);
+        int sum = 0;
+        for (int i = 0; i < nst; i++) {
+          if (widths[i] < 1 || widths[i] > 5 || (i && widths[i] > widths[i - 1])) return 1000 + logn * 10 + forced;
+          if (forced == 0 && widths[i] > 1 && n * ((1ull << widths[i]) - 1) / 2 > budget) return 2000 + logn * 10;
+          sum += widths[i];
+        }
+        if (sum != logn) return 3000 + logn * 10 + forced;
+        if (logn == 0) continue;
+        const uint64_t w = mpow(g, (p - 1) / n, p); // primitive n-th root
+        std::vector<uint64_t> x(n), work(n), next(n);
+        for (uint64_t i = 0; i < n; i++)
+          x[i] = (i * i * 31 + 7 * i + 3) % p;
+        for (uint64_t i = 0; i < n; i++) { // DIT input: bit-reversed
+          uint64_t j = 0;
+          for (int b = 0; b < logn; b++)
+            j |= ((i >> b) & 1) << (logn - 1 - b);
+          work[i] = x[j];
+        }
+        int q0 = 0;
+        for (int si = 0; si < nst; si++) {
+          const int r = widths[si];
+          const uint64_t R = 1ull << r, hr = R >> 1, L = 1ull << q0, M = L * R;
+          const uint64_t wM = mpow(w, n / M, p);
+          for (uint64_t g0 = 0; g0 < n / R; g0++) {
+            const uint64_t pos = g0 & (L - 1), blk = g0 >> q0, base = (blk << (q0 + r)) + pos;
+            for (uint64_t u = 0; u < hr; u++) {
+              uint64_t ev = work[base], od = 0;
+              for (uint64_t j = 1; j < R; j++) {
+                const uint64_t t = work[base + j * L] * mpow(wM, ecntt_term_exponent(q0, r, (uint32_t)j, (uint32_t)u, pos), p) % p;
+                if (j < hr)
+                  ev = (ev + t) % p;
+                else
+                  od = (od + t) % p;
+              }
+              next[base + u * L] = (ev + od) % p;
+              next[base + (u + hr) * L] = (ev + p - od) % p;
+            }
+          }
+          work.swap(next);
+          q0 += r;
+        }
+        for (uint64_t k = 0; k < n; k++) {
+          uint64_t acc = 0;
+          for (uint64_t j = 0; j < n; j++)
+            acc = (acc + x[j] * mpow(w, j * k % n, p)) % p;
+          if (acc != work[k]) return 4000 + logn * 10 + forced;
+        }
+      }
+  return 0;
+}

@@ -19,3 +19,5 @@ def test_ntt_plan_covers_every_slot_once():
     assert lib.msm_groups_check() == 0  # window groups of the pipelined MSM schedule (msm_plan.h)
     assert lib.split_shape_check() == 0  # shapes of a transform split over device slots (ntt_plan.h)
     assert lib.msm_plan_check() == 0  # the window plan of msm() (msm_plan.h make_plan)
+    # ECNTT: stage widths + the radix-2^r matrix-form index algebra, simulated mod a small prime against the O(n^2) definition
+    assert lib.ecntt_plan_check() == 0
