@@ -1090,6 +1090,29 @@ namespace icicle_hip {
           dst[k] = w[k];
       }
     };
+    // converts the held outputs (one inversion for all of them) and writes them; also called when the arrays are full
+    // (precompute_factor > 33: the outputs of one base then take several rounds)
+    auto flush = [&]() {
+      if (cnt == 0) return;
+      fe inv = F::inv(acc);
+      for (int k = cnt - 1; k >= 0; k--) {
+        const fe zi = F::mul(inv, pre[k]); // 1 / Z_k
+        inv = F::mul(inv, zs[k]);
+        const fe zi2 = F::sqr(zi);
+        const fe x = F::mul(xs[k], zi2), y = F::mul(ys[k], F::mul(zi2, zi));
+        uint32_t o[PW];
+        if (refmont) {
+          F::to_refmont(o, x);
+          F::to_refmont(o + E::N32, y);
+        } else {
+          F::to_canonical(o, x);
+          F::to_canonical(o + E::N32, y);
+        }
+        put(i0 * pf + slot[k], o);
+      }
+      cnt = 0;
+      acc = F::one();
+    };
     for (int q = 0; q < pt && i0 + q < n; q++) {
       const long long i = i0 + q;
       uint32_t w[PW];
@@ -1117,6 +1140,7 @@ namespace icicle_hip {
           put(i * pf + j, zw);
           continue;
         }
+        if (cnt == PRECOMP_MAX_OUT) flush();
         xs[cnt] = jp.x, ys[cnt] = jp.y, zs[cnt] = jp.z;
         pre[cnt] = acc; // product of the Z's before this one
         acc = F::mul(acc, jp.z);
@@ -1124,23 +1148,7 @@ namespace icicle_hip {
         cnt++;
       }
     }
-    if (cnt == 0) return;
-    fe inv = F::inv(acc);
-    for (int k = cnt - 1; k >= 0; k--) {
-      const fe zi = F::mul(inv, pre[k]); // 1 / Z_k
-      inv = F::mul(inv, zs[k]);
-      const fe zi2 = F::sqr(zi);
-      const fe x = F::mul(xs[k], zi2), y = F::mul(ys[k], F::mul(zi2, zi));
-      uint32_t o[PW];
-      if (refmont) {
-        F::to_refmont(o, x);
-        F::to_refmont(o + E::N32, y);
-      } else {
-        F::to_canonical(o, x);
-        F::to_canonical(o + E::N32, y);
-      }
-      put(i0 * pf + slot[k], o);
-    }
+    flush();
   }
 
   // synthetic distinct points (k0 + i) * G, i < n; each thread produces L consecutive points
@@ -1709,7 +1717,6 @@ namespace icicle_hip {
     int pt = std::max(1, std::min(4, pf > 1 ? PRECOMP_MAX_OUT / (pf - 1) : 1));
     while (pt > 1 && (long long)n / pt < 64 * 1024)
       pt--;
-    if (pf - 1 > PRECOMP_MAX_OUT) return ICICLE_INVALID_ARGUMENT; // (the reference's sweeps stop at 23: docs/docs/api/cpp/msm.md:186-201)
     const long long nthr = ((long long)n + pt - 1) / pt;
     k_precompute<C><<<(unsigned)((nthr + 63) / 64), 64, 0, st>>>(d_in, d_out, n, pf, pl.c * pl.wpf, cfg->are_points_montgomery_form, pt, ((uintptr_t)d_out & 15) == 0);
     LAUNCH_CHECK("k_precompute", st);

@@ -214,7 +214,7 @@ def test_msm_precompute(hip, cname):
     bases = points_to_array(C, pts)
     sc = to_words(rand_scalars(rng, n * 2, C.r), 8)
     exp = refc.to_affine(refc.msm(sc, bases, batch=2, shared=True))
-    for pf in (2, 3, 8):
+    for pf in (2, 3, 8) + ((40,) if cname == "bn254" else ()):  # (40: more outputs per base than one shared inversion holds)
         cfg = hip.MSMConfig.default()
         cfg.precompute_factor = pf
         cfg.batch_size = 2
