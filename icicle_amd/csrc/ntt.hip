@@ -619,7 +619,31 @@ namespace icicle_hip {
         while ((2u << lsh) <= tmax && (1u << lsh) < lparts[lp].count)
           lsh++;
       pd = make_pass(parts, P, p, n, dom.log_max, tmax >> lsh);
-      const uint32_t tw = (uint32_t)pd.T << lsh; // word-columns per tile
+      // Few launch rows (16-64 interleaved transforms = one or two slices): adjacent logical columns that share a twiddle set
+      // run as launch rows of one block -- pass 0 (its inter-pass factor depends on column / cprime only) and the last pass
+      // (none at all); not the coset / bit-reversed-output variants, whose per-block constants depend on the column.
+      uint32_t cg = 1;
+      const uint32_t tcl = (uint32_t)pd.T; // logical columns in the LDS tile
+      {
+        static const uint32_t cg_max = getenv("ICICLE_HIP_NTT_COLUMN_GROUP") ? (uint32_t)std::max(1, atoi(getenv("ICICLE_HIP_NTT_COLUMN_GROUP"))) : 8u;
+        const bool cvar_here = nl.coset && (nl.inverse ? p == P - 1 : p == 0);
+        // (only with full slices: grouping multiplies the mostly idle rows of a ragged last slice as well -- 2^20 x 100: 0.84 -> 0.89 ms)
+        const bool allowed = lane_native && fast && !cvar_here && lparts[lp].count % (1u << lsh) == 0 && ((p == 0 && P >= 2) || (p == P - 1 && !nl.out_rev));
+        const uint32_t rows_now = row_groups * ((lparts[lp].count + (1u << lsh) - 1) >> lsh);
+        uint32_t want = 1;
+        while (allowed && want * 2 <= cg_max && rows_now * want * 2 <= 8)
+          want *= 2;
+        while (want > 1) {
+          const PassDesc pg = make_pass(parts, P, p, n, dom.log_max, tcl * want);
+          if ((uint32_t)pg.T == tcl * want && (pg.is_last || (uint32_t)pg.T <= pg.cprime)) {
+            pd = pg;
+            cg = want;
+            break;
+          }
+          want >>= 1;
+        }
+      }
+      const uint32_t tw = tcl << lsh; // word-columns per tile
       static const bool xcd_on = !(getenv("ICICLE_HIP_NTT_XCD") && atoi(getenv("ICICLE_HIP_NTT_XCD")) == 0);
       pd.xcd_remap = (xcd_on && fast && tw < 32 && pd.ntiles >= 64 && pd.ntiles % 8 == 0) ? 1 : 0;
       if (fast) {
@@ -631,7 +655,10 @@ namespace icicle_hip {
           nlp.lanes = (lparts[lp].count + (1u << lsh) - 1) >> lsh;
           nlp.bs = n * lanes;
           nlp.row0 = 0;
-          nlp.nrows_launch = row_groups * nlp.lanes;
+          nlp.cgrp = cg;
+          nlp.cst_in = (uint64_t)tcl * pd.in_st * nl.es;
+          nlp.cst_out = pd.is_last ? (uint64_t)tcl * nl.es : nlp.cst_in;
+          nlp.nrows_launch = row_groups * nlp.lanes * cg;
         }
         const unsigned threads = (unsigned)(tw * (L / epb));
         const size_t lds_bytes = (size_t)2 * L * (tw + 1) * 4;

@@ -116,8 +116,9 @@ namespace icicle_hip {
     extern __shared__ uint32_t lds[];
     static_assert(!LN || (!V4 && !BIG), "lane-native tiles: 4-byte lanes, 512-thread blocks");
     const uint32_t lsh = LN ? nl.lsh : 0u, lmask = (1u << lsh) - 1u;
-    const uint32_t TC = pd.T;      // logical columns per tile
-    const uint32_t T = TC << lsh;  // word-columns per tile = LDS row length = threads along t
+    const uint32_t TC = pd.T;      // logical columns per tile (LN with column groups: per group of nl.cgrp tile-rows)
+    const uint32_t cgrp = LN ? nl.cgrp : 1u;
+    const uint32_t T = (TC / cgrp) << lsh; // word-columns per tile = LDS row length = threads along t
     const uint32_t TP = T + 1;
     // Narrow tiles (T*4 B < one 128 B line): neighbouring tiles share HBM lines. Workgroups are dealt
     // round-robin to the 8 XCDs, so give each XCD a contiguous range of tiles -- then the tiles that
@@ -247,12 +248,16 @@ namespace icicle_hip {
     }
 
     const uint32_t rloc0 = blockIdx.y * rows_per_block;
-    auto row_offset = [&](uint32_t rloc, bool rel) -> uint64_t {
+    auto row_offset = [&](uint32_t rloc, bool rel, bool dst_side = false) -> uint64_t {
       const uint32_t r = rel ? rloc : nl.row0 + rloc; // row inside this launch's group / absolute row
-      return (uint64_t)(r / nl.lanes) * nl.bs + ((uint64_t)(r % nl.lanes) << lsh) + (LN ? nl.lane0 : 0u);
+      if (LN) { // r = ((row group * slices) + slice) * cgrp + column of the group
+        const uint32_t cs = r % cgrp, rs = r / cgrp;
+        return (uint64_t)(rs / nl.lanes) * nl.bs + ((uint64_t)(rs % nl.lanes) << lsh) + nl.lane0 + (uint64_t)cs * (dst_side ? nl.cst_out : nl.cst_in);
+      }
+      return (uint64_t)(r / nl.lanes) * nl.bs + (r % nl.lanes);
     };
     // LN: lanes of this row's slice that exist (a partial last slice when ltot is not a multiple of TL)
-    auto lane_limit = [&](uint32_t rloc) -> uint32_t { return nl.ltot - (((nl.row0 + rloc) % nl.lanes) << lsh); };
+    auto lane_limit = [&](uint32_t rloc) -> uint32_t { return nl.ltot - ((((nl.row0 + rloc) / cgrp) % nl.lanes) << lsh); };
     // The E operands a thread feeds into its first round, straight from HBM. They are fetched one batch row
     // AHEAD (software prefetch into registers): without it a block alternates between a load phase and a
     // compute/LDS/store phase and the waves sit parked on s_waitcnt for more than half of their cycles
@@ -299,7 +304,7 @@ namespace icicle_hip {
     // Row rr uses LDS buffer rr & 1; the barrier inside the next row's processing orders the reuse after that.
     auto process_row = [&](uint32_t rr, const uint32_t* xin) {
       const uint32_t rloc = rloc0 + rr;
-      uint32_t* __restrict__ pout = out + row_offset(rloc, nl.dst_rel != 0) + (LN ? lB : 0u);
+      uint32_t* __restrict__ pout = out + row_offset(rloc, nl.dst_rel != 0, true) + (LN ? lB : 0u);
       const bool live = !LN || lB < lane_limit(rloc); // (every global store below is in mapping B)
       uint32_t* tile = lds + (size_t)(rr & 1) * L * TP;
       if (!DIF) {
@@ -478,7 +483,7 @@ namespace icicle_hip {
             const uint64_t k0b = (pd.pidx <= 1) ? ((uint64_t)ct * TC) : (((uint64_t)ct * TC) + (uint64_t)pd.n0 * a);
             if (LN) { // word e of the tile = (lane, row r, logical column c), lanes fastest: runs of TL words
               const uint32_t nthr = T * NG16, lim = lane_limit(rloc);
-              uint32_t* po = out + row_offset(rloc, nl.dst_rel != 0);
+              uint32_t* po = out + row_offset(rloc, nl.dst_rel != 0, true);
 #pragma unroll
               for (int it = 0; it < E; it++) {
                 const uint32_t e = (uint32_t)it * nthr + threadIdx.x;

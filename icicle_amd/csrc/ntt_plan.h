@@ -48,6 +48,11 @@ namespace icicle_hip {
     // lane-native tiles (ntt_fast.hpp, LN): `ltot` transforms interleaved word by word, a launch row = one slice of
     // 2^lsh of them; `lanes` then counts the slices per row group: offset(r) = (r / lanes) * bs + ((r % lanes) << lsh)
     uint32_t lsh = 0, ltot = 1;
+    // lane-native, few slices (16-64 interleaved transforms): `cgrp` ADJACENT logical columns share one twiddle set in pass 0
+    // (same w_M^(jnext K): jnext = column / cprime) and in the last pass (no inter-pass factor at all), so they run as launch
+    // rows of one block: row r = (row group, slice, column cs), cs = r % cgrp, at word offsets cs * cst_in / cs * cst_out
+    uint32_t cgrp = 1;
+    uint64_t cst_in = 0, cst_out = 0;
     uint32_t lane0 = 0; // first interleaved transform of this launch (a ragged lane count runs as full 32-lane slices + a narrower tail launch)
   };
 
