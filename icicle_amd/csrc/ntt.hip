@@ -622,17 +622,28 @@ namespace icicle_hip {
       // Few launch rows (16-64 interleaved transforms = one or two slices): adjacent logical columns that share a twiddle set
       // run as launch rows of one block -- pass 0 (its inter-pass factor depends on column / cprime only) and the last pass
       // (none at all); not the coset / bit-reversed-output variants, whose per-block constants depend on the column.
-      uint32_t cg = 1;
+      uint32_t cg = 1, ag_for_pass = 1;
       const uint32_t tcl = (uint32_t)pd.T; // logical columns in the LDS tile
       {
         static const uint32_t cg_max = getenv("ICICLE_HIP_NTT_COLUMN_GROUP") ? (uint32_t)std::max(1, atoi(getenv("ICICLE_HIP_NTT_COLUMN_GROUP"))) : 8u;
         const bool cvar_here = nl.coset && (nl.inverse ? p == P - 1 : p == 0);
         // (only with full slices: grouping multiplies the mostly idle rows of a ragged last slice as well -- 2^20 x 100: 0.84 -> 0.89 ms)
-        const bool allowed = lane_native && fast && !cvar_here && lparts[lp].count % (1u << lsh) == 0 && ((p == 0 && P >= 2) || (p == P - 1 && !nl.out_rev));
+        const bool full = lane_native && fast && lparts[lp].count % (1u << lsh) == 0;
+        const bool allowed = full && !cvar_here && ((p == 0 && P >= 2) || (p == P - 1 && !nl.out_rev));
+        const bool middle = full && P == 3 && p == 1; // groups over the outer index instead (ntt_plan.h agrp)
         const uint32_t rows_now = row_groups * ((lparts[lp].count + (1u << lsh) - 1) >> lsh);
         uint32_t want = 1;
-        while (allowed && want * 2 <= cg_max && rows_now * want * 2 <= 8)
+        while ((allowed || middle) && want * 2 <= cg_max && rows_now * want * 2 <= 8)
           want *= 2;
+        uint32_t ag = 1;
+        if (middle) {
+          while (want > 1 && ((uint64_t)1 << parts[0]) % want != 0)
+            want >>= 1;
+          ag = want;
+          want = 1;
+          pd.ntiles /= ag; // tiles enumerate (a / ag, ct)
+          ag_for_pass = ag;
+        }
         while (want > 1) {
           const PassDesc pg = make_pass(parts, P, p, n, dom.log_max, tcl * want);
           if ((uint32_t)pg.T == tcl * want && (pg.is_last || (uint32_t)pg.T <= pg.cprime)) {
@@ -644,6 +655,7 @@ namespace icicle_hip {
         }
       }
       const uint32_t tw = tcl << lsh; // word-columns per tile
+      const uint32_t ag_rows = ag_for_pass;
       static const bool xcd_on = !(getenv("ICICLE_HIP_NTT_XCD") && atoi(getenv("ICICLE_HIP_NTT_XCD")) == 0);
       pd.xcd_remap = (xcd_on && fast && tw < 32 && pd.ntiles >= 64 && pd.ntiles % 8 == 0) ? 1 : 0;
       if (fast) {
@@ -655,10 +667,12 @@ namespace icicle_hip {
           nlp.lanes = (lparts[lp].count + (1u << lsh) - 1) >> lsh;
           nlp.bs = n * lanes;
           nlp.row0 = 0;
-          nlp.cgrp = cg;
-          nlp.cst_in = (uint64_t)tcl * pd.in_st * nl.es;
-          nlp.cst_out = pd.is_last ? (uint64_t)tcl * nl.es : nlp.cst_in;
-          nlp.nrows_launch = row_groups * nlp.lanes * cg;
+          nlp.tcl = tcl;
+          nlp.cgrp = cg * ag_rows;
+          nlp.agrp = ag_rows;
+          nlp.cst_in = ag_rows > 1 ? pd.in_base_a * nl.es : (uint64_t)tcl * pd.in_st * nl.es;
+          nlp.cst_out = (pd.is_last && ag_rows == 1) ? (uint64_t)tcl * nl.es : nlp.cst_in;
+          nlp.nrows_launch = row_groups * nlp.lanes * nlp.cgrp;
         }
         const unsigned threads = (unsigned)(tw * (L / epb));
         const size_t lds_bytes = (size_t)2 * L * (tw + 1) * 4;

@@ -117,15 +117,15 @@ namespace icicle_hip {
     static_assert(!LN || (!V4 && !BIG), "lane-native tiles: 4-byte lanes, 512-thread blocks");
     const uint32_t lsh = LN ? nl.lsh : 0u, lmask = (1u << lsh) - 1u;
     const uint32_t TC = pd.T;      // logical columns per tile (LN with column groups: per group of nl.cgrp tile-rows)
-    const uint32_t cgrp = LN ? nl.cgrp : 1u;
-    const uint32_t T = (TC / cgrp) << lsh; // word-columns per tile = LDS row length = threads along t
+    const uint32_t cgrp = LN ? nl.cgrp : 1u, agrp = LN ? nl.agrp : 1u;
+    const uint32_t T = (LN ? nl.tcl : TC) << lsh; // word-columns per tile = LDS row length = threads along t
     const uint32_t TP = T + 1;
     // Narrow tiles (T*4 B < one 128 B line): neighbouring tiles share HBM lines. Workgroups are dealt
     // round-robin to the 8 XCDs, so give each XCD a contiguous range of tiles -- then the tiles that
     // share a line run back to back on the same XCD and meet in its L2.
     uint32_t tile = blockIdx.x;
     if (pd.xcd_remap) tile = (blockIdx.x & 7u) * (pd.ntiles >> 3) + (blockIdx.x >> 3);
-    const uint32_t a = tile / pd.tiles_per_a, ct = tile % pd.tiles_per_a;
+    const uint32_t a = (tile / pd.tiles_per_a) * agrp, ct = tile % pd.tiles_per_a; // (agrp > 1: the first of the block's outer indices)
     const uint64_t in_base = (uint64_t)a * pd.in_base_a + (uint64_t)ct * pd.in_base_ct;
     const uint64_t max_mask = ((uint64_t)1 << nl.log_max) - 1;
     const uint32_t lstride_log = nl.log_max - SS;
@@ -184,7 +184,8 @@ namespace icicle_hip {
       // split as w^(jnext*a) * w^(jnext*n0*k): the first index stays in a 256 KiB prefix of the table, the second
       // takes 2^16 distinct values shared by every block -- both live in L2 / Infinity Cache.
       const uint64_t jnext = ((uint64_t)ct * TC + cB) / pd.cprime;
-      const uint32_t wa = (pd.pidx == 0) ? 0u : tw_load(jnext * a * pd.tw_stride);
+      const bool skip_wa = pd.pidx == 0 || agrp > 1; // (agrp > 1: w^(jnext a) differs per launch row, applied to the operands instead)
+      const uint32_t wa = skip_wa ? 0u : tw_load(jnext * a * pd.tw_stride);
 #if defined(NTT_WIP_LOADS) // (rounds 1-3, kept for A/B builds: every factor loaded from the table)
 #pragma unroll
       for (int m = 0; m < E; m++) {
@@ -203,7 +204,7 @@ namespace icicle_hip {
       const uint64_t kfac = (pd.pidx == 0) ? 1u : (uint64_t)pd.n0;
       const uint32_t step = tw_load(jnext * kfac * ((uint64_t)1 << QT) * pd.tw_stride);
       const uint32_t first = tw_load(jnext * kfac * baseT * pd.tw_stride);
-      wip[0] = (pd.pidx == 0) ? first : S::mul(wa, first);
+      wip[0] = skip_wa ? first : S::mul(wa, first);
 #pragma unroll
       for (int m = 1; m < E; m++)
         wip[m] = S::mul(wip[m - 1], step);
@@ -267,6 +268,8 @@ namespace icicle_hip {
       if (LN) { // + lane, clamped into the slice: the surplus lanes of a partial slice re-read its last transform
         const uint32_t lim = lane_limit(rloc) - 1u;
         pin += std::min<uint32_t>((DIF && NR > 1) ? lA : lB, lim);
+        if (!DIF) // middle pass with outer-index groups: this row's w^(jnext (a + cs)), fetched with the operands
+          x[E] = agrp > 1 ? tw_load((((uint64_t)ct * TC + cB) / pd.cprime) * (uint64_t)(a + (nl.row0 + rloc) % cgrp) * pd.tw_stride) : 0u;
       }
       if (V4) { // top round of the row pass: slot 4g+c of the lane in wave-row r <- word c of row 4g+r
         const uint32_t* p = pin + (in_base + (uint64_t)(gA - wrow) + (uint64_t)tA * pd.in_st);
@@ -316,6 +319,11 @@ namespace icicle_hip {
 #pragma unroll
           for (int m = 0; m < (1 << NQ0); m++)
             x[m] = xin[u * (1 << NQ0) + m];
+          if (LN && agrp > 1) { // (the transform is linear: scaling its operands scales its results)
+#pragma unroll
+            for (int m = 0; m < (1 << NQ0); m++)
+              x[m] = S::mul(x[m], xin[E]);
+          }
           if (coset_in) { // row part of g^j (the column part sits in wip)
 #pragma unroll
             for (int m = 0; m < (1 << NQ0); m++)
@@ -522,7 +530,8 @@ namespace icicle_hip {
       //    for those very loads (that is what rounds 1-2 shipped, profiles/r02_notes.md);
       //  * the copy xin <- xnext stays behind the stores (sched_barrier): hoisted into the second round it needs the
       //    loads half an iteration early.
-      uint32_t xin[E], xnext[E];
+      constexpr int EX = E + (LN ? 1 : 0); // LN: one more word per row (see load_row)
+      uint32_t xin[EX], xnext[EX];
       if (nrows) {
         load_row(rloc0, xin);
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
@@ -534,13 +543,13 @@ namespace icicle_hip {
         if (has_next) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int m = 0; m < E; m++)
+          for (int m = 0; m < EX; m++)
             xin[m] = xnext[m];
         }
       }
     } else { // (three-round variants, s >= 9, are already at 110-150 VGPRs: they load each row when it is needed)
       for (uint32_t rr = 0; rr < nrows; rr++) {
-        uint32_t xin[E];
+        uint32_t xin[E + (LN ? 1 : 0)];
         load_row(rloc0 + rr, xin);
         process_row(rr, xin);
       }

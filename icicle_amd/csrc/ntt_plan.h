@@ -51,7 +51,10 @@ namespace icicle_hip {
     // lane-native, few slices (16-64 interleaved transforms): `cgrp` ADJACENT logical columns share one twiddle set in pass 0
     // (same w_M^(jnext K): jnext = column / cprime) and in the last pass (no inter-pass factor at all), so they run as launch
     // rows of one block: row r = (row group, slice, column cs), cs = r % cgrp, at word offsets cs * cst_in / cs * cst_out
-    uint32_t cgrp = 1;
+    // In the middle pass of a three-pass transform the factor is w^(column * (a + n0 k)): there `agrp` adjacent values of the OUTER
+    // index a run as the rows of a block (agrp = cgrp), w^(column * a) being applied per row to the loaded operands.
+    uint32_t cgrp = 1, agrp = 1;
+    uint32_t tcl = 1; // logical columns in the LDS tile (PassDesc::T counts the cgrp-wide group in pass 0 / the last pass)
     uint64_t cst_in = 0, cst_out = 0;
     uint32_t lane0 = 0; // first interleaved transform of this launch (a ragged lane count runs as full 32-lane slices + a narrower tail launch)
   };
