@@ -600,25 +600,14 @@ namespace icicle_hip {
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
         tmax >>= 1;
       // lane-native: the tile's tmax word-columns are (tmax >> lsh) logical columns x 2^lsh interleaved transforms. A lane count
-      // that is not a multiple of the widest slice keeps a masked last slice: running the remainder as a second launch on
-      // narrower slices (100 columns = 3 x 32 + a launch of 4-lane tiles; ICICLE_HIP_NTT_LANE_TAIL=1) was built and measured
-      // SLOWER -- 2^20 x 100: 0.79 -> 0.99 ms -- because the tail's logical columns are es * 4 bytes apart: 16-byte runs.
-      struct LanePart {
-        uint32_t lane0, count;
-      };
-      LanePart lparts[2] = {{0, ltot}, {0, 0}};
-      static const bool lane_tail = getenv("ICICLE_HIP_NTT_LANE_TAIL") && atoi(getenv("ICICLE_HIP_NTT_LANE_TAIL")) != 0;
-      if (lane_tail && lane_native && ltot > tmax && ltot % tmax != 0) {
-        lparts[0] = {0, ltot - ltot % tmax};
-        lparts[1] = {ltot - ltot % tmax, ltot % tmax};
-      }
-      PassDesc pd{};
-      for (int lp = 0; lp < 2 && lparts[lp].count > 0; lp++) {
+      // that is not a multiple of the widest slice keeps a masked last slice (running the remainder as a second launch on
+      // narrower slices -- 100 columns = 3 x 32 + a launch of 4-lane tiles -- was built and measured SLOWER, 2^20 x 100:
+      // 0.79 -> 0.99 ms: the tail's logical columns are es * 4 bytes apart, 16-byte runs; profiles/r04_notes.md section 1).
       uint32_t lsh = 0;
       if (lane_native)
-        while ((2u << lsh) <= tmax && (1u << lsh) < lparts[lp].count)
+        while ((2u << lsh) <= tmax && (1u << lsh) < ltot)
           lsh++;
-      pd = make_pass(parts, P, p, n, dom.log_max, tmax >> lsh);
+      PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax >> lsh);
       // Few launch rows (16-64 interleaved transforms = one or two slices): adjacent logical columns that share a twiddle set
       // run as launch rows of one block -- pass 0 (its inter-pass factor depends on column / cprime only) and the last pass
       // (none at all); not the coset / bit-reversed-output variants, whose per-block constants depend on the column.
@@ -628,10 +617,10 @@ namespace icicle_hip {
         static const uint32_t cg_max = getenv("ICICLE_HIP_NTT_COLUMN_GROUP") ? (uint32_t)std::max(1, atoi(getenv("ICICLE_HIP_NTT_COLUMN_GROUP"))) : 8u;
         const bool cvar_here = nl.coset && (nl.inverse ? p == P - 1 : p == 0);
         // (only with full slices: grouping multiplies the mostly idle rows of a ragged last slice as well -- 2^20 x 100: 0.84 -> 0.89 ms)
-        const bool full = lane_native && fast && lparts[lp].count % (1u << lsh) == 0;
+        const bool full = lane_native && fast && ltot % (1u << lsh) == 0;
         const bool allowed = full && !cvar_here && ((p == 0 && P >= 2) || (p == P - 1 && !nl.out_rev));
         const bool middle = full && P == 3 && p == 1; // groups over the outer index instead (ntt_plan.h agrp)
-        const uint32_t rows_now = row_groups * ((lparts[lp].count + (1u << lsh) - 1) >> lsh);
+        const uint32_t rows_now = row_groups * ((ltot + (1u << lsh) - 1) >> lsh);
         uint32_t want = 1;
         while ((allowed || middle) && want * 2 <= cg_max && rows_now * want * 2 <= 8)
           want *= 2;
@@ -662,9 +651,8 @@ namespace icicle_hip {
         NttLaunch nlp = nl;
         if (lane_native) { // launch rows = slices of 2^lsh transforms
           nlp.lsh = lsh;
-          nlp.ltot = lparts[lp].count;
-          nlp.lane0 = lparts[lp].lane0;
-          nlp.lanes = (lparts[lp].count + (1u << lsh) - 1) >> lsh;
+          nlp.ltot = ltot;
+          nlp.lanes = (ltot + (1u << lsh) - 1) >> lsh;
           nlp.bs = n * lanes;
           nlp.row0 = 0;
           nlp.tcl = tcl;
@@ -694,7 +682,6 @@ namespace icicle_hip {
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
         fn<<<dim3(pd.ntiles, gy), threads, lds_bytes, st>>>(src, dst, dom.tw, d_ctab.as<uint32_t>(), pd, nlp, rpb);
       }
-      } // lane parts
       if (!fast) {
         const uint32_t tot = (uint32_t)(L * pd.T);
         const unsigned threads = std::max(64u, std::min(1024u, tot / 2));

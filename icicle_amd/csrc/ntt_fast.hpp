@@ -253,7 +253,7 @@ namespace icicle_hip {
       const uint32_t r = rel ? rloc : nl.row0 + rloc; // row inside this launch's group / absolute row
       if (LN) { // r = ((row group * slices) + slice) * cgrp + column of the group
         const uint32_t cs = r % cgrp, rs = r / cgrp;
-        return (uint64_t)(rs / nl.lanes) * nl.bs + ((uint64_t)(rs % nl.lanes) << lsh) + nl.lane0 + (uint64_t)cs * (dst_side ? nl.cst_out : nl.cst_in);
+        return (uint64_t)(rs / nl.lanes) * nl.bs + ((uint64_t)(rs % nl.lanes) << lsh) + (uint64_t)cs * (dst_side ? nl.cst_out : nl.cst_in);
       }
       return (uint64_t)(r / nl.lanes) * nl.bs + (r % nl.lanes);
     };

@@ -56,7 +56,6 @@ namespace icicle_hip {
     uint32_t cgrp = 1, agrp = 1;
     uint32_t tcl = 1; // logical columns in the LDS tile (PassDesc::T counts the cgrp-wide group in pass 0 / the last pass)
     uint64_t cst_in = 0, cst_out = 0;
-    uint32_t lane0 = 0; // first interleaved transform of this launch (a ragged lane count runs as full 32-lane slices + a narrower tail launch)
   };
 
 #if defined(__HIPCC__)
