@@ -3,8 +3,9 @@ items 2, 3).
 
 Real RCCL refuses one GPU twice in a communicator, so until now every "G = 8" test ran one worker: no host thread per
 device, no gate crossing, no peer copy, and the grouped ncclSend / ncclRecv of the bucket exchange had zero executions.
-Here icicle_hip_test_set_virtual_devices(K) maps K device slots onto GPU 0 and the loopback stand-in
-(icicle_amd/csrc/rccl_loopback.hip) takes RCCL's place with the same call sequence and stream-ordering contract:
+Here icicle_hip_test_set_virtual_devices(K) maps K device slots onto GPU 0 and the loopback stand-in (a library of its own since
+round 4: tests/loopback/nccl_loopback.cpp -> tests/_build/libnccl_loopback.so, handed to the product with
+icicle_hip_set_collectives_library) takes RCCL's place with the same symbols, call sequence and stream-ordering contract:
   * msm, hip_num_devices = G on P in {2, 8} slots: one host thread + stream + communicator rank per slot, operands of the
     slots other than 0 staged by (peer-style) copies through the two-slot ring, E1 all-gather + k_proj_sum and E2 grouped
     send / recv of bucket slices + k_bucket_add, against the reference CPU backend and against the single-call MSM;
