@@ -131,12 +131,43 @@ namespace icicle_hip {
     p.x = F::from_canonical(w);
     p.y = F::from_canonical(w + E::N32);
     p.z = F::from_canonical(w + 2 * E::N32);
-    if (lay.coset && !lay.inverse && j != 0) {
-      uint32_t k[8];
-      T::canonical_from_mont(k, coset_pow + j * 8);
-      p = T::mul_words_serial(p, k);
+    work[b * lay.n + i] = p; // (the coset factor g^j is applied by k_ecntt_scale)
+  }
+
+  // work[b][i] *= s_i, FOUR lanes per point sharing the doubling chain and the additions (mul_words_quad) -- the factors a transform
+  // applies to every point outside its butterflies: g^j on the way in (forward coset; i = bit-reversed j), 1/N and g^-k on the way
+  // out (inverse), folded into ONE scalar per point. Rounds 2-3 did this bit-serially on one lane inside the load / store kernels:
+  // 1.8 ms (1/N) to 4.8 ms (coset + 1/N) on top of a 2.5 ms transform of 2^10 points; the quad chain is ~1.0 ms.
+  // mode 1: s_i = coset_pow[bitrev(i)] ; mode 2: s_k = ninv [* coset_pow[k]]. Tables: LDS, or global when gtabs != nullptr.
+  template <class C>
+  __global__ __launch_bounds__(64) void k_ecntt_scale(typename EC<C>::Proj* __restrict__ work, const uint32_t* __restrict__ coset_pow, BigWords ninv_mont, EcLayout lay, int mode, typename EC<C>::Proj* __restrict__ gtabs)
+  {
+    using T = EcNtt<C>;
+    using E = typename T::E;
+    using FR = typename T::FR;
+    extern __shared__ uint32_t scale_tabs_raw[];
+    const uint64_t lane = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint32_t role = threadIdx.x & 3u;
+    const uint64_t npts = lay.n * lay.batch;
+    const bool live = (lane >> 2) < npts;
+    const uint64_t t = live ? (lane >> 2) : npts - 1; // (a quad past the end redoes the last point and stores nothing)
+    const uint64_t i = t % lay.n;
+    typename E::Proj* tab = gtabs ? gtabs + (size_t)(lane >> 2) * 16 : reinterpret_cast<typename E::Proj*>(scale_tabs_raw) + (size_t)(threadIdx.x >> 2) * 16;
+    uint32_t w[8], k[8];
+    typename FR::fe sc;
+    if (mode == 1) {
+      load8(w, coset_pow + bitrev64(i, lay.logn) * 8);
+      sc = FR::unpack(w);
+    } else {
+      sc = FR::unpack(ninv_mont.w);
+      if (lay.coset) {
+        load8(w, coset_pow + i * 8);
+        sc = FR::mul(sc, FR::unpack(w));
+      }
     }
-    work[b * lay.n + i] = p;
+    FR::to_canonical(k, sc);
+    const typename E::Proj p = T::mul_words_quad(work[t], k, role, tab);
+    if (live && role == 0) work[t] = p;
   }
 
   // stage q: pairs (i, i + 2^q) inside blocks of 2^(q+1); twiddle w_n^(pos * n / 2^(q+1)).
@@ -295,15 +326,7 @@ namespace icicle_hip {
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= lay.n * lay.batch) return;
     const uint64_t b = t / lay.n, k = t % lay.n;
-    typename E::Proj p = work[b * lay.n + k];
-    if (lay.inverse) {
-      p = T::mul_words_serial(p, ninv_canonical.w);
-      if (lay.coset && k != 0) {
-        uint32_t s[8];
-        T::canonical_from_mont(s, coset_pow + k * 8);
-        p = T::mul_words_serial(p, s);
-      }
-    }
+    const typename E::Proj p = work[b * lay.n + k]; // (1/N and g^-k were applied by k_ecntt_scale)
     const uint64_t m = lay.out_rev ? bitrev64(k, lay.logn) : k;
     E::store_proj_canonical(out + (b * lay.bs + m * lay.es) * 3 * E::N32, p);
   }
@@ -340,7 +363,7 @@ namespace icicle_hip {
     constexpr size_t PWB = (size_t)3 * E::N32 * 4; // bytes per projective_t
     const size_t bytes = (size_t)n * batch * PWB;
 
-    TempBuf d_in_tmp, d_out_tmp, d_pw, d_work, d_terms, d_next; // (d_terms / d_next: the matrix-form stages; alive until the store kernel is queued)
+    TempBuf d_in_tmp, d_out_tmp, d_pw, d_work, d_terms, d_next, d_stab; // (d_terms / d_next: the matrix-form stages; alive until the store kernel is queued)
     const uint32_t* d_in = (const uint32_t*)input_v;
     uint32_t* d_out = (uint32_t*)output_v;
     if (!cfg->are_inputs_on_device) {
@@ -382,11 +405,27 @@ namespace icicle_hip {
     BigWords ninv{};
     ninv.w[0] = 1;
     if (lay.inverse) FR::to_canonical(ninv.w, host_ninv<PR>(logn));
+    BigWords ninv_mont{};
+    if (lay.inverse) ninv_mont = mont_words<PR>(host_ninv<PR>(logn)); // packed Montgomery words, like the coset table's entries
 
     const uint64_t tot = n * batch;
     Proj* work = d_work.as<Proj>();
     k_ecntt_load<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(d_in, work, d_pw.as<uint32_t>(), lay);
     LAUNCH_CHECK("k_ecntt_load", st);
+    // per-point factors outside the butterflies (forward coset on the way in; 1/N [and the coset] on the way out): k_ecntt_scale
+    const uint64_t scale_quads = ((tot * 4 + 63) / 64) * 16;
+    const bool scale_gtab = tot > (uint64_t)(sizeof(Proj) > 120 ? 12288 : 20480); // more points than LDS-resident tables allow in flight
+    auto scale = [&](Proj* pts, int mode) -> icicle_error_t {
+      Proj* gt = nullptr;
+      if (scale_gtab) {
+        if (!d_stab.ptr()) HIP_TRY(d_stab.alloc((size_t)scale_quads * 16 * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
+        gt = d_stab.as<Proj>();
+      }
+      k_ecntt_scale<C><<<(unsigned)((tot * 4 + 63) / 64), 64, scale_gtab ? 0 : (size_t)16 * 16 * sizeof(Proj), st>>>(pts, d_pw.as<uint32_t>(), ninv_mont, lay, mode, gt);
+      LAUNCH_CHECK("k_ecntt_scale", st);
+      return ICICLE_SUCCESS;
+    };
+    if (lay.coset && !lay.inverse) ICICLE_TRY(scale(work, 1));
     // stage radix: the largest r <= 5 whose n (R - 1) / 2 products still fit one round of quads on the chip (the budget is
     // a measured knee, not a hard limit: beyond it a stage simply takes a second round); ICICLE_HIP_ECNTT_RADIX_LOG forces r
     static const int forced_r = getenv("ICICLE_HIP_ECNTT_RADIX_LOG") ? atoi(getenv("ICICLE_HIP_ECNTT_RADIX_LOG")) : 0;
@@ -430,6 +469,7 @@ namespace icicle_hip {
       }
       work = cur;
     }
+    if (lay.inverse) ICICLE_TRY(scale(work, 2));
     k_ecntt_store<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(work, d_out, d_pw.as<uint32_t>(), ninv, lay);
     LAUNCH_CHECK("k_ecntt_store", st);
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
