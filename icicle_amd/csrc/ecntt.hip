@@ -114,9 +114,9 @@ namespace icicle_hip {
     uint32_t log_max;
   };
 
-  // work[b][i] = g^j * P_j with j = bitrev(i) (DIT wants its input bit-reversed)
+  // work[b][i] = P_j with j = bitrev(i) (DIT wants its input bit-reversed); the forward coset factor g^j follows in k_ecntt_scale
   template <class C>
-  __global__ __launch_bounds__(64) void k_ecntt_load(const uint32_t* __restrict__ in, typename EC<C>::Proj* __restrict__ work, const uint32_t* __restrict__ coset_pow, EcLayout lay)
+  __global__ __launch_bounds__(64) void k_ecntt_load(const uint32_t* __restrict__ in, typename EC<C>::Proj* __restrict__ work, EcLayout lay)
   {
     using T = EcNtt<C>;
     using E = typename T::E;
@@ -317,9 +317,9 @@ namespace icicle_hip {
     }
   }
 
-  // out[slot(k)] = (1/N * g^-k on the inverse) * work[b][k], in the reference's projective_t layout
+  // out[slot(k)] = work[b][k] in the reference's projective_t layout (1/N and g^-k have been applied by k_ecntt_scale)
   template <class C>
-  __global__ __launch_bounds__(64) void k_ecntt_store(const typename EC<C>::Proj* __restrict__ work, uint32_t* __restrict__ out, const uint32_t* __restrict__ coset_pow, BigWords ninv_canonical, EcLayout lay)
+  __global__ __launch_bounds__(64) void k_ecntt_store(const typename EC<C>::Proj* __restrict__ work, uint32_t* __restrict__ out, EcLayout lay)
   {
     using T = EcNtt<C>;
     using E = typename T::E;
@@ -402,15 +402,12 @@ namespace icicle_hip {
       k_big_coset_powers<PR><<<(unsigned)((n / 16 + 256) / 256), 256, 0, st>>>(d_pw.as<uint32_t>(), mont_words<PR>(gm), n);
       LAUNCH_CHECK("k_big_coset_powers", st);
     }
-    BigWords ninv{};
-    ninv.w[0] = 1;
-    if (lay.inverse) FR::to_canonical(ninv.w, host_ninv<PR>(logn));
     BigWords ninv_mont{};
     if (lay.inverse) ninv_mont = mont_words<PR>(host_ninv<PR>(logn)); // packed Montgomery words, like the coset table's entries
 
     const uint64_t tot = n * batch;
     Proj* work = d_work.as<Proj>();
-    k_ecntt_load<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(d_in, work, d_pw.as<uint32_t>(), lay);
+    k_ecntt_load<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(d_in, work, lay);
     LAUNCH_CHECK("k_ecntt_load", st);
     // per-point factors outside the butterflies (forward coset on the way in; 1/N [and the coset] on the way out): k_ecntt_scale
     const uint64_t scale_quads = ((tot * 4 + 63) / 64) * 16;
@@ -470,7 +467,7 @@ namespace icicle_hip {
       work = cur;
     }
     if (lay.inverse) ICICLE_TRY(scale(work, 2));
-    k_ecntt_store<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(work, d_out, d_pw.as<uint32_t>(), ninv, lay);
+    k_ecntt_store<C><<<(unsigned)((tot + 63) / 64), 64, 0, st>>>(work, d_out, lay);
     LAUNCH_CHECK("k_ecntt_store", st);
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
 
