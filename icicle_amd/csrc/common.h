@@ -67,6 +67,19 @@ namespace icicle_hip {
   // makes the calling thread's HIP context match its icicle device; call at the top of every API
   icicle_error_t bind_current_device();
 
+  // true when `p` lies in a device allocation of the HIP runtime (hipMalloc memory of any device), false for pageable or
+  // pinned host memory. For the few entry points where a wrapper of the reference leaves a location flag at its default
+  // although the buffer's location is fixed by its type (msm_precompute_bases, below).
+  inline bool points_to_device_memory(const void* p)
+  {
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) {
+      (void)hipGetLastError(); // plain malloc memory: "invalid value", not an error of ours
+      return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+  }
+
   // opaque ConfigExtension (reference: include/icicle/config_extension.h:12-46)
   struct ConfigExt {
     std::unordered_map<std::string, std::variant<int, bool>> kv;
@@ -221,6 +234,18 @@ namespace icicle_hip {
   // Also called when the caller frees a device allocation through icicle_free / icicle_free_async: copies made for a
   // pointer that is gone must not be served to whatever is allocated at that address next.
   size_t resident_release(const void* bases);
+
+  // ---- precomputed base tables (msm_precompute_bases) ---------------------------------------------
+  // A table fixes the doubling shift c * wpf between the copies of a base, so msm() must run with the window size the table
+  // was built for. Both calls derive c from the size of ONE MSM (like cpu_msm.hpp:466 vs :207), which goes silently wrong
+  // as soon as the sizes differ -- an MSM over a prefix of a table, a per-MSM table precomputed with another batch_size
+  // (ADVICE r04). msm_precompute_bases therefore REMEMBERS where it wrote a table and with which c; msm() with
+  // precompute_factor > 1 and config.c <= 0 asks here first and only derives c from its own size for a table this process
+  // has not seen (one the caller copied or loaded: the reference's own contract then). Entries go when the allocation is
+  // freed through icicle_free / the plugin (table_forget_range); a host table is recognised by 32 bytes of its second entry.
+  void table_register(const void* table, size_t bytes, size_t entry_bytes, int pf, int c);
+  int table_lookup_c(const void* bases, size_t entry_bytes, int pf); // 0: unknown table
+  void table_forget_range(const void* ptr); // every table that starts inside the device allocation `ptr` belongs to
 
   // ---- host-thread rendezvous of the multi-device entry points (msm_multi.hpp, ntt_split.hpp) ----
   // Rendezvous of the per-device host threads in front of a collective: a thread that failed earlier (allocation,

@@ -1687,28 +1687,44 @@ namespace icicle_hip {
 #include "msm_multi.hpp"
 namespace icicle_hip {
 
+  // <curve>_msm_precompute_bases(input_bases, nof_bases, config, output_bases). `nof_bases` is the number of bases of ONE
+  // MSM: when every MSM of a batch brings its own (batch_size > 1, are_points_shared_in_batch = false) the input holds
+  // nof_bases * batch_size bases and all of them are extended -- this is what both wrappers hand over
+  // (wrappers/rust/icicle-core/src/msm/mod.rs:296 `points.len() / config.batch_size`, wrappers/golang/curves/bn254/msm/
+  // msm.go:39-43) and what their tests rely on (msm/tests.rs:195-217). The reference's CPU backend extends nof_bases
+  // points whatever the batch (cpu_msm.hpp:470-485) and leaves the rest of the table unwritten; rounds 1-4 here took
+  // nof_bases for the total. Table layout as the reference's: output[pf * i + j] = 2^(j * c * wpf) * input[i].
   template <class C>
-  static icicle_error_t msm_precompute_run(const void* in_v, int n, const icicle_msm_config_t* cfg, void* out_v)
+  static icicle_error_t msm_precompute_run(const void* in_v, int n_one, const icicle_msm_config_t* cfg, void* out_v)
   {
     using E = EC<C>;
     constexpr int PW = 2 * E::N32;
-    if (!cfg || n < 0) return ICICLE_INVALID_ARGUMENT;
-    if (n == 0) return ICICLE_SUCCESS;
+    if (!cfg || n_one < 0) return ICICLE_INVALID_ARGUMENT;
+    if (n_one == 0) return ICICLE_SUCCESS;
     if (!in_v || !out_v) return ICICLE_INVALID_POINTER;
     ICICLE_TRY(bind_current_device());
     hipStream_t st = (hipStream_t)cfg->stream;
-    const MsmPlan pl = make_plan(precompute_msm_size(n, *cfg), C::fr::NBITS, *cfg);
+    const int batch = std::max(1, cfg->batch_size);
+    const long long n_all = (!cfg->are_points_shared_in_batch && batch > 1) ? (long long)n_one * batch : n_one;
+    const MsmPlan pl = make_plan(n_one, C::fr::NBITS, *cfg);
     const int pf = pl.pf;
+    if (n_all * pf >= (1ll << 31)) return ICICLE_INVALID_ARGUMENT;
+    const int n = (int)n_all;
     TempBuf d_in_tmp, d_out_tmp;
     const uint32_t* d_in = (const uint32_t*)in_v;
     uint32_t* d_out = (uint32_t*)out_v;
-    // input location: are_points_on_device ; output location: are_results_on_device (msm.h:39-47)
-    if (!cfg->are_points_on_device) {
+    // input location: are_points_on_device ; output location: are_results_on_device (msm.h:39-47) -- as the Go wrapper sets
+    // them (wrappers/golang/core/msm.go:138-139). The Rust wrapper hands its MSMConfig through untouched
+    // (icicle-core/src/msm/mod.rs:288-302: the two flags are private and only msm() derives them) while the output is a
+    // DeviceSlice by type and the input may be one: a flag left at "host" is checked against the pointer itself.
+    const bool in_on_device = cfg->are_points_on_device || points_to_device_memory(in_v);
+    const bool out_on_device = cfg->are_results_on_device || points_to_device_memory(out_v);
+    if (!in_on_device) {
       HIP_TRY(d_in_tmp.alloc((size_t)n * PW * 4, st), ICICLE_ALLOCATION_FAILED);
       HIP_TRY(hipMemcpyAsync(d_in_tmp.ptr(), in_v, (size_t)n * PW * 4, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
       d_in = d_in_tmp.as<uint32_t>();
     }
-    if (!cfg->are_results_on_device) {
+    if (!out_on_device) {
       HIP_TRY(d_out_tmp.alloc((size_t)n * pf * PW * 4, st), ICICLE_ALLOCATION_FAILED);
       d_out = d_out_tmp.as<uint32_t>();
     }
@@ -1721,12 +1737,13 @@ namespace icicle_hip {
     k_precompute<C><<<(unsigned)((nthr + 63) / 64), 64, 0, st>>>(d_in, d_out, n, pf, pl.c * pl.wpf, cfg->are_points_montgomery_form, pt, ((uintptr_t)d_out & 15) == 0);
     LAUNCH_CHECK("k_precompute", st);
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
-    if (!cfg->are_results_on_device) {
+    if (!out_on_device) {
       HIP_TRY(hipMemcpyAsync(out_v, d_out, (size_t)n * pf * PW * 4, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
       HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
     } else if (!cfg->is_async) {
       HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
     }
+    table_register(out_v, (size_t)n * pf * PW * 4, (size_t)PW * 4, pf, pl.c); // msm() on this table finds its window size here
     return ICICLE_SUCCESS;
   }
 

@@ -436,6 +436,17 @@ namespace icicle_hip {
   static icicle_error_t msm_run(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v)
   {
     if (!cfg) return ICICLE_INVALID_ARGUMENT;
+    icicle_msm_config_t with_c;
+    if (cfg->precompute_factor > 1 && cfg->c <= 0) {
+      // a base table written by msm_precompute_bases in this process: run with the window size it was built for, whatever
+      // the size of THIS msm is (a prefix of the table, another batch shape; common.h "precomputed base tables")
+      const int c = table_lookup_c(bases_v, (size_t)2 * EC<C>::N32 * 4, cfg->precompute_factor);
+      if (c > 0) {
+        with_c = *cfg;
+        with_c.c = c;
+        cfg = &with_c;
+      }
+    }
     MsmMultiOpts opt;
     opt.G = 0;
     if (cfg->ext) {

@@ -42,14 +42,6 @@ namespace icicle_hip {
     uint32_t seg; // bucket-accumulation segment size: a bucket with more points is split across threads
   };
 
-  // the MSM size msm_precompute_bases(nof_bases, config) plans for: one MSM's bases when they are shared over the batch
-  // (or there is no batch), nof_bases / batch_size when every MSM of the batch brings its own
-  static inline int precompute_msm_size(int nof_bases, const icicle_msm_config_t& cfg)
-  {
-    const int b = std::max(1, cfg.batch_size);
-    return (!cfg.are_points_shared_in_batch && b > 1 && nof_bases % b == 0) ? nof_bases / b : nof_bases;
-  }
-
   static MsmPlan make_plan(int n, int scalar_bits, const icicle_msm_config_t& cfg)
   {
     MsmPlan p;
@@ -61,8 +53,8 @@ namespace icicle_hip {
     // size of ONE MSM, the scalar bits and precompute_factor -- and from nothing else: with precompute_factor > 1 the
     // choice ignores batch_size (the two calls rarely carry the same one: the Rust suite precomputes shared bases with
     // batch_size 1 and then runs batches of 1, 3 and 16 on the table, wrappers/rust/icicle-core/src/msm/tests.rs:96-134).
-    // msm_precompute_bases sees nof_bases: the size of one MSM for shared bases, batch_size of them otherwise
-    // (precompute_msm_size below; tests.rs:195-201). Rounds 1-3 used a fixed c = 16 here, which made every MSM from 2^20 up
+    // msm_precompute_bases is handed the size of one MSM as nof_bases by both wrappers (msm_impl.hpp msm_precompute_run), and
+    // msm() on a table this process wrote takes c from the table registry (common.h) before it gets here. Rounds 1-3 used a fixed c = 16 here, which made every MSM from 2^20 up
     // SLOWER with a table (16 windows against 13); now a table lowers the bucket count per window set by pf and the cost
     // model moves c up with it, as docs/docs/api/cpp/msm.md:155-201 describes. Pass config.c on both calls to override.
     const bool table = p.pf > 1;

@@ -364,6 +364,60 @@ namespace icicle_hip {
     t_event_rings.clear();
   }
 
+  // ---- precomputed base tables: where msm_precompute_bases wrote them and with which window size (common.h) ----
+  namespace {
+    struct TableInfo {
+      size_t bytes, entry_bytes;
+      int pf, c;
+      bool on_device;
+      unsigned char print[32]; // host tables: the first bytes of entry 1 (= 2^(c wpf) * base 0)
+    };
+    std::mutex g_table_mtx;
+    std::map<uintptr_t, TableInfo> g_tables; // start address -> table
+  } // namespace
+  void table_register(const void* table, size_t bytes, size_t entry_bytes, int pf, int c)
+  {
+    if (!table || pf <= 1 || bytes < 2 * entry_bytes) return;
+    TableInfo t{bytes, entry_bytes, pf, c, points_to_device_memory(table), {}};
+    if (!t.on_device) memcpy(t.print, (const char*)table + entry_bytes, std::min<size_t>(32, entry_bytes));
+    std::lock_guard<std::mutex> g(g_table_mtx);
+    const uintptr_t a = (uintptr_t)table;
+    for (auto it = g_tables.lower_bound(a); it != g_tables.end() && it->first < a + bytes;) // tables this one overwrites
+      it = g_tables.erase(it);
+    auto lo = g_tables.lower_bound(a);
+    if (lo != g_tables.begin() && (--lo)->first + lo->second.bytes > a) g_tables.erase(lo);
+    g_tables[a] = t;
+  }
+  int table_lookup_c(const void* bases, size_t entry_bytes, int pf)
+  {
+    if (!bases || pf <= 1) return 0;
+    std::lock_guard<std::mutex> g(g_table_mtx);
+    const uintptr_t a = (uintptr_t)bases;
+    auto it = g_tables.upper_bound(a);
+    if (it == g_tables.begin()) return 0;
+    --it;
+    const TableInfo& t = it->second;
+    if (a >= it->first + t.bytes || t.pf != pf || t.entry_bytes != entry_bytes || (a - it->first) % (entry_bytes * pf) != 0) return 0;
+    if (!t.on_device && memcmp(t.print, (const char*)it->first + entry_bytes, std::min<size_t>(32, entry_bytes)) != 0) {
+      g_tables.erase(it); // the host memory holds something else by now
+      return 0;
+    }
+    return t.c;
+  }
+  void table_forget_range(const void* ptr)
+  {
+    if (!ptr) return;
+    void* base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void*>(ptr)) != hipSuccess) {
+      (void)hipGetLastError();
+      base = const_cast<void*>(ptr), size = 1;
+    }
+    std::lock_guard<std::mutex> g(g_table_mtx);
+    for (auto it = g_tables.lower_bound((uintptr_t)base); it != g_tables.end() && it->first < (uintptr_t)base + size;)
+      it = g_tables.erase(it);
+  }
+
   // ---- resident base shards ("hip_bases_resident") -----------------------------------------------
   std::mutex& resident_mtx()
   {
@@ -377,6 +431,7 @@ namespace icicle_hip {
   }
   size_t resident_release(const void* bases)
   {
+    if (bases) table_forget_range(bases); // (called for every allocation that is being freed: its tables go with it)
     std::lock_guard<std::mutex> g(resident_mtx());
     auto& m = resident_map();
     if (m.empty()) return 0;
@@ -758,8 +813,16 @@ icicle_error_t icicle_create_stream(icicleStreamHandle* stream)
 {
   if (!stream) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(bind_current_device());
+  // a BLOCKING stream, like the reference's GPU DeviceAPI (cudaStreamCreate, backend/cuda_pqc/src/cuda_pqc_device_api.cu:98-105):
+  // the synchronous icicle_copy* / icicle_memset run on the null stream and therefore behind everything queued on any
+  // user stream -- the order wrappers/rust/icicle-core/src/msm/tests.rs:60-79 depends on (result copied before the
+  // stream is synchronized). ICICLE_HIP_STREAMS_NONBLOCKING=1: rounds 1-4's hipStreamNonBlocking, for the A/B only.
+  static const bool nonblocking = [] {
+    const char* e = getenv("ICICLE_HIP_STREAMS_NONBLOCKING");
+    return e && *e && *e != '0';
+  }();
   hipStream_t s;
-  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), ICICLE_STREAM_CREATION_FAILED);
+  HIP_TRY(hipStreamCreateWithFlags(&s, nonblocking ? hipStreamNonBlocking : hipStreamDefault), ICICLE_STREAM_CREATION_FAILED);
   *stream = (icicleStreamHandle)s;
   return ICICLE_SUCCESS;
 }

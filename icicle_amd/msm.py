@@ -54,10 +54,13 @@ def precompute_bases(curve: str, bases, cfg: MSMConfig, output=None, nof_bases: 
     L, sym = _group(curve, g2)
     bp, b_dev = _ptr(bases)
     cfg.are_points_on_device = b_dev
+    # nof_bases = the bases of ONE MSM, as both wrappers pass it (icicle-core/src/msm/mod.rs:296, golang .../msm/msm.go:39-43):
+    # with per-MSM bases (batch_size > 1, are_points_shared_in_batch = False) the input holds nof_bases * batch_size points
+    per_msm = max(1, cfg.batch_size) if not cfg.are_points_shared_in_batch else 1
     if nof_bases is None:
-        nof_bases = bases.size // (2 * L)
+        nof_bases = bases.size // (2 * L) // per_msm
     if output is None:
-        output = np.zeros((nof_bases * cfg.precompute_factor, 2 * L), dtype=np.uint32)
+        output = np.zeros((nof_bases * per_msm * cfg.precompute_factor, 2 * L), dtype=np.uint32)
     op, o_dev = _ptr(output)
     cfg.are_results_on_device = o_dev
     check(getattr(lib, f"{sym}_msm_precompute_bases")(bp, nof_bases, ctypes.byref(cfg), op), f"{sym}_msm_precompute_bases")

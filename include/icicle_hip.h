@@ -130,6 +130,17 @@ typedef struct {
   icicle_config_extension_t* ext;  /* 32 */
 } icicle_msm_config_t;
 
+/* <curve>_msm_precompute_bases: `nof_bases` is the number of bases of ONE MSM, as both wrappers of the reference pass it
+ * (wrappers/rust/icicle-core/src/msm/mod.rs:296, wrappers/golang/curves/bn254/msm/msm.go:39-43): with per-MSM bases
+ * (batch_size > 1, are_points_shared_in_batch = false) input_bases holds nof_bases * batch_size points and output_bases
+ * takes precompute_factor times as many; layout output[precompute_factor * i + j] = 2^(j * shift) * input[i]
+ * (backend/cpu/src/curve/cpu_msm.hpp:470-485). The output is device memory whenever the pointer says so, even with
+ * are_results_on_device left false (the Rust wrapper never sets it for this call).
+ * Window size with a table: pass the same config.c > 0 to both calls, or leave both at 0 -- then msm() takes the c the table
+ * was built with from a per-process record of the tables msm_precompute_bases wrote (any aligned slice of such a table
+ * works, whatever msm_size / batch_size), and only for a table it has never seen (copied, loaded from disk) derives c from
+ * msm_size, scalar bits and precompute_factor exactly as msm_precompute_bases does from nof_bases -- the reference's rule
+ * (cpu_msm.hpp:466 vs :207), correct when the two sizes are equal. */
 icicle_error_t bn254_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results); /* src/msm.cpp:12 */
 icicle_error_t bn254_msm_precompute_bases(const void* input_bases, int nof_bases, const icicle_msm_config_t* config, void* output_bases); /* src/msm.cpp:45 */
 icicle_error_t bls12_381_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results);

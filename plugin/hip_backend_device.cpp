@@ -10,6 +10,7 @@
 // Structural model: the reference's only in-tree GPU DeviceAPI,
 // icicle/backend/cuda_pqc/src/cuda_pqc_device_api.cu:11-121 (not copied; different API, same contract).
 #include <dlfcn.h>
+#include <cstdlib>
 #include <hip/hip_runtime_api.h>
 #include <mutex>
 #include <vector>
@@ -183,10 +184,24 @@ public:
     reap(false);
     return e;
   }
+  // User streams are BLOCKING streams, as the reference's own GPU DeviceAPI creates them (cudaStreamCreate,
+  // backend/cuda_pqc/src/cuda_pqc_device_api.cu:98-105): the synchronous copy / memset entry points run on the null stream,
+  // which waits for everything queued on every blocking stream of the device. Callers rely on that order -- the Rust suite's
+  // check_msm copies the result of an async msm() to the host BEFORE it synchronizes the stream (msm/tests.rs:60-79).
+  // Rounds 1-4 created hipStreamNonBlocking streams, which made that copy race with the MSM's last kernel.
+  // ICICLE_HIP_STREAMS_NONBLOCKING=1 brings the old behaviour back for the A/B in tests/test_gpu_rust_suite.py.
+  static bool nonblocking_streams()
+  {
+    static const bool v = [] {
+      const char* e = getenv("ICICLE_HIP_STREAMS_NONBLOCKING");
+      return e && *e && *e != '0';
+    }();
+    return v;
+  }
   eIcicleError create_stream(icicleStreamHandle* stream) const override
   {
     hipStream_t s;
-    eIcicleError e = tr(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), eIcicleError::STREAM_CREATION_FAILED);
+    eIcicleError e = tr(hipStreamCreateWithFlags(&s, nonblocking_streams() ? hipStreamNonBlocking : hipStreamDefault), eIcicleError::STREAM_CREATION_FAILED);
     if (e == eIcicleError::SUCCESS) *stream = (icicleStreamHandle)s;
     return e;
   }

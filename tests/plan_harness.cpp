@@ -113,10 +113,6 @@ extern "C" int msm_plan_check(void)
             icicle_msm_config_t c1 = cfg;
             c1.batch_size = 1;
             if (make_plan(n, bits, c1).c != p.c) return tag * 10 + 5;
-            c1.batch_size = 3, c1.are_points_shared_in_batch = false; // per-MSM tables: nof_bases = 3 n
-            if (precompute_msm_size(3 * n, c1) != n) return tag * 10 + 8;
-            c1.are_points_shared_in_batch = true;
-            if (precompute_msm_size(n, c1) != n) return tag * 10 + 9;
           }
           cfg.c = 13;
           if (make_plan(n, bits, cfg).c != 13) return tag * 10 + 6;

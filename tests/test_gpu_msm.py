@@ -228,9 +228,8 @@ def test_msm_precompute(hip, cname):
 @pytest.mark.parametrize("cname", CURVES)
 def test_msm_precompute_non_shared_batch(hip, cname):
     """per-MSM base tables as the Rust suite builds them (wrappers/rust/icicle-core/src/msm/tests.rs:195-220):
-    msm_precompute_bases over batch * n bases with batch_size / are_points_shared_in_batch = false set on BOTH calls (the
-    window size follows the size of one MSM on both sides, like cpu_msm.hpp:466 vs :207); and a different msm_size on the
-    same table with config.c pinned on both calls"""
+    msm_precompute_bases over batch * n bases with batch_size / are_points_shared_in_batch = false set on BOTH calls and
+    nof_bases = the bases of ONE MSM (msm/mod.rs:296); and a different msm_size on the same table with config.c pinned"""
     from icicle_amd import msm as M
 
     C = pyref.CURVES[cname]
@@ -244,7 +243,8 @@ def test_msm_precompute_non_shared_batch(hip, cname):
     cfg.precompute_factor = pf
     cfg.batch_size = batch
     cfg.are_points_shared_in_batch = False
-    pre = M.precompute_bases(cname, bases, cfg)  # nof_bases = batch * n
+    pre = M.precompute_bases(cname, bases, cfg)  # nof_bases = n, batch * n bases extended
+    assert pre.shape[0] == n * batch * pf and pre[-1].any()
     got = M.msm(cname, sc, pre, cfg)
     assert np.array_equal(refc.to_affine(got), exp)
     # the first 100 bases of a table built with an explicit c, as a single MSM of a different size
@@ -255,6 +255,43 @@ def test_msm_precompute_non_shared_batch(hip, cname):
     cfg1.c = 9
     got1 = M.msm(cname, np.ascontiguousarray(sc[:100]), np.ascontiguousarray(pre[: 100 * pf]), cfg1)
     assert np.array_equal(refc.to_affine(got1), refc.to_affine(refc.msm(np.ascontiguousarray(sc[:100]), np.ascontiguousarray(bases[:100]))))
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_on_a_table_of_another_size_finds_its_window(hip, cname):
+    """with precompute_factor > 1 and config.c = 0 both calls derive c from their OWN size, so an MSM over a prefix
+    of a table, or a batched MSM on a table precomputed with batch_size 1, used a shift the table was not built with --
+    silently wrong. msm_precompute_bases now records (address range -> c) and msm() looks its bases pointer up first."""
+    from icicle_amd import msm as M
+    import ctypes
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(35)
+    n, pf = 1 << 14, 8
+    bases = points_to_array(C, cached_points(C, 2048))
+    bases = np.ascontiguousarray(np.tile(bases, (n // 2048, 1)))
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    cfg = hip.MSMConfig.default()
+    cfg.precompute_factor = pf
+    pre = M.precompute_bases(cname, bases, cfg)  # c chosen for 2^14
+    c_big, c_small, nw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    hip.lib.icicle_hip_msm_plan(n, C.r.bit_length(), ctypes.byref(cfg), ctypes.byref(c_big), ctypes.byref(nw))
+    hip.lib.icicle_hip_msm_plan(100, C.r.bit_length(), ctypes.byref(cfg), ctypes.byref(c_small), ctypes.byref(nw))
+    assert c_big.value != c_small.value  # (otherwise this test proves nothing)
+    # (1) a prefix of the table as an MSM of 100 terms, c left to the backend
+    got = M.msm(cname, np.ascontiguousarray(sc[:100]), pre[: 100 * pf], cfg)
+    assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(np.ascontiguousarray(sc[:100]), np.ascontiguousarray(bases[:100]))))
+    # (2) an interior slice of the table (starts at base 512)
+    got = M.msm(cname, np.ascontiguousarray(sc[512:812]), pre[512 * pf: 812 * pf], cfg)
+    assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(np.ascontiguousarray(sc[512:812]), np.ascontiguousarray(bases[512:812]))))
+    # (3) the table precomputed in ONE call with batch_size 1, used as per-MSM tables of a batch of 16 MSMs of 2^10
+    cfgb = hip.MSMConfig.default()
+    cfgb.precompute_factor = pf
+    cfgb.batch_size = 16
+    cfgb.are_points_shared_in_batch = False
+    got = M.msm(cname, sc, pre, cfgb)
+    assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(sc, bases, batch=16, shared=False)))
 
 
 def test_generated_points_are_distinct_multiples_of_g(hip):
