@@ -139,10 +139,31 @@ namespace icicle_hip {
     it.w[8] = 0;
     it.carry = 0;
   }
+  // window widths of a launch (msm_plan.h MsmPlan): windows [0, n_lo) are c - 1 bits wide, the others c; `negate`: a scalar
+  // with its top bit set is replaced by r - s and every digit of it changes sign (cpu_msm.hpp:276-277,300-306)
+  struct WinWidths {
+    int c, n_lo;
+    bool negate;
+    __host__ __device__ int width(int wi) const { return wi < n_lo ? c - 1 : c; }
+  };
+  template <class C>
+  __device__ __forceinline__ bool negate_scalar_if_top_bit(DigitIter& it)
+  {
+    constexpr int TOP = C::fr::NBITS - 1;
+    if (!((it.w[TOP >> 5] >> (TOP & 31)) & 1u)) return false;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { // r - s, both below 2^256
+      const uint64_t d = (uint64_t)C::fr::P32[k] - it.w[k] - borrow;
+      it.w[k] = (uint32_t)d;
+      borrow = (uint32_t)(d >> 63);
+    }
+    return true;
+  }
 
   // digits of all windows, dig[wi*n + i] (coalesced 4-byte writes; read back window by window)
   template <class C>
-  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, size_t nscal, int c, int nwin, bool scalars_refmont, int bits)
+  __global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, int n, size_t nscal, WinWidths ww, int nwin, bool scalars_refmont, int bits)
   {
     // nscal = (MSMs in this launch) * n scalars; row (b*nwin + wi) of `dig` holds window wi of MSM b
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -150,15 +171,18 @@ namespace icicle_hip {
     const size_t b = t / n, i = t - b * n;
     DigitIter it;
     load_scalar<C>(it, scalars, t, scalars_refmont, bits);
-    for (int wi = 0; wi < nwin; wi++)
-      dig[(b * nwin + wi) * n + i] = it.next(c);
+    const uint32_t flip = (ww.negate && negate_scalar_if_top_bit<C>(it)) ? 0x80000000u : 0u;
+    for (int wi = 0; wi < nwin; wi++) {
+      const uint32_t d = it.next(ww.width(wi));
+      dig[(b * nwin + wi) * n + i] = d ? (d ^ flip) : 0u;
+    }
   }
 
   // k_digits fused with pass A's histogram (k_a_count): block (b, mb) owns scalar chunk b of MSM mb, writes its digits
   // and counts, per target window, how many fall into each of the 2^hb partitions -- the counts come from registers
   // instead of a second read of the 13 x 4 B per scalar digit array. Dynamic LDS: wpf * 2^hb counters.
   template <class C>
-  __global__ __launch_bounds__(1024) void k_digits_count(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int c, int nwin, int wpf, SortPlan sp, bool scalars_refmont, int bits)
+  __global__ __launch_bounds__(1024) void k_digits_count(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, WinWidths ww, int nwin, int wpf, SortPlan sp, bool scalars_refmont, int bits)
   {
     extern __shared__ uint32_t lds[];
     const int b = blockIdx.x, mb = blockIdx.y;
@@ -170,9 +194,11 @@ namespace icicle_hip {
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
       DigitIter it;
       load_scalar<C>(it, scalars, (size_t)mb * n + i, scalars_refmont, bits);
+      const uint32_t flip = (ww.negate && negate_scalar_if_top_bit<C>(it)) ? 0x80000000u : 0u;
       int wp = 0;
       for (int wi = 0; wi < nwin; wi++) {
-        const uint32_t d = it.next(c);
+        uint32_t d = it.next(ww.width(wi));
+        d = d ? (d ^ flip) : 0u;
         dig[((size_t)mb * nwin + wi) * n + i] = d;
         const uint32_t key = d & 0x7fffffffu;
         if (key) atomicAdd(&lds[(uint32_t)wp * D + ((key - 1) >> sp.lb)], 1u);
@@ -220,24 +246,28 @@ namespace icicle_hip {
   // scatters (the unstaged scatter wrote 30 GB to place 3.5 GB, profiles/r01_notes.md).
   constexpr int SORT_EPT = 16;                 // elements per thread per tile
   constexpr uint32_t SORT_TS = 1024 * SORT_EPT; // tile size with 1024 threads
+  // Two block shapes. 1024 threads (a whole CU: 16 waves, ~100 KiB of LDS) is the stand-alone sort. 256 threads (one wave per
+  // SIMD, a 4096-element tile, ~36 KiB) is the CO-RESIDENT sort of the pipelined schedule (msm_run_single, window groups):
+  // its waves fit beside two k_accumulate waves per SIMD, so the sort of window group g + 1 -- waves parked on memory most
+  // of the time -- runs in the issue slots the accumulation of group g leaves, instead of before it.
   struct TileLds {
     uint32_t* cnt;   // [D] per-destination count of this tile -> reused as tile-local offset
     uint32_t* gbase; // [D] global position of this tile's run per destination
-    uint32_t* stage; // [SORT_TS]
-    uint16_t* sdest; // [SORT_TS]
+    uint32_t* stage; // [TS]
+    uint16_t* sdest; // [TS]
     uint32_t* wsum;  // [32]
   };
-  __device__ __forceinline__ TileLds tile_lds(uint32_t* lds, uint32_t D)
+  __device__ __forceinline__ TileLds tile_lds(uint32_t* lds, uint32_t D, uint32_t TS = SORT_TS)
   {
     TileLds t;
     t.cnt = lds;
     t.gbase = lds + D;
     t.stage = lds + 2 * D;
-    t.sdest = reinterpret_cast<uint16_t*>(lds + 2 * D + SORT_TS);
-    t.wsum = lds + 2 * D + SORT_TS + SORT_TS / 2;
+    t.sdest = reinterpret_cast<uint16_t*>(lds + 2 * D + TS);
+    t.wsum = lds + 2 * D + TS + TS / 2;
     return t;
   }
-  __host__ __device__ static inline size_t tile_lds_bytes(uint32_t D) { return ((size_t)2 * D + SORT_TS + SORT_TS / 2 + 32) * 4; }
+  __host__ __device__ static inline size_t tile_lds_bytes(uint32_t D, uint32_t TS = SORT_TS) { return ((size_t)2 * D + TS + TS / 2 + 32) * 4; }
 
   // pass A count: block (b, wl) histograms the high key bits of scalar chunk b for target window w0+wl
   static __global__ __launch_bounds__(1024) void k_a_count(const uint32_t* __restrict__ dig, uint32_t* __restrict__ cntA, int n, int nwin, int wpf, int pf, SortPlan sp)
@@ -276,17 +306,19 @@ namespace icicle_hip {
 
   // pass A scatter: element = sign | low key bits | j | index within chunk, into partition runs
   // FINAL: single-level sort (lb == 0): the element is already the bucket-list entry (point index | sign)
-  template <bool FINAL>
-  __global__ __launch_bounds__(1024) void k_a_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int nwin, int wpf, int pf, SortPlan sp, size_t cap, int wl0)
+  template <bool FINAL, int TPB>
+  __global__ __launch_bounds__(TPB) void k_a_scatter(const uint32_t* __restrict__ dig, const uint32_t* __restrict__ offA, uint32_t* __restrict__ outA, int n, int nwin, int wpf, int pf, SortPlan sp, size_t cap, int wl0)
   {
     // wl0: first window of this launch (window groups of the pipelined schedule); every table is indexed by the global wl
     extern __shared__ uint32_t lds[];
+    constexpr uint32_t TS = (uint32_t)TPB * SORT_EPT;
     const int b = blockIdx.x, wl = wl0 + (int)blockIdx.y, wp = wl % wpf;
     const size_t rowbase = (size_t)(wl / wpf) * nwin;
     const uint32_t D = 1u << sp.hb;
-    TileLds t = tile_lds(lds, D);
-    uint32_t* cursor = lds + tile_lds_bytes(D) / 4; // [D] running write position per destination
-    for (uint32_t k = threadIdx.x; k < D; k += blockDim.x)
+    const uint32_t R = (D + TPB - 1) / TPB, k0 = threadIdx.x * R; // destinations [k0, k0 + R) belong to this thread (D <= TPB: one)
+    TileLds t = tile_lds(lds, D, TS);
+    uint32_t* cursor = lds + tile_lds_bytes(D, TS) / 4; // [D] running write position per destination
+    for (uint32_t k = threadIdx.x; k < D; k += TPB)
       cursor[k] = offA[(((size_t)wl << sp.hb) + k) * sp.nblk + b];
     __syncthreads();
     const int lo = b << sp.chunk_log, hi = min(n, lo + (1 << sp.chunk_log));
@@ -301,22 +333,23 @@ namespace icicle_hip {
       auto fetch = [&](int tile0, uint32_t* buf) {
 #pragma unroll
         for (int it = 0; it < SORT_EPT; it++) {
-          const int i = tile0 + it * 1024 + threadIdx.x;
+          const int i = tile0 + it * TPB + threadIdx.x;
           buf[it] = i < hi ? d[i] : 0u;
         }
       };
       uint32_t cur[SORT_EPT];
       fetch(lo, cur);
       __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first tile lands before the loop (see k_ntt_fast: a pending entry edge makes the waitcnt pass guard every iteration conservatively)
-      for (int tile0 = lo; tile0 < hi; tile0 += SORT_TS) {
+      for (int tile0 = lo; tile0 < hi; tile0 += TS) {
         uint32_t nxt[SORT_EPT];
-        fetch(tile0 + (int)SORT_TS, nxt); // past the end of the chunk every lane is predicated off (zeros)
-        if (threadIdx.x < D) t.cnt[threadIdx.x] = 0;
+        fetch(tile0 + (int)TS, nxt); // past the end of the chunk every lane is predicated off (zeros)
+        for (uint32_t k = threadIdx.x; k < D; k += TPB)
+          t.cnt[k] = 0;
         __syncthreads();
         uint32_t el[SORT_EPT], dr[SORT_EPT]; // element, (dest << 16 | rank)
 #pragma unroll
         for (int it = 0; it < SORT_EPT; it++) {
-          const int i = tile0 + it * 1024 + threadIdx.x;
+          const int i = tile0 + it * TPB + threadIdx.x;
           dr[it] = 0xffffffffu;
           if (i < hi) {
             const uint32_t dv = cur[it];
@@ -330,13 +363,18 @@ namespace icicle_hip {
           }
         }
         __syncthreads();
-        const uint32_t mycnt = threadIdx.x < D ? t.cnt[threadIdx.x] : 0;
-        const uint32_t toff = block_exscan(mycnt, t.wsum);
-        if (threadIdx.x < D) {
-          t.cnt[threadIdx.x] = toff; // now the tile-local offset
-          t.gbase[threadIdx.x] = cursor[threadIdx.x];
-          cursor[threadIdx.x] += mycnt;
-        }
+        uint32_t mysum = 0;
+        for (uint32_t r = 0; r < R; r++)
+          if (k0 + r < D) mysum += t.cnt[k0 + r];
+        uint32_t toff = block_exscan(mysum, t.wsum);
+        for (uint32_t r = 0; r < R; r++)
+          if (k0 + r < D) {
+            const uint32_t c1 = t.cnt[k0 + r];
+            t.cnt[k0 + r] = toff; // now the tile-local offset
+            t.gbase[k0 + r] = cursor[k0 + r];
+            cursor[k0 + r] += c1;
+            toff += c1;
+          }
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < SORT_EPT; it++)
@@ -357,7 +395,7 @@ namespace icicle_hip {
           asm volatile("" : "+v"(cur[it]));
         }
         const uint32_t ntile = t.cnt[D - 1] + (cursor[D - 1] - t.gbase[D - 1]);
-        for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += blockDim.x) {
+        for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += TPB) {
           const uint32_t h = t.sdest[sidx];
           dst[t.gbase[h] + (sidx - t.cnt[h])] = t.stage[sidx];
         }
@@ -527,19 +565,22 @@ namespace icicle_hip {
       if (lds[k]) atomicAdd(&cw[k], lds[k]);
   }
 
-  static __global__ __launch_bounds__(1024) void k_b_scatter(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted, uint32_t nparts, int wpf, int pf, SortPlan sp, size_t cap, uint32_t nb, uint32_t p0)
+  template <int TPB>
+  __global__ __launch_bounds__(TPB) void k_b_scatter(const uint32_t* __restrict__ inA, const uint32_t* __restrict__ offA, const uint32_t* __restrict__ bstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted, uint32_t nparts, int wpf, int pf, SortPlan sp, size_t cap, uint32_t nb, uint32_t p0)
   {
     extern __shared__ uint32_t lds[]; // tile-sort arrays | [nblk+1] piece offsets of this partition
+    constexpr uint32_t TS = (uint32_t)TPB * SORT_EPT;
     uint32_t p, r0, r1;
     if (!b_locate(bstart, offA, nparts, wpf, sp.hb, sp.nblk, p0, p, r0, r1)) return;
     const uint32_t D = 1u << sp.lb;
-    TileLds t = tile_lds(lds, D);
-    uint32_t* boffs = lds + tile_lds_bytes(D) / 4;
-    uint32_t* gmap = boffs + sp.nblk + 1; // [SORT_TS / 64]
+    const uint32_t R = (D + TPB - 1) / TPB, k0 = threadIdx.x * R; // bins [k0, k0 + R) belong to this thread
+    TileLds t = tile_lds(lds, D, TS);
+    uint32_t* boffs = lds + tile_lds_bytes(D, TS) / 4;
+    uint32_t* gmap = boffs + sp.nblk + 1; // [TS / 64]
     const uint32_t wp = p >> sp.hb, h = p & ((1u << sp.hb) - 1);
     const uint32_t nparts_w = 1u << sp.hb;
     const size_t row = (size_t)p * sp.nblk;
-    for (uint32_t k = threadIdx.x; k <= (uint32_t)sp.nblk; k += blockDim.x)
+    for (uint32_t k = threadIdx.x; k <= (uint32_t)sp.nblk; k += TPB)
       boffs[k] = (k < (uint32_t)sp.nblk) ? offA[row + k] : ((h + 1 < nparts_w) ? offA[row + sp.nblk] : offA[(size_t)wpf * nparts_w * sp.nblk + wp]);
     __syncthreads();
     const uint32_t* src = inA + (size_t)wp * cap;
@@ -552,22 +593,22 @@ namespace icicle_hip {
     auto fetch = [&](uint32_t tile0, uint32_t* buf) { // next tile's elements, see k_a_scatter
 #pragma unroll
       for (int it = 0; it < SORT_EPT; it++) {
-        const uint32_t pos = tile0 + it * 1024 + threadIdx.x;
+        const uint32_t pos = tile0 + it * TPB + threadIdx.x;
         buf[it] = pos < r1 ? src[pos] : 0u;
       }
     };
     uint32_t cur[SORT_EPT];
     fetch(r0, cur);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), see k_a_scatter
-    for (uint32_t tile0 = r0; tile0 < r1; tile0 += SORT_TS) {
+    for (uint32_t tile0 = r0; tile0 < r1; tile0 += TS) {
       uint32_t nxt[SORT_EPT];
-      fetch(tile0 + SORT_TS, nxt); // past the end of the run every lane is predicated off (zeros)
-      for (uint32_t k = threadIdx.x; k < D; k += 1024) // (D = 2048 bins at c = 22: two per thread)
+      fetch(tile0 + TS, nxt); // past the end of the run every lane is predicated off (zeros)
+      for (uint32_t k = threadIdx.x; k < D; k += TPB) // (D = 2048 bins at c = 22)
         t.cnt[k] = 0;
       // source block (scalar chunk) of an element = last bsrc with boffs[bsrc] <= pos. One binary search per
-      // 64 consecutive positions (256 threads, once per tile); an element then starts from its group's answer
+      // 64 consecutive positions (once per tile); an element then starts from its group's answer
       // and walks forward (pieces are ~64 elements long, so 0-2 steps) instead of 10 dependent LDS reads each.
-      if (threadIdx.x < SORT_TS / 64) {
+      if (threadIdx.x < TS / 64) {
         const uint32_t pos = tile0 + threadIdx.x * 64;
         uint32_t blo = 0, bhi = sp.nblk;
         if (pos < r1) {
@@ -586,11 +627,11 @@ namespace icicle_hip {
       uint32_t el[SORT_EPT], dr[SORT_EPT];
 #pragma unroll
       for (int it = 0; it < SORT_EPT; it++) {
-        const uint32_t pos = tile0 + it * 1024 + threadIdx.x;
+        const uint32_t pos = tile0 + it * TPB + threadIdx.x;
         dr[it] = 0xffffffffu;
         if (pos < r1) {
           const uint32_t e = cur[it];
-          uint32_t blo = gmap[(it * 1024 + threadIdx.x) >> 6];
+          uint32_t blo = gmap[(it * TPB + threadIdx.x) >> 6];
           while (blo + 1 < (uint32_t)sp.nblk && boffs[blo + 1] <= pos)
             blo++;
           const uint32_t i = (blo << sp.chunk_log) + (e & imask);
@@ -601,21 +642,18 @@ namespace icicle_hip {
         }
       }
       __syncthreads();
-      if (D <= 1024) {
-        const uint32_t mycnt = threadIdx.x < D ? t.cnt[threadIdx.x] : 0;
-        const uint32_t toff = block_exscan(mycnt, t.wsum);
-        if (threadIdx.x < D) {
-          t.cnt[threadIdx.x] = toff;
-          t.gbase[threadIdx.x] = mycnt ? atomicAdd(&cw[threadIdx.x], mycnt) : 0u; // reserve the run in the bucket list
-        }
-      } else { // 2048 bins (lb = 11, window size 22): bins 2 tid and 2 tid + 1
-        const uint32_t k0 = 2 * threadIdx.x;
-        const uint32_t m0 = t.cnt[k0], m1 = t.cnt[k0 + 1];
-        const uint32_t toff = block_exscan(m0 + m1, t.wsum);
-        t.cnt[k0] = toff;
-        t.cnt[k0 + 1] = toff + m0;
-        t.gbase[k0] = m0 ? atomicAdd(&cw[k0], m0) : 0u;
-        t.gbase[k0 + 1] = m1 ? atomicAdd(&cw[k0 + 1], m1) : 0u;
+      {
+        uint32_t mysum = 0;
+        for (uint32_t r = 0; r < R; r++)
+          if (k0 + r < D) mysum += t.cnt[k0 + r];
+        uint32_t toff = block_exscan(mysum, t.wsum);
+        for (uint32_t r = 0; r < R; r++)
+          if (k0 + r < D) {
+            const uint32_t c1 = t.cnt[k0 + r];
+            t.cnt[k0 + r] = toff;
+            t.gbase[k0 + r] = c1 ? atomicAdd(&cw[k0 + r], c1) : 0u; // reserve the run in the bucket list
+            toff += c1;
+          }
       }
       __syncthreads();
 #pragma unroll
@@ -631,8 +669,8 @@ namespace icicle_hip {
         cur[it] = nxt[it];
         asm volatile("" : "+v"(cur[it]));
       }
-      const uint32_t ntile = min(r1 - tile0, SORT_TS);
-      for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += blockDim.x) {
+      const uint32_t ntile = min(r1 - tile0, TS);
+      for (uint32_t sidx = threadIdx.x; sidx < ntile; sidx += TPB) {
         const uint32_t bin = t.sdest[sidx];
         dst[t.gbase[bin] + (sidx - t.cnt[bin])] = t.stage[sidx];
       }
@@ -690,7 +728,13 @@ namespace icicle_hip {
     const uint32_t q = (uint32_t)(((uint64_t)min(cnt, seg) * 256u) / seg); // 0..256
     return 256u - q;                                                       // heavy first
   }
-  static __global__ __launch_bounds__(1024) void k_bsize_count(const uint32_t* __restrict__ count, uint32_t* __restrict__ table, size_t nbk, uint32_t seg, size_t bk0)
+  // (mixed-width plans: the narrow windows [0, n_lo) use the first nb / 2 buckets of their slot; the other half is not a
+  //  bucket -- it gets no thread of k_accumulate and nothing reads it. `used_bucket` on a global bucket id.)
+  __device__ __forceinline__ bool used_bucket(size_t bucket, uint32_t nb, uint32_t n_lo)
+  {
+    return n_lo == 0 || bucket / nb >= n_lo || (bucket & (nb - 1)) < nb / 2;
+  }
+  static __global__ __launch_bounds__(1024) void k_bsize_count(const uint32_t* __restrict__ count, uint32_t* __restrict__ table, size_t nbk, uint32_t seg, size_t bk0, uint32_t nb, uint32_t n_lo)
   {
     __shared__ uint32_t hist[SZ_BINS];
     for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
@@ -700,13 +744,13 @@ namespace icicle_hip {
 #pragma unroll
     for (int it = 0; it < 16; it++) {
       const size_t b = base + it * 1024 + threadIdx.x;
-      if (b < nbk) atomicAdd(&hist[size_class(count[bk0 + b], seg)], 1u);
+      if (b < nbk && used_bucket(bk0 + b, nb, n_lo)) atomicAdd(&hist[size_class(count[bk0 + b], seg)], 1u);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
       table[(size_t)k * gridDim.x + blockIdx.x] = hist[k];
   }
-  static __global__ __launch_bounds__(1024) void k_bsize_scatter(const uint32_t* __restrict__ count, const uint32_t* __restrict__ table_off, uint32_t* __restrict__ perm, size_t nbk, uint32_t seg, size_t bk0)
+  static __global__ __launch_bounds__(1024) void k_bsize_scatter(const uint32_t* __restrict__ count, const uint32_t* __restrict__ table_off, uint32_t* __restrict__ perm, size_t nbk, uint32_t seg, size_t bk0, uint32_t nb, uint32_t n_lo)
   {
     __shared__ uint32_t cursor[SZ_BINS];
     for (uint32_t k = threadIdx.x; k < SZ_BINS; k += blockDim.x)
@@ -716,17 +760,21 @@ namespace icicle_hip {
 #pragma unroll
     for (int it = 0; it < 16; it++) {
       const size_t b = base + it * 1024 + threadIdx.x;
-      if (b < nbk) perm[atomicAdd(&cursor[size_class(count[bk0 + b], seg)], 1u)] = (uint32_t)(bk0 + b);
+      if (b < nbk && used_bucket(bk0 + b, nb, n_lo)) perm[atomicAdd(&cursor[size_class(count[bk0 + b], seg)], 1u)] = (uint32_t)(bk0 + b);
     }
   }
 
-  template <class C, int MINW>
+  // PAD: the kernel claims 176 VGPRs instead of the 155 it needs, so that exactly TWO of its waves fit a SIMD (3 x 176 > 512)
+  // and 160 registers per lane stay free for a co-resident wave of the next window group's sort (pipelined schedule). Two
+  // waves per SIMD run this kernel as fast as three (60.14 vs 60.10 ms, profiles/r03_notes.md): nothing is left to hide.
+  template <class C, int MINW, bool PAD = false>
   __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, const uint32_t* __restrict__ perm, uint32_t ovf_cap, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
   {
     // bases_stride: words between the base arrays of consecutive MSMs of a batch (0 = shared bases)
     // perm: thread t < nbk accumulates bucket perm[t] (size-balanced order)
     using E = EC<C>;
     constexpr int PW = 2 * E::N32; // words per affine point
+    if constexpr (PAD) asm volatile("" ::: "v175");
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t bucket;
     uint32_t start;
@@ -887,14 +935,27 @@ namespace icicle_hip {
   }
 
   template <class C>
-  __global__ __launch_bounds__(64) void k_reduce_wave(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ chunkV, typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum_direct, uint32_t nb, uint32_t m, uint32_t seg_lo, uint32_t nsegr)
+  __global__ __launch_bounds__(64) void k_reduce_wave(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ chunkV, typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum_direct, uint32_t nb_stride, uint32_t nb_wide, uint32_t m, uint32_t seg_lo, uint32_t nsegr, uint32_t nlo_w, uint32_t nseg_lo)
   {
+    // nb_stride: buckets between the slots of consecutive windows. The first nlo_w windows of the launch are the NARROW
+    // windows of a mixed-width plan: they use the first nb_wide / 2 buckets of their slot = nseg_lo chunks; the others use
+    // nb_wide buckets, chunks [seg_lo, seg_lo + nsegr). One launch for both kinds: a window set of ~1800 waves fits the chip
+    // at once, two launches of the same waves ran one after the other (5.5 against 3.4 ms at 2^26). Chunk outputs of window
+    // wp start at wp * nsegr for both kinds (nseg_lo <= nsegr).
     using E = EC<C>;
     const int lane = threadIdx.x;
-    const size_t wp = blockIdx.x / nsegr;
-    const uint32_t ch = seg_lo + blockIdx.x % nsegr;
+    const uint32_t nlo_blocks = nlo_w * nseg_lo;
+    size_t wp;
+    uint32_t ch, nb, lch;
+    if (blockIdx.x < nlo_blocks) {
+      wp = blockIdx.x / nseg_lo, lch = blockIdx.x % nseg_lo, ch = lch, nb = nb_wide / 2;
+    } else {
+      const uint32_t r = blockIdx.x - nlo_blocks;
+      wp = nlo_w + r / nsegr, lch = r % nsegr, ch = seg_lo + lch, nb = nb_wide;
+    }
+    const size_t oi = wp * nsegr + lch;
     const uint32_t k0 = ch * 64u * m;
-    const typename E::Proj* b = buckets + wp * nb;
+    const typename E::Proj* b = buckets + wp * nb_stride;
     typename E::Proj line = E::proj_identity(), tri0 = E::proj_identity();
     for (int i = (int)m - 1; i >= 0; i--) {
       const uint32_t k = k0 + 64u * (uint32_t)i + (uint32_t)lane;
@@ -909,10 +970,10 @@ namespace icicle_hip {
     const typename E::Proj v = wave_sum<C>(E::add(x, tri0), lane);
     if (lane == 0) {
       if (winsum_direct) { // the chunk is the whole window (small windows, batches of small MSMs): S = V + T
-        winsum_direct[blockIdx.x] = E::add(v, suf);
+        winsum_direct[oi] = E::add(v, suf);
       } else {
-        chunkV[blockIdx.x] = v;
-        chunkT[blockIdx.x] = suf;
+        chunkV[oi] = v;
+        chunkT[oi] = suf;
       }
     }
   }
@@ -920,16 +981,18 @@ namespace icicle_hip {
   // per window: S = sum_c (V_c + T_c) + chunk * sum_c c * T_c over the nsegr <= blockDim chunks of this device's slice
   // (c = global chunk index = seg_lo + local index)
   template <class C>
-  __global__ __launch_bounds__(ReduceWindowLanes<C>::value) void k_reduce_window(const typename EC<C>::Proj* __restrict__ chunkV, const typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum, uint32_t nsegr, uint32_t seg_lo, uint32_t log_chunk)
+  __global__ __launch_bounds__(ReduceWindowLanes<C>::value) void k_reduce_window(const typename EC<C>::Proj* __restrict__ chunkV, const typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum, uint32_t nsegr_wide, uint32_t seg_lo_wide, uint32_t log_chunk, uint32_t nlo_w, uint32_t nseg_lo)
   {
+    // (windows [0, nlo_w) of the launch: narrow windows of a mixed-width plan, nseg_lo chunks from 0; chunk rows are nsegr_wide apart)
+    const uint32_t nsegr = blockIdx.x < nlo_w ? nseg_lo : nsegr_wide, seg_lo = blockIdx.x < nlo_w ? 0u : seg_lo_wide;
     using E = EC<C>;
     constexpr int RWL = ReduceWindowLanes<C>::value;
     __shared__ typename E::Proj sh[RWL];
     const int NW = blockDim.x / 64; // launched with the power of two >= nsegr (64 .. RWL threads)
     const int wp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool have = (uint32_t)tid < nsegr;
-    const typename E::Proj t = have ? chunkT[(size_t)wp * nsegr + tid] : E::proj_identity();
-    typename E::Proj u = have ? E::add(chunkV[(size_t)wp * nsegr + tid], t) : E::proj_identity();
+    const typename E::Proj t = have ? chunkT[(size_t)wp * nsegr_wide + tid] : E::proj_identity();
+    typename E::Proj u = have ? E::add(chunkV[(size_t)wp * nsegr_wide + tid], t) : E::proj_identity();
     // exclusive suffix sum of T over the block
     const typename E::Proj suf = wave_suffix_sum<C>(t, lane);
     if (lane == 0) sh[wave] = suf; // wave totals
@@ -981,8 +1044,9 @@ namespace icicle_hip {
   // by their full 2^(c*w). With `partial` the block's sum goes to partial[(slot0 + bw) * nmsm + b] in the kernels' own
   // representation (several blocks per MSM, or a window group of the pipelined schedule); without, to result[b].
   template <class C>
-  __global__ __launch_bounds__(64) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, int c, int w0, int nw, typename EC<C>::Proj* __restrict__ partial, int slot0, int nmsm)
+  __global__ __launch_bounds__(64) void k_final(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, WinWidths ww, int w0, int nw, typename EC<C>::Proj* __restrict__ partial, int slot0, int nmsm)
   {
+    const int c = ww.c;
     using E = EC<C>;
     __shared__ typename E::Proj sh[FINAL_WINDOWS_PER_BLOCK];
     // four lanes per window: the doubling chain 2^(c*w) * S_w is the latency floor of the whole MSM, and a quad
@@ -998,7 +1062,9 @@ namespace icicle_hip {
       v = winsum[w];
       if (wfirst + w > 0) { // Jacobian doubling chain (ec.hpp), 2M + 5S per step
         typename E::Jac j = E::to_jac(v);
-        for (int i = 0; i < (wfirst + w) * c; i++) // the same trip count in all four lanes of a quad
+        const int wg = wfirst + w; // bit offset of the window = sum of the widths below it
+        const int nd = wg < ww.n_lo ? wg * (c - 1) : ww.n_lo * (c - 1) + (wg - ww.n_lo) * c;
+        for (int i = 0; i < nd; i++) // the same trip count in all four lanes of a quad
           j = E::dbl_jac_quad(j, role);
         v = E::from_jac(j);
       }
@@ -1249,7 +1315,14 @@ namespace icicle_hip {
     if (n > 0 && (!scalars_v || !bases_v)) return ICICLE_INVALID_POINTER;
     ICICLE_TRY(bind_current_device());
     hipStream_t st = (hipStream_t)cfg->stream;
-    const MsmPlan pl = make_plan(std::max(n, 1), C::fr::NBITS, *cfg);
+    int force_windows = hook ? -1 : 0; // (a bucket exchange adds bucket arrays of several calls element-wise: uniform widths)
+    if (!hook && cfg->ext) force_windows = std::max(0, reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_msm_windows", 0));
+    {
+      static const int env_w = getenv("ICICLE_HIP_MSM_WINDOWS") ? atoi(getenv("ICICLE_HIP_MSM_WINDOWS")) : 0; // A/B: -1 = uniform only
+      if (force_windows == 0 && env_w != 0) force_windows = env_w;
+    }
+    const MsmPlan pl = make_plan(std::max(n, 1), C::fr::NBITS, *cfg, force_windows);
+    const WinWidths ww{pl.c, pl.n_lo, pl.negate};
     const int pf = pl.pf;
     if ((long long)n * pf >= (1ll << 31)) return ICICLE_INVALID_ARGUMENT;
     const bool shared = cfg->are_points_shared_in_batch || batch == 1;
@@ -1394,11 +1467,15 @@ namespace icicle_hip {
 
     const size_t ldsA = tile_lds_bytes(1u << sp.hb) + ((size_t)4 << sp.hb);
     const size_t ldsB = tile_lds_bytes(1u << sp.lb) + ((size_t)sp.nblk + 1) * 4 + (SORT_TS / 64) * 4;
+    constexpr int CO_TPB = 256; // block size of the co-resident sort (window groups, below)
+    constexpr uint32_t CO_TS = CO_TPB * SORT_EPT;
+    const size_t ldsA_co = tile_lds_bytes(1u << sp.hb, CO_TS) + ((size_t)4 << sp.hb);
+    const size_t ldsB_co = tile_lds_bytes(1u << sp.lb, CO_TS) + ((size_t)sp.nblk + 1) * 4 + (CO_TS / 64) * 4;
     if (ldsA > 156 * 1024 || ldsB > 156 * 1024) return ICICLE_INVALID_ARGUMENT;
-    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_a_scatter<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
     HIP_TRY(hipFuncSetAttribute((const void*)k_b_count, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
-    HIP_TRY(hipFuncSetAttribute((const void*)k_b_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipFuncSetAttribute((const void*)k_b_scatter<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), ICICLE_INVALID_ARGUMENT);
 
     uint32_t* dig = d_dig.as<uint32_t>();
     uint32_t* cntA = d_cntA.as<uint32_t>();
@@ -1429,10 +1506,10 @@ namespace icicle_hip {
       // digits + pass-A histogram in one pass over the scalars, when there are enough chunks to fill the chip
       // (a block walks a whole chunk; with few chunks the thread-per-scalar k_digits + k_a_count pair is faster)
       if (lds_dc <= 64 * 1024 && bb <= 65535 && (size_t)sp.nblk * bb >= 512) {
-        k_digits_count<C><<<dim3(sp.nblk, (unsigned)bb), 1024, lds_dc, st>>>(sc, dig, cntA, n, pl.c, pl.nwin, wpf, sp, cfg->are_scalars_montgomery_form, pl.bits);
+        k_digits_count<C><<<dim3(sp.nblk, (unsigned)bb), 1024, lds_dc, st>>>(sc, dig, cntA, n, ww, pl.nwin, wpf, sp, cfg->are_scalars_montgomery_form, pl.bits);
         LAUNCH_CHECK("k_digits_count", st);
       } else {
-        k_digits<C><<<(unsigned)((nscal + 255) / 256), 256, 0, st>>>(sc, dig, n, nscal, pl.c, pl.nwin, cfg->are_scalars_montgomery_form, pl.bits);
+        k_digits<C><<<(unsigned)((nscal + 255) / 256), 256, 0, st>>>(sc, dig, n, nscal, ww, pl.nwin, cfg->are_scalars_montgomery_form, pl.bits);
         LAUNCH_CHECK("k_digits", st);
         k_a_count<<<dim3(sp.nblk, (unsigned)tw), 1024, ((size_t)4 << sp.hb), st>>>(dig, cntA, n, pl.nwin, wpf, pf, sp);
         LAUNCH_CHECK("k_a_count", st);
@@ -1501,13 +1578,20 @@ namespace icicle_hip {
       }
 
       // ---- phase 1 of a group: bucket lists (pass-A scatter, pass B, overflow plan, size-balanced order)
+      // groups behind the first are sorted WHILE the group before them is accumulated: small blocks that fit beside the
+      // padded k_accumulate (two waves per SIMD). Only the 9-limb G1 curves leave the registers for that.
+      constexpr bool CAN_CORESIDE = !(sizeof(typename E::XYZZ) > 256) && E::F::N <= 9;
+      static const bool co_env = !(getenv("ICICLE_HIP_MSM_CORESIDENT") && atoi(getenv("ICICLE_HIP_MSM_CORESIDENT")) == 0);
+      const bool co_ok = CAN_CORESIDE && co_env && NG > 1 && ldsA_co <= 60 * 1024 && ldsB_co <= 60 * 1024;
       auto sort_group = [&](int g, hipStream_t sq) -> icicle_error_t {
+        const bool coresident = co_ok && g > 0;
         const int w0 = glo[g], nw = ghi[g] - glo[g];
         const size_t bk0 = (size_t)w0 * nb, nbk_g = (size_t)nw * nb;
         const uint32_t p0 = (uint32_t)((size_t)w0 << sp.hb), np_g = (uint32_t)((size_t)nw << sp.hb);
         uint32_t* scan_g = NG > 1 ? d_gscan.as<uint32_t>() + (size_t)g * scan_words : d_scansum.as<uint32_t>();
         if (single_level) {
-          k_a_scatter<true><<<dim3(sp.nblk, (unsigned)nw), 1024, ldsA, sq>>>(dig, offA, sorted, n, pl.nwin, wpf, pf, sp, cap, w0);
+          if (coresident) k_a_scatter<true, CO_TPB><<<dim3(sp.nblk, (unsigned)nw), CO_TPB, ldsA_co, sq>>>(dig, offA, sorted, n, pl.nwin, wpf, pf, sp, cap, w0);
+          else k_a_scatter<true, 1024><<<dim3(sp.nblk, (unsigned)nw), 1024, ldsA, sq>>>(dig, offA, sorted, n, pl.nwin, wpf, pf, sp, cap, w0);
           LAUNCH_CHECK("k_a_scatter<final>", sq);
           k_tables_from_a<<<(unsigned)((nbk_g + 255) / 256), 256, 0, sq>>>(offA, count, offs, nbk_g, nb, sp.nblk, gparts * sp.nblk, bk0);
           LAUNCH_CHECK("k_tables_from_a", sq);
@@ -1516,7 +1600,8 @@ namespace icicle_hip {
           uint32_t* bstart = d_bstart.as<uint32_t>() + p0 + (NG - 1 - g); // nparts_g + 1 entries per group, groups in window order
           const size_t elems = (size_t)bb * n * pf * (size_t)nw + 1;
           const uint32_t nblkB = (uint32_t)std::min<size_t>(np_g + (elems >> CHUNKB_LOG) + 2, maxblkB);
-          k_a_scatter<false><<<dim3(sp.nblk, (unsigned)nw), 1024, ldsA, sq>>>(dig, offA, partA, n, pl.nwin, wpf, pf, sp, cap, w0);
+          if (coresident) k_a_scatter<false, CO_TPB><<<dim3(sp.nblk, (unsigned)nw), CO_TPB, ldsA_co, sq>>>(dig, offA, partA, n, pl.nwin, wpf, pf, sp, cap, w0);
+          else k_a_scatter<false, 1024><<<dim3(sp.nblk, (unsigned)nw), 1024, ldsA, sq>>>(dig, offA, partA, n, pl.nwin, wpf, pf, sp, cap, w0);
           LAUNCH_CHECK("k_a_scatter", sq);
           k_b_plan<<<1, 1024, 0, sq>>>(offA, bstart, np_g, (int)tw, sp.hb, sp.nblk, p0);
           LAUNCH_CHECK("k_b_plan", sq);
@@ -1529,7 +1614,8 @@ namespace icicle_hip {
             k_scan_apply<<<dim3(nch, (unsigned)nw), 1024, 0, sq>>>(count + bk0, scan_g, offs + bk0, d_cursor.as<uint32_t>() + bk0, nullptr, nb);
           }
           LAUNCH_CHECK("k_scan_buckets", sq);
-          k_b_scatter<<<nblkB, 1024, ldsB, sq>>>(partA, offA, bstart, d_cursor.as<uint32_t>(), sorted, np_g, (int)tw, pf, sp, cap, nb, p0);
+          if (coresident) k_b_scatter<CO_TPB><<<nblkB, CO_TPB, ldsB_co, sq>>>(partA, offA, bstart, d_cursor.as<uint32_t>(), sorted, np_g, (int)tw, pf, sp, cap, nb, p0);
+          else k_b_scatter<1024><<<nblkB, 1024, ldsB, sq>>>(partA, offA, bstart, d_cursor.as<uint32_t>(), sorted, np_g, (int)tw, pf, sp, cap, nb, p0);
           LAUNCH_CHECK("k_b_scatter", sq);
         }
         uint32_t* ovfcnt = d_ovfcnt.as<uint32_t>() + 4 * g;
@@ -1542,10 +1628,10 @@ namespace icicle_hip {
           const uint32_t m = szblk * SZ_BINS, nch = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
           uint32_t* sztab = d_sztab.as<uint32_t>() + sz0;
           uint32_t* szoff = d_szoff.as<uint32_t>() + sz0;
-          k_bsize_count<<<szblk, 1024, 0, sq>>>(count, sztab, nbk_g, pl.seg, bk0);
+          k_bsize_count<<<szblk, 1024, 0, sq>>>(count, sztab, nbk_g, pl.seg, bk0, nb, (uint32_t)pl.n_lo);
           k_scan_sums<<<dim3(nch, 1), 1024, 0, sq>>>(sztab, scan_g, m);
           k_scan_apply<<<dim3(nch, 1), 1024, 0, sq>>>(sztab, scan_g, szoff, nullptr, nullptr, m);
-          k_bsize_scatter<<<szblk, 1024, 0, sq>>>(count, szoff, d_perm.as<uint32_t>() + bk0, nbk_g, pl.seg, bk0);
+          k_bsize_scatter<<<szblk, 1024, 0, sq>>>(count, szoff, d_perm.as<uint32_t>() + bk0, nbk_g, pl.seg, bk0, nb, (uint32_t)pl.n_lo);
           LAUNCH_CHECK("k_bsize_scatter", sq);
         }
         return ICICLE_SUCCESS;
@@ -1566,10 +1652,13 @@ namespace icicle_hip {
           constexpr bool BIGPT = sizeof(typename E::XYZZ) > 256; // G2
           static const int minw = getenv("ICICLE_HIP_MSM_ACC_WAVES") ? atoi(getenv("ICICLE_HIP_MSM_ACC_WAVES"))
                                                                      : (BIGPT ? (sizeof(typename E::XYZZ) <= 288 ? 2 : 1) : (E::F::N <= 9 ? 3 : 2));
-          const size_t nthreads_acc = nbk_g + ocap;
+          // threads = the group's buckets in use (perm[] lists exactly those) + its overflow slots
+          const int nlo_g = std::max(0, std::min(pl.n_lo, w0 + nw) - w0); // (bb == 1 whenever n_lo > 0)
+          const size_t nbk_used = nbk_g - (size_t)nlo_g * (nb / 2);
+          const size_t nthreads_acc = nbk_used + ocap;
           const unsigned gridn = (unsigned)((nthreads_acc + 127) / 128);
           const size_t bstride = shared ? 0 : npts_one * PW;
-#define ACC_ARGS acc_bases, sorted, count, offs, buckets, ovfpart, ovf, ovfcnt, d_perm.as<uint32_t>() + bk0, ocap, nb, nbk_g, cap, pl.seg, wpf, bstride
+#define ACC_ARGS acc_bases, sorted, count, offs, buckets, ovfpart, ovf, ovfcnt, d_perm.as<uint32_t>() + bk0, ocap, nb, nbk_used, cap, pl.seg, wpf, bstride
           if constexpr (BIGPT) {
             if constexpr (sizeof(typename E::XYZZ) <= 288) {
               if (minw >= 2) k_accumulate<C, 2><<<gridn, 128, 0, sq>>>(ACC_ARGS);
@@ -1578,7 +1667,9 @@ namespace icicle_hip {
               k_accumulate<C, 1><<<gridn, 128, 0, sq>>>(ACC_ARGS);
             }
           } else {
-            if (minw == 2) k_accumulate<C, 2><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+            if (co_ok) {
+              if constexpr (CAN_CORESIDE) k_accumulate<C, 2, true><<<gridn, 128, 0, sq>>>(ACC_ARGS);
+            } else if (minw == 2) k_accumulate<C, 2><<<gridn, 128, 0, sq>>>(ACC_ARGS);
             else if (minw == 4) k_accumulate<C, 4><<<gridn, 128, 0, sq>>>(ACC_ARGS);
             else if (minw == 1) k_accumulate<C, 1><<<gridn, 128, 0, sq>>>(ACC_ARGS);
             else k_accumulate<C, 3><<<gridn, 128, 0, sq>>>(ACC_ARGS);
@@ -1595,22 +1686,30 @@ namespace icicle_hip {
       // ---- phase 3 of a group: bucket reduction of its windows, then their share of the window combine
       auto reduce_group = [&](int g, hipStream_t sq, uint32_t seg_lo, uint32_t nsegr) -> icicle_error_t {
         const int w0 = glo[g], nw = ghi[g] - glo[g];
+        // windows [w0, split) of the group are the narrow windows of a mixed-width plan (half the buckets, nseg_lo chunks), the
+        // rest wide; one launch of each kernel serves both (a uniform plan has n_lo = 0: no narrow windows). (bb == 1 whenever n_lo > 0)
+        const int split = std::min(std::max(pl.n_lo, w0), w0 + nw);
+        const uint32_t nlo_w = (uint32_t)(split - w0);
+        const uint32_t nseg_lo = std::max<uint32_t>(1, (nb / 2) / m);
         const bool direct = (nseg == 1 && nsegr == 1 && seg_lo == 0);
         typename E::Proj* win = d_win.as<typename E::Proj>() + w0;
-        if ((size_t)nw * nsegr) {
-          k_reduce_wave<C><<<(unsigned)((size_t)nw * nsegr), 64, 0, sq>>>(buckets + (size_t)w0 * nb, chunkV + (size_t)w0 * nseg, chunkT + (size_t)w0 * nseg, direct ? win : nullptr, nb, mrow, seg_lo, nsegr);
+        typename E::Proj* cV = chunkV + (size_t)w0 * nseg;
+        typename E::Proj* cT = chunkT + (size_t)w0 * nseg;
+        const size_t nblocks = (size_t)nlo_w * nseg_lo + (size_t)(nw - nlo_w) * nsegr;
+        if (nblocks) {
+          k_reduce_wave<C><<<(unsigned)nblocks, 64, 0, sq>>>(buckets + (size_t)w0 * nb, cV, cT, direct ? win : nullptr, nb, nb, mrow, seg_lo, nsegr, nlo_w, nseg_lo);
           LAUNCH_CHECK("k_reduce_wave", sq);
         }
         if (!direct) {
-          unsigned rthreads = 64; // power of two (LDS tree), >= nsegr
-          while (rthreads < nsegr && rthreads < RWL)
+          unsigned rthreads = 64; // power of two (LDS tree), >= the chunks of a window
+          while (rthreads < std::max(nsegr, nlo_w ? nseg_lo : 0u) && rthreads < RWL)
             rthreads <<= 1;
-          k_reduce_window<C><<<(unsigned)nw, rthreads, 0, sq>>>(chunkV + (size_t)w0 * nseg, chunkT + (size_t)w0 * nseg, win, nsegr, seg_lo, log_chunk);
+          k_reduce_window<C><<<(unsigned)nw, rthreads, 0, sq>>>(cV, cT, win, nsegr, seg_lo, log_chunk, nlo_w, nseg_lo);
           LAUNCH_CHECK("k_reduce_window", sq);
         }
         if (NG > 1) { // (bb == 1) this group's windows, scaled, into its partial slots
           const int nbw = (nw + FINAL_WINDOWS_PER_BLOCK - 1) / FINAL_WINDOWS_PER_BLOCK;
-          k_final<C><<<dim3((unsigned)nbw, 1), 64, 0, sq>>>(d_win.as<typename E::Proj>(), nullptr, wpf, pl.c, w0, nw, d_part.as<typename E::Proj>(), part_slot[g], 1);
+          k_final<C><<<dim3((unsigned)nbw, 1), 64, 0, sq>>>(d_win.as<typename E::Proj>(), nullptr, wpf, ww, w0, nw, d_part.as<typename E::Proj>(), part_slot[g], 1);
           LAUNCH_CHECK("k_final(group)", sq);
         }
         return ICICLE_SUCCESS;
@@ -1630,7 +1729,7 @@ namespace icicle_hip {
         ICICLE_TRY(reduce_group(0, st, seg_lo, nsegr));
         {
           const int nbw = (wpf + FINAL_WINDOWS_PER_BLOCK - 1) / FINAL_WINDOWS_PER_BLOCK;
-          k_final<C><<<dim3((unsigned)nbw, (unsigned)bb), 64, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, pl.c, 0, wpf, nbw > 1 ? d_part.as<typename E::Proj>() : nullptr, 0, bb);
+          k_final<C><<<dim3((unsigned)nbw, (unsigned)bb), 64, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, ww, 0, wpf, nbw > 1 ? d_part.as<typename E::Proj>() : nullptr, 0, bb);
           LAUNCH_CHECK("k_final", st);
           if (nbw > 1) { // more than 16 windows: one single-wave block per 16 of them, then the sum of the partials
             k_final_combine<C><<<(unsigned)((bb + 63) / 64), 64, 0, st>>>(d_part.as<typename E::Proj>(), d_res + (size_t)b0 * RW, nbw, bb);
@@ -1648,6 +1747,14 @@ namespace icicle_hip {
         }
         ICICLE_TRY(sort_group(0, st));
         KernelTimer::end(2, st); // (the exposed part of the sort)
+        if (co_ok) {
+          // the co-resident sort of group 1 starts WITH the accumulation of group 0, not beside the stand-alone sort of
+          // group 0 (where it would only take bandwidth from it and delay the first accumulation)
+          hipEvent_t ev_s0 = ring_event();
+          if (!ev_s0) return ICICLE_ALLOCATION_FAILED;
+          HIP_TRY(hipEventRecord(ev_s0, st), ICICLE_SYNCHRONIZATION_FAILED);
+          HIP_TRY(hipStreamWaitEvent(s_sort, ev_s0, 0), ICICLE_SYNCHRONIZATION_FAILED);
+        }
         for (int g = 1; g < NG; g++) {
           ICICLE_TRY(sort_group(g, s_sort));
           HIP_TRY(hipEventRecord(ev_sorted[g], s_sort), ICICLE_SYNCHRONIZATION_FAILED);

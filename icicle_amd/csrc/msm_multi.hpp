@@ -192,7 +192,7 @@ namespace icicle_hip {
     icicle_msm_config_t sub = *cfg;
     sub.ext = nullptr;
     {
-      const MsmPlan pl = make_plan(std::max(pf > 1 ? n : (n + G - 1) / G, 1), C::fr::NBITS, *cfg);
+      const MsmPlan pl = make_plan(std::max(pf > 1 ? n : (n + G - 1) / G, 1), C::fr::NBITS, *cfg, -1);
       sub.c = pl.c;
       // the bucket exchange needs a whole batch in one launch group of msm_run_single; decided here, from the shape
       // alone, so that every device takes the same branch (fallback: partial-sum exchange)

@@ -34,15 +34,28 @@ namespace icicle_hip {
   #endif
   struct MsmPlan {
     int bits;    // scalar bits considered
-    int c;       // window bits
-    int nwin;    // total windows W = ceil((bits+1)/c)
+    int c;       // window bits (of the widest windows)
+    int nwin;    // total windows W = ceil((bits+1)/c)   [mixed plan: chosen W, sum of the widths = bits]
     int pf;      // precompute factor
     int wpf;     // windows per precomputed base = target windows actually accumulated
-    uint32_t nb; // buckets per window = 2^(c-1)
+    uint32_t nb; // buckets per window = 2^(c-1) (array stride of every per-bucket table)
     uint32_t seg; // bucket-accumulation segment size: a bucket with more points is split across threads
+    // Mixed window widths (round 5): windows [0, n_lo) are c - 1 bits wide and use the first nb / 2 buckets of their slot,
+    // windows [n_lo, nwin) are c bits wide; n_lo = 0 is the uniform plan of rounds 1-4. With `negate` a scalar whose top bit
+    // is set is replaced by r - s and its point negated (the reference's own trick, cpu_msm.hpp:276-277), so scalars stay
+    // below 2^(bits-1) and the widths only have to add up to `bits`: 254 bits = 10 x 21 + 2 x 22, twelve windows instead of
+    // the thirteen of c = 20 (-7.7 % mixed additions) for 2.15 x the buckets (uniform c = 22: 3.7 x, measured a wash).
+    int n_lo = 0;
+    bool negate = false;
+    int width(int w) const { return w < n_lo ? c - 1 : c; }
+    int offset(int w) const { return w < n_lo ? w * (c - 1) : n_lo * (c - 1) + (w - n_lo) * c; } // bit offset of window w
+    uint32_t nb_of(int w) const { return w < n_lo ? nb / 2 : nb; }
+    size_t buckets_used() const { return (size_t)n_lo * (nb / 2) + (size_t)(nwin - n_lo) * nb; }
   };
 
-  static MsmPlan make_plan(int n, int scalar_bits, const icicle_msm_config_t& cfg)
+  // force_windows: 0 = the cost model decides; W > 0 = W windows whose widths add up to the scalar bits (tests, A/B:
+  // MSMConfig.ext "hip_msm_windows"); -1 = uniform widths only (callers that fix config.c for several sub-calls)
+  static MsmPlan make_plan(int n, int scalar_bits, const icicle_msm_config_t& cfg, int force_windows = 0)
   {
     MsmPlan p;
     p.bits = (cfg.bitsize > 0 && cfg.bitsize < scalar_bits) ? cfg.bitsize : scalar_bits;
@@ -104,12 +117,39 @@ namespace icicle_hip {
     p.nwin = (p.bits + 1 + c - 1) / c;
     p.wpf = (p.nwin + p.pf - 1) / p.pf;
     p.nb = 1u << (c - 1);
+    // ---- mixed widths: W windows, the top x of them one bit wider, widths adding up to the scalar bits exactly. Needs the
+    // negation trick, i.e. full-width scalars (a chopped scalar has no top bit to test, cpu_msm.hpp:276), no base table (its
+    // doubling shift is c * wpf) and the two-level sort (c - 1 >= 12). The cost model compares it with the best uniform plan
+    // at the same weights: it wins from ~2^25 terms up, where a window of mixed additions outweighs twice the buckets.
+    if (cfg.c <= 0 && p.pf == 1 && p.bits == scalar_bits && std::max(1, cfg.batch_size) == 1 && (force_windows > 0 || (force_windows == 0 && n >= (1 << 23)))) {
+      auto uniform_cost = [&](int w, double nbk) {
+        const double occupancy = std::max(1.0, 2.5 * 65536.0 / nbk);
+        return (double)w * n * occupancy + 4.0 * nbk;
+      };
+      int bestW = 0;
+      double best = force_windows > 0 ? 1e300 : 0.995 * uniform_cost(p.nwin, (double)p.nwin * p.nb);
+      for (int W = (force_windows > 0 ? force_windows : 2); W <= (force_windows > 0 ? force_windows : 40); W++) {
+        const int clo = p.bits / W, x = p.bits - clo * W; // x windows of clo + 1 bits, W - x of clo bits
+        if (x == 0 || clo + 1 > 22 || clo < (force_windows > 0 ? 2 : 12)) continue;
+        const double nbk = (double)(W - x) * (double)(1u << (clo - 1)) + (double)x * (double)(1u << clo);
+        const double cost = force_windows > 0 ? 0.0 : uniform_cost(W, nbk);
+        if (cost < best) best = cost, bestW = W;
+      }
+      if (bestW > 0) {
+        const int clo = p.bits / bestW, x = p.bits - clo * bestW;
+        p.c = clo + 1;
+        p.nwin = p.wpf = bestW;
+        p.n_lo = bestW - x;
+        p.negate = true;
+        p.nb = 1u << (p.c - 1);
+      }
+    }
     {
       // points per bucket: the nwin windows of a scalar land in wpf bucket sets. (Rounds 1-3 had one more factor pf here: with
       // a base table the segments came out pf times too long, and the handful of buckets that take the whole short top window
       // -- n / 2^(top bits - 1) points each -- were walked by a few threads in chains of thousands of additions: pf = 8, c = 19
       // at 2^24 took 49.9 ms against 19.9 ms at c = 20, profiles/r04_precompute_sweep.txt.)
-      const double avg = (double)n * ((double)p.nwin / p.wpf) / (double)p.nb;
+      const double avg = (double)n * ((double)p.nwin / p.wpf) / (double)(p.n_lo > 0 ? p.nb / 2 : p.nb); // (of the narrow windows)
       uint32_t sgm = 64;
       while ((double)sgm < 2.0 * avg)
         sgm <<= 1;

@@ -471,7 +471,12 @@ namespace icicle_hip {
     auto it = streams.find({dev, which});
     if (it != streams.end()) return it->second;
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    // streams 10 / 11 carry the co-resident sort and the early bucket reductions of the pipelined MSM: their small blocks take
+    // a free slot before the next block of the accumulation's huge grid does
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const hipError_t ce = (which == 10 || which == 11) ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (ce != hipSuccess) {
       (void)hipGetLastError();
       return nullptr;
     }

@@ -105,7 +105,14 @@ extern "C" int msm_plan_check(void)
           const int n = 1 << logn;
           const MsmPlan p = make_plan(n, bits, cfg);
           const int tag = ((bits * 100 + logn) * 10 + (batch > 1)) * 10 + pf;
-          if (p.c < 2 || p.c > 21) return tag * 10 + 1;
+          if (p.c < 2 || p.c > (p.n_lo > 0 ? 22 : 21)) return tag * 10 + 1;
+          if (p.n_lo > 0) { // mixed widths: they add up to the scalar bits, narrow windows below wide ones, full-width scalars only
+            if (!p.negate || pf != 1 || batch != 1 || p.bits != bits || p.n_lo >= p.nwin) return tag * 10 + 2;
+            if (p.offset(p.nwin - 1) + p.width(p.nwin - 1) != p.bits || p.nb != (1u << (p.c - 1)) || p.wpf != p.nwin) return tag * 10 + 2;
+            if (logn < 23) return tag * 10 + 3; // never below 2^23 terms
+            continue;
+          }
+          if (p.negate) return tag * 10 + 2;
           if (p.nwin != (p.bits + 1 + p.c - 1) / p.c || p.wpf != (p.nwin + pf - 1) / pf || p.nb != (1u << (p.c - 1))) return tag * 10 + 2;
           if (pf == 1 && p.nwin > 1 && p.bits > 8 && p.bits + 1 - p.c * (p.nwin - 1) <= 3) return tag * 10 + 3; // tiny top window
           if (pf == 1 && batch > 1 && logn <= 17 && p.c > 11) return tag * 10 + 4;

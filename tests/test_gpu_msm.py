@@ -456,3 +456,38 @@ def test_msm_window_size_22_forced(hip, cname):
     sc[: n // 2, 1:] = 0
     sc[: n // 2, 0] = rng.integers(1, 3, size=n // 2)
     _check(hip, cname, sc, bases, refc, c=22)
+
+
+@pytest.mark.parametrize("cname", CURVES)
+@pytest.mark.parametrize("nwin", [12, 13, 17, 23, 31, 40])
+def test_msm_mixed_window_widths(hip, cname, nwin):
+    """Round 5: window widths that add up to the scalar bits exactly (the top x windows one bit wider) with the reference's
+    'negate scalar and point when the top bit is set' trick (cpu_msm.hpp:276-277). The cost model picks such a plan from
+    ~2^25 terms up (BN254 2^26: 10 x 21 + 2 x 22 bits); MSMConfig.ext "hip_msm_windows" forces one at a size the oracle
+    finishes in seconds. Scalars include r - 1, 2^253 +- 1, the all-ones digits and 0 / 1; bases include the identity."""
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(1000 + nwin)
+    n = 5000
+    pts = list(cached_points(C, n))
+    pts[3] = pyref.INF
+    bases = points_to_array(C, pts)
+    vals = rand_scalars(rng, n, C.r)
+    top = C.r.bit_length() - 1
+    edge = [C.r - 1, C.r - 2, (1 << top), (1 << top) - 1, (1 << top) + 1, 0, 1, 2, (1 << (top - 1)), C.r // 2, C.r // 2 + 1, ((1 << top) - 1) // 3]
+    for k, v in enumerate(edge):
+        vals[10 + k] = v % C.r
+    sc = to_words(vals, 8)
+    ext = lib.create_config_extension()
+    lib.config_extension_set_int(ext, b"hip_msm_windows", nwin)
+    try:
+        cfg = hip.MSMConfig.default()
+        cfg.ext = ext
+        got = M.msm(cname, sc, bases, cfg)
+    finally:
+        lib.destroy_config_extension(ext)
+    assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(sc, bases)))
+    assert refc.is_on_curve(got[0])
