@@ -177,6 +177,8 @@ namespace icicle_hip {
   struct RcclCommSet {
     std::vector<void*> comms;
     std::mutex call_mtx;
+    const RcclApi* api = nullptr; // the library the communicators were created by: every collective on them goes through IT
+                                  // (a concurrent icicle_hip_set_collectives_library() must not pair them with another one)
   };
   icicle_error_t rccl_comms_for(const std::vector<int>& devs, RcclCommSet** set);
 

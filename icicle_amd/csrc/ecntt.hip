@@ -166,7 +166,9 @@ namespace icicle_hip {
       }
     }
     FR::to_canonical(k, sc);
-    const typename E::Proj p = T::mul_words_quad(work[t], k, role, tab);
+    // (a quad past the end works on the identity, not on the slot the last live quad is overwriting in place: ADVICE r04)
+    const typename E::Proj pin = live ? work[t] : E::proj_identity();
+    const typename E::Proj p = T::mul_words_quad(pin, k, role, tab);
     if (live && role == 0) work[t] = p;
   }
 
@@ -195,8 +197,8 @@ namespace icicle_hip {
     const uint64_t pos = bf & (half - 1);
     const uint64_t i = ((bf >> q) << (q + 1)) + pos;
     typename E::Proj* base = work + b * lay.n;
-    const typename E::Proj u = base[i];
-    typename E::Proj v = base[i + half];
+    const typename E::Proj u = live ? base[i] : E::proj_identity(); // (dead quads: not the slots the last live quad rewrites in place)
+    typename E::Proj v = live ? base[i + half] : E::proj_identity();
 #ifdef ECNTT_OLD_MUL
     if (pos != 0) {
       const uint64_t max_mask = ((uint64_t)1 << lay.log_max) - 1;
@@ -363,7 +365,7 @@ namespace icicle_hip {
     constexpr size_t PWB = (size_t)3 * E::N32 * 4; // bytes per projective_t
     const size_t bytes = (size_t)n * batch * PWB;
 
-    TempBuf d_in_tmp, d_out_tmp, d_pw, d_work, d_terms, d_next, d_stab; // (d_terms / d_next: the matrix-form stages; alive until the store kernel is queued)
+    TempBuf d_in_tmp, d_out_tmp, d_pw, d_work, d_terms, d_next; // (d_terms / d_next: the matrix-form stages; alive until the store kernel is queued)
     const uint32_t* d_in = (const uint32_t*)input_v;
     uint32_t* d_out = (uint32_t*)output_v;
     if (!cfg->are_inputs_on_device) {
@@ -412,41 +414,42 @@ namespace icicle_hip {
     // per-point factors outside the butterflies (forward coset on the way in; 1/N [and the coset] on the way out): k_ecntt_scale
     const uint64_t scale_quads = ((tot * 4 + 63) / 64) * 16;
     const bool scale_gtab = tot > (uint64_t)(sizeof(Proj) > 120 ? 12288 : 20480); // more points than LDS-resident tables allow in flight
+    // ONE scratch buffer (d_terms) serves the scale tables, the stage tables and the matrix-form terms: they are never alive
+    // at the same time on the stream (rounds 1-4 kept the scale tables next to the stage scratch: 2^20 BLS12-381 points took
+    // 2.4 GB + 1.2 GB for a 151 MB transform). Sized once, for the largest of the three.
+    static const int forced_r = getenv("ICICLE_HIP_ECNTT_RADIX_LOG") ? atoi(getenv("ICICLE_HIP_ECNTT_RADIX_LOG")) : 0;
+    static const uint64_t budget = getenv("ICICLE_HIP_ECNTT_QUADS") ? (uint64_t)atoll(getenv("ICICLE_HIP_ECNTT_QUADS")) : 16384;
+    static const int gtab_mode = getenv("ICICLE_HIP_ECNTT_GTABS") ? atoi(getenv("ICICLE_HIP_ECNTT_GTABS")) : -1; // 0 / 1 force, -1 auto
+    int widths[64];
+    const int nst = ecntt_stage_plan(logn, tot, budget, forced_r, widths);
+    const int rmax = nst ? widths[0] : 1; // (widths are non-increasing)
+    const uint64_t stage_quads = ((tot / 2 * 4 + 63) / 64) * 16; // quads launched per radix-2 stage (incl. the padding of the last block)
+    const bool stage_gtab = gtab_mode >= 0 ? gtab_mode != 0 : tot / 2 > (uint64_t)(sizeof(Proj) > 120 ? 12288 : 20480);
+    {
+      size_t need = 0;
+      if (scale_gtab && (lay.inverse || lay.coset)) need = std::max(need, (size_t)scale_quads * 16 * sizeof(Proj));
+      if (rmax == 1 && stage_gtab) need = std::max(need, (size_t)stage_quads * 16 * sizeof(Proj));
+      if (rmax > 1 && logn > 0) need = std::max(need, (size_t)(tot * ((1ull << rmax) - 1) / 2) * sizeof(Proj)); // n (R - 1) / 2 products of the widest stage
+      if (need) HIP_TRY(d_terms.alloc(need, st), ICICLE_ALLOCATION_FAILED);
+    }
     auto scale = [&](Proj* pts, int mode) -> icicle_error_t {
-      Proj* gt = nullptr;
-      if (scale_gtab) {
-        if (!d_stab.ptr()) HIP_TRY(d_stab.alloc((size_t)scale_quads * 16 * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
-        gt = d_stab.as<Proj>();
-      }
+      Proj* gt = scale_gtab ? d_terms.as<Proj>() : nullptr;
       k_ecntt_scale<C><<<(unsigned)((tot * 4 + 63) / 64), 64, scale_gtab ? 0 : (size_t)16 * 16 * sizeof(Proj), st>>>(pts, d_pw.as<uint32_t>(), ninv_mont, lay, mode, gt);
       LAUNCH_CHECK("k_ecntt_scale", st);
       return ICICLE_SUCCESS;
     };
     if (lay.coset && !lay.inverse) ICICLE_TRY(scale(work, 1));
-    // stage radix: the largest r <= 5 whose n (R - 1) / 2 products still fit one round of quads on the chip (the budget is
-    // a measured knee, not a hard limit: beyond it a stage simply takes a second round); ICICLE_HIP_ECNTT_RADIX_LOG forces r
-    static const int forced_r = getenv("ICICLE_HIP_ECNTT_RADIX_LOG") ? atoi(getenv("ICICLE_HIP_ECNTT_RADIX_LOG")) : 0;
-    static const uint64_t budget = getenv("ICICLE_HIP_ECNTT_QUADS") ? (uint64_t)atoll(getenv("ICICLE_HIP_ECNTT_QUADS")) : 16384;
-    int widths[64];
-    const int nst = ecntt_stage_plan(logn, tot, budget, forced_r, widths);
-    const int rmax = nst ? widths[0] : 1; // (widths are non-increasing)
+    // stage radix (planned above): the largest r <= 5 whose n (R - 1) / 2 products still fit one round of quads on the chip (the
+    // budget is a measured knee, not a hard limit: beyond it a stage simply takes a second round); ICICLE_HIP_ECNTT_RADIX_LOG forces r
     if (rmax == 1) {
       // more butterflies per stage than LDS-resident tables allow in flight: tables in global memory (see k_ecntt_stage)
-      static const int gtab_mode = getenv("ICICLE_HIP_ECNTT_GTABS") ? atoi(getenv("ICICLE_HIP_ECNTT_GTABS")) : -1; // 0 / 1 force, -1 auto
-      const uint64_t nquads = ((tot / 2 * 4 + 63) / 64) * 16; // quads launched per stage (incl. the padding of the last block)
-      const bool gtab = gtab_mode >= 0 ? gtab_mode != 0 : tot / 2 > (uint64_t)(sizeof(Proj) > 120 ? 12288 : 20480);
-      Proj* gt = nullptr;
-      if (gtab) {
-        HIP_TRY(d_terms.alloc((size_t)nquads * 16 * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
-        gt = d_terms.as<Proj>();
-      }
+      const bool gtab = stage_gtab;
+      Proj* gt = gtab ? d_terms.as<Proj>() : nullptr;
       for (int q = 0; q < logn; q++) {
         k_ecntt_stage<C><<<(unsigned)((tot / 2 * 4 + 63) / 64), 64, gtab ? 0 : (size_t)16 * 16 * sizeof(Proj), st>>>(work, dom.tw, lay, q, gt);
         LAUNCH_CHECK("k_ecntt_stage", st);
       }
     } else if (logn > 0) {
-      const uint64_t max_items = tot * ((1ull << rmax) - 1) / 2; // n (R - 1) / 2 products of the widest stage
-      HIP_TRY(d_terms.alloc((size_t)max_items * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
       HIP_TRY(d_next.alloc((size_t)tot * sizeof(Proj), st), ICICLE_ALLOCATION_FAILED);
       Proj* cur = work;
       Proj* nxt = d_next.as<Proj>();

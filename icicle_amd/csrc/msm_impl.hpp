@@ -1727,6 +1727,28 @@ namespace icicle_hip {
           if (skip) continue; // another shard of this device (or the exchange step) produces the result
         }
         ICICLE_TRY(reduce_group(0, st, seg_lo, nsegr));
+        // Window combine on the HOST when the result goes there anyway (every wrapper's default; the reference's phase 3 is
+        // host code too, cpu_msm.hpp:365-417): result = sum_w 2^offset(w) S_w is a chain of ~250 DEPENDENT doublings whatever
+        // the window size. On the GPU that is the latency floor of a small MSM (k_final: 0.65 ms with four lanes per window);
+        // one host core runs the same Jacobian chain (ec.hpp dbl_jac, 2M + 5S per step) in ~0.15 ms, and the 13 window sums
+        // are a 1.4 KB download that replaces the download of the result. Single MSMs only (a batch of 1024 combines runs in
+        // parallel on the GPU); device-resident results keep k_final. ICICLE_HIP_MSM_HOST_COMBINE=0: always k_final.
+        static const bool host_combine_env = !(getenv("ICICLE_HIP_MSM_HOST_COMBINE") && atoi(getenv("ICICLE_HIP_MSM_HOST_COMBINE")) == 0);
+        if (host_combine_env && !cfg->are_results_on_device && batch == 1 && bb == 1 && !hook && wpf <= 64) {
+          typename E::Proj hw[64];
+          HIP_TRY(hipMemcpyAsync(hw, d_win.ptr(), (size_t)wpf * sizeof(typename E::Proj), hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
+          KernelTimer::end(3, st);
+          HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+          typename E::Proj acc = hw[wpf - 1];
+          for (int w = wpf - 2; w >= 0; w--) { // Horner from the top window: acc = 2^width(w) * acc + S_w
+            typename E::Jac j = E::to_jac(acc);
+            for (int i = 0; i < pl.width(w); i++)
+              j = E::dbl_jac(j);
+            acc = E::add(E::from_jac(j), hw[w]);
+          }
+          E::store_proj_canonical((uint32_t*)results_v, acc);
+          return ICICLE_SUCCESS;
+        }
         {
           const int nbw = (wpf + FINAL_WINDOWS_PER_BLOCK - 1) / FINAL_WINDOWS_PER_BLOCK;
           k_final<C><<<dim3((unsigned)nbw, (unsigned)bb), 64, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, ww, 0, wpf, nbw > 1 ? d_part.as<typename E::Proj>() : nullptr, 0, bb);

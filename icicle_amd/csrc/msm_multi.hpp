@@ -60,6 +60,7 @@ namespace icicle_hip {
     TempBuf acc, recv, send;
     bool self_exchange = false; // "hip_force_rccl" with one device slot
     void* comm = nullptr;
+    const RcclApi* api_of_comm = nullptr; // the library `comm` belongs to (RcclCommSet::api)
     GateTicket* ticket = nullptr; // used (once) right before the slice exchange
 
     icicle_error_t after_accumulate(Proj* buckets, size_t tw, uint32_t nb, uint32_t nseg, uint32_t m, hipStream_t st, bool* skip_reduce, uint32_t* seg_lo, uint32_t* nsegr) override
@@ -100,7 +101,8 @@ namespace icicle_hip {
       // REPLACES the slice with what arrived, so that the real librccl point-to-point calls run on a single-GPU box and a
       // mis-delivered byte shows up in the MSM result.
       if (P == 1 && !self_exchange) return ICICLE_SUCCESS;
-      const RcclApi* api = rccl_api();
+      const RcclApi* api = api_of_comm;
+      if (!api) return ICICLE_API_NOT_IMPLEMENTED;
       const size_t mine = bhi - blo; // buckets of my slice per window
       // ONE message per peer: the tw window slices a peer owns are packed into a contiguous send buffer first (a strided
       // device copy), and arrive contiguously ([peer][window][mine]) -- rounds 2-3 issued tw x (P - 1) Send / Recv pairs per
@@ -254,6 +256,7 @@ namespace icicle_hip {
           HIP_TRY(partials.alloc((size_t)std::max(1, ns_p) * batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
           HIP_TRY(devpart.alloc((size_t)batch * RW * 4, st), ICICLE_ALLOCATION_FAILED);
           hook.nshards = ns_p, hook.P = P, hook.p = p, hook.comm = cset ? cset->comms[p] : nullptr;
+          hook.api_of_comm = cset ? cset->api : nullptr;
           hook.self_exchange = P == 1 && opt.force_rccl && cset != nullptr;
           hook.ticket = &t_exchange;
           icicle_msm_config_t c2 = sub;
@@ -385,7 +388,7 @@ namespace icicle_hip {
           }
           const uint32_t* result = devpart.as<uint32_t>();
           if (use_rccl) { // "all-reduce" of partial sums: EC addition is not an RCCL reduce op -> all-gather + local projective sum
-            const RcclApi* api = rccl_api();
+            const RcclApi* api = cset->api;
             bool have_bufs = gathered.alloc((size_t)P * batch * RW * 4, st) == hipSuccess && fin.alloc((size_t)batch * RW * 4, st) == hipSuccess;
             if (test_failure_armed(p, 3)) have_bufs = false;
             if (!t_gather.arrive(have_bufs) || !have_bufs) return ICICLE_ALLOCATION_FAILED;

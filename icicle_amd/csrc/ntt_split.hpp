@@ -83,7 +83,7 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
     hipStream_t st = side_stream(200 + p); // long-lived per (device, slot): see msm_multi.hpp
     if (!st) return ICICLE_STREAM_CREATION_FAILED;
     icicle_error_t rc = [&]() -> icicle_error_t {
-      const RcclApi* api = rccl_api();
+      const RcclApi* api = cset->api;
       void* comm = cset->comms[p];
       TempBuf bufA, bufB, bufT;
       bool ready = bufA.alloc(chunk * 4, st) == hipSuccess && bufB.alloc(chunk * 4, st) == hipSuccess && bufT.alloc(chunk * 4, st) == hipSuccess;

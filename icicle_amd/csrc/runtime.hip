@@ -254,11 +254,10 @@ namespace icicle_hip {
     return api.CommInitAll && api.AllGather && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
   }
 
-  const RcclApi* rccl_api()
+  static const RcclApi* rccl_api_at(const std::string& path)
   {
     static std::mutex mtx;
     static std::map<std::string, std::unique_ptr<RcclApi>> loaded; // path -> bound entry points (nullptr: not loadable); never unloaded
-    const std::string path = collectives_path();
     std::lock_guard<std::mutex> g(mtx);
     auto it = loaded.find(path);
     if (it != loaded.end()) return it->second.get();
@@ -282,17 +281,21 @@ namespace icicle_hip {
     return loaded.emplace(path, std::move(api)).first->second.get();
   }
 
+  const RcclApi* rccl_api() { return rccl_api_at(collectives_path()); }
+
   icicle_error_t rccl_comms_for(const std::vector<int>& devs, RcclCommSet** set)
   {
     static std::mutex mtx;
     static std::map<std::pair<std::string, std::vector<int>>, RcclCommSet*> cache; // per collectives library and device list; sets live as long as the process
-    const RcclApi* api = rccl_api();
+    const std::string path = collectives_path(); // read ONCE: the entry points and the cache key belong to the same library
+    const RcclApi* api = rccl_api_at(path);
     if (!api || !set) return ICICLE_API_NOT_IMPLEMENTED;
     std::lock_guard<std::mutex> g(mtx);
-    const auto key = std::make_pair(collectives_path(), devs);
+    const auto key = std::make_pair(path, devs);
     auto it = cache.find(key);
     if (it == cache.end()) {
       auto* cs = new RcclCommSet;
+      cs->api = api;
       cs->comms.assign(devs.size(), nullptr);
       const int rc = api->CommInitAll(cs->comms.data(), (int)devs.size(), devs.data());
       if (rc != 0) {
@@ -575,16 +578,17 @@ icicle_error_t icicle_hip_test_inject_failure(int slot, int stage)
   g_fail_stage.store(stage);
   return ICICLE_SUCCESS;
 }
-icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset)
+// Counters of the multi-device / pipelined paths. icicle_hip_multi_stats2 writes at most `n` of them (the caller says how
+// many its buffer holds; later versions may append); icicle_hip_multi_stats keeps round 3's contract of exactly FIVE values
+// (round 4 wrote a sixth through the same symbol: a silent overflow for a C caller with the documented out[5]).
+icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset)
 {
   MultiStats& m = multi_stats();
-  if (out5) {
-    out5[5] = m.exchange_messages.load();
-    out5[0] = m.staged_base_bytes.load();
-    out5[1] = m.staged_scalar_bytes.load();
-    out5[2] = m.exchanged_bucket_bytes.load();
-    out5[3] = m.resident_base_hits.load();
-    out5[4] = m.threaded_calls.load();
+  if (out) {
+    const uint64_t v[6] = {m.staged_base_bytes.load(), m.staged_scalar_bytes.load(), m.exchanged_bucket_bytes.load(),
+                           m.resident_base_hits.load(), m.threaded_calls.load(), m.exchange_messages.load()};
+    for (int i = 0; i < n && i < 6; i++)
+      out[i] = v[i];
   }
   if (reset) {
     m.staged_base_bytes = 0;
@@ -596,6 +600,7 @@ icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset)
   }
   return ICICLE_SUCCESS;
 }
+icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset) { return icicle_hip_multi_stats2(out5, 5, reset); }
 
 // plugin helper: select the GPU for the calling thread without going through icicle_set_device
 // (whose name belongs to the reference runtime when both libraries live in one process)

@@ -349,10 +349,12 @@ icicle_error_t icicle_hip_workspace_bytes(size_t* bytes);
  * icicle_hip_msm_release_resident_bases(bases) frees the resident copies made for `bases` (NULL: for every pointer);
  * icicle_free / icicle_free_async of a device allocation release the copies made for it as well. */
 icicle_error_t icicle_hip_msm_release_resident_bases(const void* bases);
-/* Counters of what the multi-device / pipelined paths moved since the last reset, out[6] = { base bytes staged to a
- * device, scalar bytes staged, bytes sent by the bucket exchange / the split transform's all-to-all, resident-base hits
- * (shards NOT staged again), calls that ran one host thread per device slot, point-to-point messages sent }. */
-icicle_error_t icicle_hip_multi_stats(uint64_t* out, bool reset);
+/* Counters of what the multi-device / pipelined paths moved since the last reset: { base bytes staged to a device, scalar
+ * bytes staged, bytes sent by the bucket exchange / the split transform's all-to-all, resident-base hits (shards NOT staged
+ * again), calls that ran one host thread per device slot, point-to-point messages sent }. icicle_hip_multi_stats2 writes the
+ * first min(n, 6) of them; icicle_hip_multi_stats writes exactly the first FIVE (out[5], the contract since round 3). */
+icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset);
+icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset);
 /* The multi-device paths take their collectives from a library with the NCCL C ABI (ncclCommInitAll, ncclCommDestroy,
  * ncclAllGather, ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd, ncclGetErrorString), bound with dlopen: librccl.so by default,
  * or the library at `path` (NULL / "" = default again; ICICLE_HIP_RCCL_LIB in the environment does the same) -- another RCCL

@@ -54,3 +54,26 @@ def test_bench_inprocess_leg_rehearsed_on_virtual_slots():
     assert out["resident_base_hits_per_call"] == 3
     assert out["ntt"]["roundtrip_ok"] is True
     assert out["result_ok"] is True  # the timed result equals the sum of plain single-GPU MSMs over the shards
+
+
+@pytest.mark.gpu
+def test_bench_one_process_per_gpu_leg_rehearsed_with_two_ranks():
+    """`bench.py --gpus 2` end to end on the ONE GPU of the test box -- the self-launch under
+    torch.distributed.run, two ranks (sharing GPU 0, collectives over gloo: ICICLE_BENCH_GLOO_REHEARSAL), the weak line, the
+    strong object, the split transform with its all-to-alls, the watchdogs, and the in-process leg (virtual slots) -- so that
+    every line of the N > 1 path has executed before the driver's 8-GPU node runs it over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ICICLE_BENCH_GLOO_REHEARSAL"] = "1"
+    env["ICICLE_BENCH_INPROC_VIRTUAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size-log2", "18",
+                        "--ntt-log2", "16", "--ntt-batch", "8"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert "error" not in out, out
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "rehearsal" in out
+    assert out["strong"]["value"] > 0 and out["strong"]["n_gpus"] == 2, out.get("strong")
+    assert out["ntt"]["roundtrip_ok"] is True and out["ntt"]["value"] > 0
+    assert out["ntt_split"]["roundtrip_ok"] is True, out.get("ntt_split")
+    assert out["inproc"]["result_ok"] is True and out["inproc"]["n_gpus"] == 2, out.get("inproc")

@@ -119,6 +119,17 @@ def test_config4_koalabear_ntt_2_22_x_1024_whole(hip):
         exp = rf.ntt(hx, n, 0, batch=len(pick))
         assert np.array_equal(hy, exp), "forward 2^22 x 1024: sampled rows differ from the reference CPU backend"
         assert np.array_equal(rf.ntt(exp, n, 1, batch=len(pick)), hx)
+        # one WHOLE 128-row shard (shard 5: rows 640..767) against the reference, forward and inverse
+        hs = np.ascontiguousarray(x[640:768].cpu().numpy().view(np.uint32)).reshape(-1)
+        es = rf.ntt(hs, n, 0, batch=128)
+        assert np.array_equal(np.ascontiguousarray(y[640:768].cpu().numpy().view(np.uint32)).reshape(-1), es), "forward, shard 5 whole"
+        zi = torch.empty((128, n), dtype=torch.int32, device=dev)
+        cfgs = hip.NTTConfigU32.default()
+        cfgs.batch_size, cfgs.is_async = 128, True
+        N.ntt("koalabear", x[640:768].data_ptr(), N.INVERSE, cfgs, out=zi.data_ptr(), size=n)
+        torch.cuda.synchronize()
+        assert np.array_equal(np.ascontiguousarray(zi.cpu().numpy().view(np.uint32)).reshape(-1), rf.ntt(hs, n, 1, batch=128)), "inverse, shard 5 whole"
+        del hs, es, zi
         # the same shards without the extension (one launch sequence over all rows) give the same bytes
         y2 = torch.empty((256, n), dtype=torch.int32, device=dev)
         cfg2 = hip.NTTConfigU32.default()
