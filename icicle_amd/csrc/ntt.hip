@@ -530,8 +530,12 @@ namespace icicle_hip {
 
     // fast path: natural-order input (kNN / kNM / kMN / kNR), or bit-reversed input after the reordering pre-pass
     // below (kRN / kRR, P >= 2); cosets and single-pass reversed-input transforms use the generic kernel
-    const bool prerev = nl.in_rev && P >= 2;
-    const bool fast = !nl.in_rev || prerev;
+    // kRN: the passes consume the bit-reversed rows as they lie (ntt_fast.hpp RN, in place behind pass 0); kRR and forward cosets
+    // still reorder first. ICICLE_HIP_NTT_RN_NATIVE=0: the pre-pass for every reversed input (rounds 1-4).
+    static const bool rn_on = !(getenv("ICICLE_HIP_NTT_RN_NATIVE") && atoi(getenv("ICICLE_HIP_NTT_RN_NATIVE")) == 0);
+    const bool rn_native = rn_on && nl.in_rev && !nl.out_rev && !(nl.coset && !nl.inverse);
+    const bool prerev = nl.in_rev && P >= 2 && !rn_native;
+    const bool fast = !nl.in_rev || prerev || rn_native;
     TempBuf d_ctab;
     if (nl.coset && fast) { // two-level table, 4096 + N/4096 entries
       const uint32_t nhi = (uint32_t)std::max<uint64_t>(1, n >> 12);
@@ -549,7 +553,7 @@ namespace icicle_hip {
     // groups, because a block then serves 1-2 rows and the per-block twiddle gathers (46 per thread)
     // are no longer amortised over the batch. Kept for experiments only.
     uint32_t rows_per_group = nl.nbatch;
-    if (fast && !prerev && P >= 2 && !cfg->columns_batch && lanes == 1) {
+    if (fast && !prerev && !rn_native && P >= 2 && !cfg->columns_batch && lanes == 1) {
       size_t group_mb = 0;
       if (const char* e = getenv("ICICLE_HIP_NTT_GROUP_MB")) group_mb = (size_t)atoi(e);
       if (group_mb > 0) {
@@ -564,7 +568,7 @@ namespace icicle_hip {
     const uint32_t ltot = cfg->columns_batch ? (uint32_t)batch * lanes : lanes;
     const bool lane_native = lanes_on && fast && ltot > 1;
     const uint32_t row_groups = cfg->columns_batch ? 1u : (uint32_t)batch;
-    if (P >= 2) {
+    if (P >= 2 && !rn_native) {
       HIP_TRY(d_work.alloc(grouped ? (size_t)rows_per_group * n * 4 : bytes, st), ICICLE_ALLOCATION_FAILED);
       W = d_work.as<uint32_t>();
     }
@@ -583,8 +587,8 @@ namespace icicle_hip {
     nl.row0 = g0;
     nl.nrows_launch = std::min<uint32_t>(rows_per_group, nl.nbatch - g0);
     for (int p = 0; p < P; p++) {
-      const uint32_t* src = (p == 0 && !prerev) ? d_in : W;
-      uint32_t* dst = (p == P - 1) ? d_out : W;
+      const uint32_t* src = rn_native ? (p == 0 ? d_in : d_out) : ((p == 0 && !prerev) ? d_in : W);
+      uint32_t* dst = (rn_native || p == P - 1) ? d_out : W; // (RN: every pass is in place once pass 0 has moved the rows to the output)
       nl.src_rel = (grouped && p != 0) ? 1 : 0;
       nl.dst_rel = (grouped && p != P - 1) ? 1 : 0;
       const uint64_t L = (uint64_t)1 << parts[p];
@@ -595,9 +599,12 @@ namespace icicle_hip {
       const bool cvar_p = nl.coset && (nl.inverse ? p == P - 1 : p == 0);
       // Measured (profiles/r03_notes.md section 9): 2^27 x 4 5.63 -> 5.18 ms, 2^27 x 8 9.74 -> 9.15, but 2^26 x 16 7.25 -> 7.52 and
       // 2^25 x 32 unchanged (one 16-wave block per CU hides less latency than two 8-wave ones): only from 2^27 up.
-      const bool big = big_on && fast && !lane_native && logn >= 27 && p < P - 1 && P >= 2 && (parts[p] == 9 || parts[p] == 10) && !cvar_p;
+      const bool big = big_on && fast && !rn_native && !lane_native && logn >= 27 && p < P - 1 && P >= 2 && (parts[p] == 9 || parts[p] == 10) && !cvar_p;
       uint32_t tmax = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (big ? 1024 : 512) * epb / L));
       while (tmax > 1 && 2 * L * (tmax + 1) * 4 > 160 * 1024)
+        tmax >>= 1;
+      const int rn_mode = !rn_native ? 0 : ((p == 0 && !lane_native) ? 2 : 1);
+      while (rn_mode == 2 && tmax > 1 && 2 * (L + (L >> 4)) * tmax * 4 > 160 * 1024)
         tmax >>= 1;
       // lane-native: the tile's tmax word-columns are (tmax >> lsh) logical columns x 2^lsh interleaved transforms. A lane count
       // that is not a multiple of the widest slice keeps a masked last slice (running the remainder as a second launch on
@@ -607,7 +614,7 @@ namespace icicle_hip {
       if (lane_native)
         while ((2u << lsh) <= tmax && (1u << lsh) < ltot)
           lsh++;
-      PassDesc pd = make_pass(parts, P, p, n, dom.log_max, tmax >> lsh);
+      PassDesc pd = rn_native ? make_pass_rn(parts, P, p, dom.log_max, tmax >> lsh) : make_pass(parts, P, p, n, dom.log_max, tmax >> lsh);
       // Few launch rows (16-64 interleaved transforms = one or two slices): adjacent logical columns that share a twiddle set
       // run as launch rows of one block -- pass 0 (its inter-pass factor depends on column / cprime only) and the last pass
       // (none at all); not the coset / bit-reversed-output variants, whose per-block constants depend on the column.
@@ -617,7 +624,7 @@ namespace icicle_hip {
         static const uint32_t cg_max = getenv("ICICLE_HIP_NTT_COLUMN_GROUP") ? (uint32_t)std::max(1, atoi(getenv("ICICLE_HIP_NTT_COLUMN_GROUP"))) : 8u;
         const bool cvar_here = nl.coset && (nl.inverse ? p == P - 1 : p == 0);
         // (only with full slices: grouping multiplies the mostly idle rows of a ragged last slice as well -- 2^20 x 100: 0.84 -> 0.89 ms)
-        const bool full = lane_native && fast && ltot % (1u << lsh) == 0;
+        const bool full = lane_native && fast && !rn_native && ltot % (1u << lsh) == 0;
         const bool allowed = full && !cvar_here && ((p == 0 && P >= 2) || (p == P - 1 && !nl.out_rev));
         const bool middle = full && P == 3 && p == 1; // groups over the outer index instead (ntt_plan.h agrp)
         const uint32_t rows_now = row_groups * ((ltot + (1u << lsh) - 1) >> lsh);
@@ -663,7 +670,8 @@ namespace icicle_hip {
           nlp.nrows_launch = row_groups * nlp.lanes * nlp.cgrp;
         }
         const unsigned threads = (unsigned)(tw * (L / epb));
-        const size_t lds_bytes = (size_t)2 * L * (tw + 1) * 4;
+        const size_t lds_bytes = rn_mode == 2 ? (size_t)2 * tw * (L + (L >> 4)) * 4 : (size_t)2 * L * (tw + 1) * 4;
+        nlp.vec4 = (rn_mode == 2 && nl.es == 1 && nl.bs % 4 == 0 && L >= 16 && (((uintptr_t)src) & 15) == 0) ? 1 : 0;
         // rows of the batch handled by one block (twiddles are loaded once per block): aim for >= 1024 blocks = two rounds of
         // the 2 x 256 resident ones (4096 through round 3; same box, profiles/r04_ntt_twiddle_ab.txt: 2^20 x 256 1.39 -> 1.32 ms,
         // 2^16 x 1024 0.272 -> 0.244, 2^24 x 64 5.50 -> 5.45; the per-block twiddle prologue is what the extra rows amortise)
@@ -677,7 +685,8 @@ namespace icicle_hip {
         static const bool v4_on = !(getenv("ICICLE_HIP_NTT_V4") && atoi(getenv("ICICLE_HIP_NTT_V4")) == 0);
         const bool v4 = v4_on && pd.is_last && lanes == 1 && nl.es == 1 && nl.bs % 4 == 0 && pd.T == 32 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
         const bool orev = nl.out_rev != 0 && pd.is_last != 0;
-        pass_fn_t fn = lane_native ? pick_pass_lanes<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, orev) : pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, orev, v4, big && threads > 512);
+        pass_fn_t fn = rn_mode ? (lane_native ? pick_pass_rn_lanes<PR>(pd.s, cvar) : pick_pass_rn_t<PR, false>(pd.s, rn_mode, cvar))
+                       : lane_native ? pick_pass_lanes<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, orev) : pick_pass<PR>(pd.s, pd.is_last != 0, nl.inverse != 0, cvar, orev, v4, big && threads > 512);
         if (!fn) return ICICLE_INVALID_ARGUMENT;
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), ICICLE_INVALID_ARGUMENT);
         fn<<<dim3(pd.ntiles, gy), threads, lds_bytes, st>>>(src, dst, dom.tw, d_ctab.as<uint32_t>(), pd, nlp, rpb);

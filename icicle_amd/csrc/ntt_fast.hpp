@@ -102,8 +102,16 @@ namespace icicle_hip {
   // tile is ONE logical column of 32 adjacent transforms (no transposition left for the last pass to do), with TL = 4
   // eight columns of one extension-field row. A "row" of the launch is one slice of TL transforms; the lanes of a
   // partial last slice (ltot not a multiple of TL) load a clamped address and store nothing.
-  template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV, bool V4 = false, bool BIG = false, bool LN = false>
-  __global__ __launch_bounds__(BIG ? 1024 : 512, BIG ? 1 : ntt_fast_min_waves(NR, (COSET && (DIF || LN)) || OUTREV)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
+  // RN (bit-reversed INPUT consumed natively, kRN; round 5): in-place DIT by digits. Every pass reads the rows of its digit as
+  // they lie in memory (bit-reversed) and writes them back in natural order, so after the last pass the whole transform is in
+  // natural order -- P reads + P writes like kNN, no reordering pre-pass (the reference reads through a permutation too,
+  // ntt_cpu.h:252,286-296). Pass 0 works on the contiguous runs of 2^s0 elements that hold digit j_0: RN == 2, lanes along
+  // the run on both sides (16 consecutive words per thread in, 4-byte coalesced out), column-major LDS tile padded by one
+  // word per 16; passes q >= 1 (and pass 0 of lane-native tiles, whose word-columns are interleaved transforms) are column
+  // passes, RN == 1: the DIT column code with direct loads and the factor w_M^(j_{q+1} (column + A_q row)) behind it.
+  // The last pass applies 1/N (or g^-k / N) instead. Forward cosets and kRR keep the pre-pass.
+  template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV, bool V4 = false, bool BIG = false, bool LN = false, int RN = 0>
+  __global__ __launch_bounds__(BIG ? 1024 : 512, BIG ? 1 : ntt_fast_min_waves(NR, (COSET && (DIF || LN || RN != 0)) || OUTREV)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
   {
     using S = SmallField<PR>;
     constexpr int SS = NQ0 + 4 * (NR - 1);
@@ -115,6 +123,8 @@ namespace icicle_hip {
     constexpr int KB_BITS = SS - NQ0;
     extern __shared__ uint32_t lds[];
     static_assert(!LN || (!V4 && !BIG), "lane-native tiles: 4-byte lanes, 512-thread blocks");
+    static_assert(RN == 0 || (!DIF && !INV && !OUTREV && !V4 && !BIG), "bit-reversed input: DIT column-type passes (the direction is a run-time flag there)");
+    static_assert(RN != 2 || !LN, "the run pass is the row-major form of pass 0");
     const uint32_t lsh = LN ? nl.lsh : 0u, lmask = (1u << lsh) - 1u;
     const uint32_t TC = pd.T;      // logical columns per tile (LN with column groups: per group of nl.cgrp tile-rows)
     const uint32_t cgrp = LN ? nl.cgrp : 1u, agrp = LN ? nl.agrp : 1u;
@@ -153,7 +163,7 @@ namespace icicle_hip {
     // coset factor g^e (forward) or N^-1 * g^-e (inverse) from the two-level table: lo[e & 4095] * hi[e >> 12]
     auto cpow = [&](uint64_t e) -> uint32_t { return S::mul(ctab[e & 4095], ctab[4096 + (e >> 12)]); };
     // COSET variants are separate instantiations: the 16 per-thread factors must not cost the plain path registers
-    const bool coset_in = COSET && !nl.inverse && pd.pidx == 0;  // x[j] *= g^j on the way in (first pass)
+    const bool coset_in = RN == 0 && COSET && !nl.inverse && pd.pidx == 0;  // x[j] *= g^j on the way in (first pass)
     const bool coset_out = COSET && nl.inverse && pd.is_last;    // X[k] *= g^-k / N on the way out (last pass)
 
     // ---- per-thread twiddles, loaded once per block ---------------------------------------------
@@ -167,7 +177,7 @@ namespace icicle_hip {
 #pragma unroll
     for (int r = 1; r < NR; r++) {
       const int q0 = NQ0 + 4 * (r - 1);
-      const uint32_t g = (DIF && r == NR - 1) ? gA : gB;
+      const uint32_t g = (RN == 2 || (DIF && r == NR - 1)) ? gA : gB;
       const uint32_t base_low = g & ((1u << q0) - 1);
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -178,7 +188,29 @@ namespace icicle_hip {
     // base row of this thread's elements in the top round (natural order, mapping B)
     const uint32_t baseT = (NR == 1) ? 0u : (((gB >> QT) << (QT + 4)) | (gB & ((1u << QT) - 1)));
     uint32_t wip[E]; // inter-pass twiddles of the E elements this thread stores (column passes)
-    if (!DIF) {
+    bool rn_fac = false; // RN: whether the stored values are multiplied by wip[] at all (not in a forward last pass)
+    if (RN != 0) {
+      const uint32_t ccol = RN == 2 ? cA : cB;                   // the thread's logical column of the tile
+      const uint32_t brow = RN == 2 ? gA : baseT;                // its first output row in the round that stores
+      const uint64_t colg = pd.rn_first ? 0u : ((uint64_t)ct * TC + ccol); // low output digits = column (passes q >= 1)
+      const uint64_t A = pd.rn_first ? 1u : pd.in_sk;            // A_q: the row index counts in units of A_q
+      if (!pd.is_last) {
+        const uint64_t outer = pd.rn_first ? ((uint64_t)ct * TC + ccol) : (uint64_t)a; // bitrev of the digits still to come
+        const uint32_t nb = (uint32_t)pd.rn_next_bits;
+        const uint64_t jn = nb ? (uint64_t)(__brev((uint32_t)(outer & ((1u << nb) - 1u))) >> (32 - nb)) : 0u;
+        const uint32_t step = tw_load(jn * A * ((uint64_t)1 << QT) * pd.tw_stride);
+        wip[0] = tw_load(jn * (colg + A * (NR == 1 ? 0u : brow)) * pd.tw_stride);
+#pragma unroll
+        for (int m = 1; m < E; m++)
+          wip[m] = S::mul(wip[m - 1], step);
+        rn_fac = true;
+      } else if (nl.inverse) { // X[K] *= 1/N, or g^-K / N (the coset table is pre-scaled by 1/N), K = column + A_q * row
+#pragma unroll
+        for (int m = 0; m < E; m++)
+          wip[m] = COSET ? cpow(colg + A * ((NR == 1 ? 0u : brow) + ((uint64_t)m << QT))) : nl.ninv_mont;
+        rn_fac = true;
+      }
+    } else if (!DIF) {
       // w_M^(jnext * K), K = k (pass 0) or a + n0*k (pass 1). In pass 1 jnext is the column itself, so
       // jnext * K walks the whole table at random (a 64-byte line per 4-byte twiddle, +25 % traffic on that pass);
       // split as w^(jnext*a) * w^(jnext*n0*k): the first index stays in a 256 KiB prefix of the table, the second
@@ -271,7 +303,29 @@ namespace icicle_hip {
         if (!DIF) // middle pass with outer-index groups: this row's w^(jnext (a + cs)), fetched with the operands
           x[E] = agrp > 1 ? tw_load((((uint64_t)ct * TC + cB) / pd.cprime) * (uint64_t)(a + (nl.row0 + rloc) % cgrp) * pd.tw_stride) : 0u;
       }
-      if (V4) { // top round of the row pass: slot 4g+c of the lane in wave-row r <- word c of row 4g+r
+      if (RN == 2) { // run pass: slots E * gA .. + E - 1 of run cA, as they lie (16 consecutive words of this lane)
+        const uint32_t* p = pin + (in_base + (uint64_t)cA * pd.in_st + (uint64_t)E * gA) * es;
+        if (E == 16 && nl.vec4) {
+#pragma unroll
+          for (int g = 0; g < E / 4; g++) {
+            const uint4 v = reinterpret_cast<const uint4*>(p)[g];
+            x[4 * g] = v.x, x[4 * g + 1] = v.y, x[4 * g + 2] = v.z, x[4 * g + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < E; m++)
+            x[m] = p[(uint64_t)m * es];
+        }
+      } else if (RN == 1) { // column pass on rows in bit-reversed order: slot (gi << NQ0) + m <- row (gi << NQ0) + m, no reversal
+#pragma unroll
+        for (int u = 0; u < G0; u++) {
+          const uint32_t gi = gB * G0 + u;
+          const uint32_t* p = pin + (in_base + ((uint64_t)gi << NQ0) * pd.in_sk + (uint64_t)cB * pd.in_st) * es;
+#pragma unroll
+          for (int m = 0; m < (1 << NQ0); m++)
+            x[u * (1 << NQ0) + m] = p[(uint64_t)m * pd.in_sk * es];
+        }
+      } else if (V4) { // top round of the row pass: slot 4g+c of the lane in wave-row r <- word c of row 4g+r
         const uint32_t* p = pin + (in_base + (uint64_t)(gA - wrow) + (uint64_t)tA * pd.in_st);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -309,8 +363,57 @@ namespace icicle_hip {
       const uint32_t rloc = rloc0 + rr;
       uint32_t* __restrict__ pout = out + row_offset(rloc, nl.dst_rel != 0, true) + (LN ? lB : 0u);
       const bool live = !LN || lB < lane_limit(rloc); // (every global store below is in mapping B)
-      uint32_t* tile = lds + (size_t)(rr & 1) * L * TP;
-      if (!DIF) {
+      uint32_t* tile = lds + (size_t)(rr & 1) * (RN == 2 ? T * (L + (L >> 4)) : L * TP);
+      if (RN == 2) {
+        // ================= run pass: DIT on a contiguous run, lanes along the run =================
+        // LDS: column-major, slot sl of run c at c * LC + sl + (sl >> 4) -- a thread's 16 consecutive slots (lowest round) and
+        // its 16 slots 2^q0 apart (later rounds) are both conflict-free for the 32 lanes of a half-wave
+        constexpr uint32_t LC = L + (L >> 4);
+        uint32_t* colp = tile + cA * LC;
+        uint32_t x[E];
+#pragma unroll
+        for (int m = 0; m < E; m++)
+          x[m] = xin[m];
+#pragma unroll
+        for (int u = 0; u < G0; u++)
+          ntt_stages<S, NQ0, false, true>(x + u * (1 << NQ0), w0);
+        if (NR == 1) {
+          uint32_t* q = pout + (in_base + (uint64_t)cA * pd.in_st + (uint64_t)E * gA) * es;
+#pragma unroll
+          for (int m = 0; m < E; m++)
+            q[(uint64_t)m * es] = rn_fac ? S::mul(x[m], wip[m]) : x[m];
+        } else {
+#pragma unroll
+          for (int m = 0; m < E; m++)
+            colp[(E + 1) * gA + m] = x[m]; // slot E gA + m, + one pad word per 16 slots
+          __syncthreads();
+#pragma unroll
+          for (int r = 1; r < NR; r++) {
+            const int q0 = NQ0 + 4 * (r - 1);
+            const uint32_t base = ((gA >> q0) << (q0 + 4)) | (gA & ((1u << q0) - 1));
+            uint32_t y[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+              const uint32_t sl = base + ((uint32_t)m << q0);
+              y[m] = colp[sl + (sl >> 4)];
+            }
+            ntt_stages<S, 4, false, false>(y, wr[r - 1]);
+            if (r == NR - 1) { // slots gA + m * L/16: 4-byte lanes along the run
+              uint32_t* q = pout + (in_base + (uint64_t)cA * pd.in_st + (uint64_t)base) * es;
+#pragma unroll
+              for (int m = 0; m < 16; m++)
+                q[((uint64_t)m << q0) * es] = rn_fac ? S::mul(y[m], wip[m]) : y[m];
+            } else {
+#pragma unroll
+              for (int m = 0; m < 16; m++) {
+                const uint32_t sl = base + ((uint32_t)m << q0);
+                colp[sl + (sl >> 4)] = y[m];
+              }
+              __syncthreads();
+            }
+          }
+        }
+      } else if (!DIF) {
         // ================= column pass, DIT =================
 #pragma unroll
         for (int u = 0; u < G0; u++) {
@@ -335,7 +438,7 @@ namespace icicle_hip {
             if (live) {
 #pragma unroll
               for (int m = 0; m < (1 << NQ0); m++)
-                q[(uint64_t)m * pd.in_sk * es] = S::mul(x[m], wip[m]);
+                q[(uint64_t)m * pd.in_sk * es] = (RN != 0 && !rn_fac) ? x[m] : S::mul(x[m], wip[m]);
             }
           } else {
 #pragma unroll
@@ -360,7 +463,7 @@ namespace icicle_hip {
               if (live) {
 #pragma unroll
                 for (int m = 0; m < 16; m++)
-                  q[(uint64_t)m * step] = S::mul(x[m], wip[m]);
+                  q[(uint64_t)m * step] = (RN != 0 && !rn_fac) ? x[m] : S::mul(x[m], wip[m]);
               }
             } else {
 #pragma unroll
@@ -590,6 +693,45 @@ namespace icicle_hip {
     case 12: return pick_variant<PR, LN, 4, 3>(dif, inv, coset, outrev);
     }
     return nullptr;
+  }
+
+  // bit-reversed input consumed natively: mode 2 = run pass (pass 0 of a row-major batch), mode 1 = column-type pass
+  template <class PR, bool LN, int NQ0, int NR>
+  static pass_fn_t pick_variant_rn(int mode, bool coset)
+  {
+    if (mode == 2) {
+      if constexpr (!LN)
+        return coset ? (pass_fn_t)k_ntt_fast<PR, NQ0, NR, false, false, true, false, false, false, false, 2> : (pass_fn_t)k_ntt_fast<PR, NQ0, NR, false, false, false, false, false, false, false, 2>;
+      else
+        return nullptr;
+    }
+    return coset ? (pass_fn_t)k_ntt_fast<PR, NQ0, NR, false, false, true, false, false, false, LN, 1> : (pass_fn_t)k_ntt_fast<PR, NQ0, NR, false, false, false, false, false, false, LN, 1>;
+  }
+  template <class PR, bool LN>
+  static pass_fn_t pick_pass_rn_t(int s, int mode, bool coset)
+  {
+    switch (s) {
+    case 1: return pick_variant_rn<PR, LN, 1, 1>(mode, coset);
+    case 2: return pick_variant_rn<PR, LN, 2, 1>(mode, coset);
+    case 3: return pick_variant_rn<PR, LN, 3, 1>(mode, coset);
+    case 4: return pick_variant_rn<PR, LN, 4, 1>(mode, coset);
+    case 5: return pick_variant_rn<PR, LN, 1, 2>(mode, coset);
+    case 6: return pick_variant_rn<PR, LN, 2, 2>(mode, coset);
+    case 7: return pick_variant_rn<PR, LN, 3, 2>(mode, coset);
+    case 8: return pick_variant_rn<PR, LN, 4, 2>(mode, coset);
+    case 9: return pick_variant_rn<PR, LN, 1, 3>(mode, coset);
+    case 10: return pick_variant_rn<PR, LN, 2, 3>(mode, coset);
+    case 11: return pick_variant_rn<PR, LN, 3, 3>(mode, coset);
+    case 12: return pick_variant_rn<PR, LN, 4, 3>(mode, coset);
+    }
+    return nullptr;
+  }
+  pass_fn_t pick_pass_rn_lanes_babybear(int s, bool coset);
+  pass_fn_t pick_pass_rn_lanes_koalabear(int s, bool coset);
+  template <class PR>
+  static pass_fn_t pick_pass_rn_lanes(int s, bool coset)
+  {
+    return PR::P == babybear_params::P ? pick_pass_rn_lanes_babybear(s, coset) : pick_pass_rn_lanes_koalabear(s, coset);
   }
 
   // lane-native variants (LN = true), compiled in ntt_lanes.hip

@@ -7,4 +7,6 @@
 namespace icicle_hip {
   pass_fn_t pick_pass_lanes_babybear(int s, bool dif, bool inv, bool coset, bool outrev) { return pick_pass_t<babybear_params, true>(s, dif, inv, coset, outrev); }
   pass_fn_t pick_pass_lanes_koalabear(int s, bool dif, bool inv, bool coset, bool outrev) { return pick_pass_t<koalabear_params, true>(s, dif, inv, coset, outrev); }
+  pass_fn_t pick_pass_rn_lanes_babybear(int s, bool coset) { return pick_pass_rn_t<babybear_params, true>(s, 1, coset); }
+  pass_fn_t pick_pass_rn_lanes_koalabear(int s, bool coset) { return pick_pass_rn_t<koalabear_params, true>(s, 1, coset); }
 } // namespace icicle_hip

@@ -27,6 +27,12 @@ namespace icicle_hip {
     uint64_t tw_stride;  // max / M
     uint32_t cprime;     // C' = C / N_{p+1}; jnext = (c0 + t) / C'
     uint32_t n0, n1;     // N_0, N_1 (for K and digit reversal)
+    // bit-reversed INPUT consumed natively (kRN, ntt_fast.hpp RN != 0): in-place DIT by digits. Pass q transforms digit j_q
+    // (rows in bit-reversed order in memory, read as they lie) into k_q (rows in natural order); the columns of pass q >= 1 are
+    // the A_q = N_0 .. N_{q-1} low output digits already produced, the outer index `a` is the bit reversal of the digits still
+    // to come. rn_first: pass 0, whose rows are the elements of a contiguous run (the tile's columns are runs, not output digits).
+    // rn_next_bits = log2 N_{q+1}: the factor behind pass q is w_{M}^(j_{q+1} * (column + A_q * row)), j_{q+1} = bitrev(a mod N_{q+1}).
+    int rn_first = 0, rn_next_bits = 0;
   };
 
   struct NttLaunch {
@@ -54,6 +60,7 @@ namespace icicle_hip {
     // In the middle pass of a three-pass transform the factor is w^(column * (a + n0 k)): there `agrp` adjacent values of the OUTER
     // index a run as the rows of a block (agrp = cgrp), w^(column * a) being applied per row to the loaded operands.
     uint32_t cgrp = 1, agrp = 1;
+    int vec4 = 0;     // RN run pass: unit element stride and 16-byte aligned rows -- a thread's 16 consecutive words load as 4 x uint4
     uint32_t tcl = 1; // logical columns in the LDS tile (PassDesc::T counts the cgrp-wide group in pass 0 / the last pass)
     uint64_t cst_in = 0, cst_out = 0;
   };
@@ -118,6 +125,51 @@ namespace icicle_hip {
       pd.in_st = n1 * L;
       pd.out_sk = n >> pd.s;
       pd.out_st = 1;
+    }
+    return pd;
+  }
+
+  // Pass q of the native bit-reversed-input pipeline (see PassDesc::rn_first). run_pass: pass 0 of a row-major batch, run by
+  // the RN == 2 code (lanes along the run); otherwise pass 0 has the column shape too (lane-native tiles: the tile's word-columns
+  // are interleaved transforms, a row = one position of the run).
+  static inline PassDesc make_pass_rn(const int* parts, int P, int q, int log_max, uint32_t tmax)
+  {
+    PassDesc pd{};
+    pd.s = parts[q];
+    pd.pidx = q;
+    pd.is_last = (q == P - 1);
+    const uint64_t L = (uint64_t)1 << pd.s;
+    uint64_t C = 1, O = 1; // columns = low output digits done; outer = input digits still to come
+    for (int i = 0; i < q; i++)
+      C <<= parts[i];
+    for (int i = q + 1; i < P; i++)
+      O <<= parts[i];
+    pd.n0 = 1u << parts[0];
+    pd.n1 = P > 1 ? (1u << parts[1]) : 1;
+    pd.rn_first = (q == 0);
+    if (q == 0) { // tile = T runs of L contiguous elements
+      pd.T = (int)std::min<uint64_t>(tmax, O);
+      pd.tiles_per_a = (uint32_t)(O / pd.T);
+      pd.ntiles = pd.tiles_per_a;
+      pd.in_base_a = 0;
+      pd.in_base_ct = (uint64_t)pd.T * L;
+      pd.in_sk = 1;
+      pd.in_st = L;
+    } else {
+      pd.T = (int)std::min<uint64_t>(tmax, C);
+      pd.tiles_per_a = (uint32_t)(C / pd.T);
+      pd.ntiles = (uint32_t)(O * pd.tiles_per_a);
+      pd.in_base_a = L * C;
+      pd.in_base_ct = pd.T;
+      pd.in_sk = C;
+      pd.in_st = 1;
+    }
+    if (!pd.is_last) {
+      int lm = 0; // M = N_0 .. N_{q+1}
+      for (int i = 0; i <= q + 1; i++)
+        lm += parts[i];
+      pd.tw_stride = (uint64_t)1 << (log_max - lm);
+      pd.rn_next_bits = parts[q + 1];
     }
     return pd;
   }

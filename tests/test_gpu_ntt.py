@@ -303,3 +303,43 @@ def test_stream_ordered_alloc_and_workspace(env, hip):
     check(lib.icicle_hip_workspace_bytes(ctypes.byref(cached)))
     assert cached.value == 0
     st.destroy()
+
+
+@pytest.mark.parametrize("logn", list(range(1, 21)))
+def test_ntt_bit_reversed_input_consumed_natively(env, hip, logn):
+    """Round 5: kRN without the reordering pre-pass (ntt_fast.hpp RN: a run pass over the contiguous reversed runs, then
+    in-place column passes; the reference reads through a permutation at no extra data pass either, ntt_cpu.h:252,286-296).
+    Every size 2^1 .. 2^20 (1, 2 and 3 passes, every sub-transform length), both directions, inverse with a coset, row
+    batches, columns_batch (lane-native tiles, full and ragged slices), the extension field, in place -- memcmp with the
+    reference CPU backend. Forward cosets and kRR (which keep the pre-pass) ride along as controls."""
+    import ctypes
+
+    fname, F, rf, N = env
+    rng = np.random.default_rng(7000 + logn)
+    n = 1 << logn
+    cases = [(1, False, N.INVERSE, 1), (3, False, N.FORWARD, 1), (5, False, N.INVERSE, int(rng.integers(2, F.p))),
+             (32, True, N.INVERSE, 1), (7, True, N.FORWARD, 1), (37, True, N.INVERSE, int(rng.integers(2, F.p))),
+             (2, False, N.FORWARD, int(rng.integers(2, F.p)))]
+    if logn > 16:
+        cases = cases[:2] + [cases[3], cases[5]]
+    for batch, columns, direction, coset in cases:
+        x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
+        cfg = hip.NTTConfigU32.default()
+        cfg.batch_size, cfg.columns_batch, cfg.ordering, cfg.coset_gen = batch, columns, N.kRN, coset
+        exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, ordering=N.kRN, coset_gen=coset)
+        got = N.ntt(fname, x, direction, cfg)
+        assert np.array_equal(got, exp), (logn, batch, columns, direction, coset)
+        y = x.copy()  # in place (host buffers: staged once, transformed in place on the device)
+        N.ntt(fname, y, direction, cfg, out=y)
+        assert np.array_equal(y, exp), ("in place", logn, batch, columns, direction, coset)
+    # kRR control + the extension field (4 interleaved base-field transforms per element)
+    x = rng.integers(0, F.p, size=n * 2, dtype=np.uint32)
+    cfg = hip.NTTConfigU32.default()
+    cfg.batch_size, cfg.ordering = 2, N.kRR
+    assert np.array_equal(N.ntt(fname, x, N.FORWARD, cfg), rf.ntt(x, n, 0, batch=2, ordering=N.kRR))
+    if logn <= 16:
+        xe = rng.integers(0, F.p, size=n * 4 * 3, dtype=np.uint32)
+        cfg = hip.NTTConfigU32.default()
+        cfg.batch_size, cfg.ordering = 3, N.kRN
+        for direction in (N.FORWARD, N.INVERSE):
+            assert np.array_equal(N.ntt(fname, xe, direction, cfg, extension=True), rf.ntt(xe, n, direction, batch=3, ordering=N.kRN, extension=True)), ("ext", logn, direction)
