@@ -624,9 +624,10 @@ namespace icicle_hip {
         static const uint32_t cg_max = getenv("ICICLE_HIP_NTT_COLUMN_GROUP") ? (uint32_t)std::max(1, atoi(getenv("ICICLE_HIP_NTT_COLUMN_GROUP"))) : 8u;
         const bool cvar_here = nl.coset && (nl.inverse ? p == P - 1 : p == 0);
         // (only with full slices: grouping multiplies the mostly idle rows of a ragged last slice as well -- 2^20 x 100: 0.84 -> 0.89 ms)
-        const bool full = lane_native && fast && !rn_native && ltot % (1u << lsh) == 0;
-        const bool allowed = full && !cvar_here && ((p == 0 && P >= 2) || (p == P - 1 && !nl.out_rev));
-        const bool middle = full && P == 3 && p == 1; // groups over the outer index instead (ntt_plan.h agrp)
+        const bool full = lane_native && fast && ltot % (1u << lsh) == 0;
+        // (RN: every pass can group adjacent logical columns -- the factor behind a pass is rebuilt per row, ntt_fast.hpp rn_rowfac)
+        const bool allowed = full && !cvar_here && (rn_native ? P >= 2 : ((p == 0 && P >= 2) || (p == P - 1 && !nl.out_rev)));
+        const bool middle = full && !rn_native && P == 3 && p == 1; // groups over the outer index instead (ntt_plan.h agrp)
         const uint32_t rows_now = row_groups * ((ltot + (1u << lsh) - 1) >> lsh);
         uint32_t want = 1;
         while ((allowed || middle) && want * 2 <= cg_max && rows_now * want * 2 <= 8)
@@ -641,8 +642,8 @@ namespace icicle_hip {
           ag_for_pass = ag;
         }
         while (want > 1) {
-          const PassDesc pg = make_pass(parts, P, p, n, dom.log_max, tcl * want);
-          if ((uint32_t)pg.T == tcl * want && (pg.is_last || (uint32_t)pg.T <= pg.cprime)) {
+          const PassDesc pg = rn_native ? make_pass_rn(parts, P, p, dom.log_max, tcl * want) : make_pass(parts, P, p, n, dom.log_max, tcl * want);
+          if ((uint32_t)pg.T == tcl * want && (rn_native || pg.is_last || (uint32_t)pg.T <= pg.cprime)) {
             pd = pg;
             cg = want;
             break;
@@ -666,7 +667,7 @@ namespace icicle_hip {
           nlp.cgrp = cg * ag_rows;
           nlp.agrp = ag_rows;
           nlp.cst_in = ag_rows > 1 ? pd.in_base_a * nl.es : (uint64_t)tcl * pd.in_st * nl.es;
-          nlp.cst_out = (pd.is_last && ag_rows == 1) ? (uint64_t)tcl * nl.es : nlp.cst_in;
+          nlp.cst_out = (pd.is_last && ag_rows == 1 && !rn_native) ? (uint64_t)tcl * nl.es : nlp.cst_in; // (RN passes are in place: same layout both sides)
           nlp.nrows_launch = row_groups * nlp.lanes * nlp.cgrp;
         }
         const unsigned threads = (unsigned)(tw * (L / epb));

@@ -189,6 +189,11 @@ namespace icicle_hip {
     const uint32_t baseT = (NR == 1) ? 0u : (((gB >> QT) << (QT + 4)) | (gB & ((1u << QT) - 1)));
     uint32_t wip[E]; // inter-pass twiddles of the E elements this thread stores (column passes)
     bool rn_fac = false; // RN: whether the stored values are multiplied by wip[] at all (not in a forward last pass)
+    // RN with column groups (lane-native, few slices): the launch rows of a block are cgrp ADJACENT logical columns (runs in pass
+    // 0). The stage twiddles are shared; the factor behind the pass is not -- w^(j_next (column + A row)) with the row's own
+    // column, and in pass 0 the row's own j_next -- so each row fetches the first term and the ratio of its geometric
+    // progression with its operands (load_row: x[E], x[E + 1]) and rebuilds the 16 factors: 15 products per row and thread.
+    const bool rn_rowfac = RN == 1 && LN && cgrp > 1 && !pd.is_last;
     if (RN != 0) {
       const uint32_t ccol = RN == 2 ? cA : cB;                   // the thread's logical column of the tile
       const uint32_t brow = RN == 2 ? gA : baseT;                // its first output row in the round that stores
@@ -300,7 +305,17 @@ namespace icicle_hip {
       if (LN) { // + lane, clamped into the slice: the surplus lanes of a partial slice re-read its last transform
         const uint32_t lim = lane_limit(rloc) - 1u;
         pin += std::min<uint32_t>((DIF && NR > 1) ? lA : lB, lim);
-        if (!DIF) // middle pass with outer-index groups: this row's w^(jnext (a + cs)), fetched with the operands
+        if (RN == 1) {
+          if (rn_rowfac) { // this row's logical column = the block's first + cs * tcl
+            const uint64_t ccol = (uint64_t)ct * TC + (uint64_t)((nl.row0 + rloc) % cgrp) * nl.tcl + cB;
+            const uint64_t outer = pd.rn_first ? ccol : (uint64_t)a;
+            const uint32_t nb = (uint32_t)pd.rn_next_bits;
+            const uint64_t jn = nb ? (uint64_t)(__brev((uint32_t)(outer & ((1u << nb) - 1u))) >> (32 - nb)) : 0u;
+            const uint64_t A = pd.rn_first ? 1u : pd.in_sk;
+            x[E] = tw_load(jn * ((pd.rn_first ? 0u : ccol) + A * (NR == 1 ? 0u : baseT)) * pd.tw_stride);
+            x[E + 1] = tw_load(jn * A * ((uint64_t)1 << QT) * pd.tw_stride);
+          }
+        } else if (!DIF) // middle pass with outer-index groups: this row's w^(jnext (a + cs)), fetched with the operands
           x[E] = agrp > 1 ? tw_load((((uint64_t)ct * TC + cB) / pd.cprime) * (uint64_t)(a + (nl.row0 + rloc) % cgrp) * pd.tw_stride) : 0u;
       }
       if (RN == 2) { // run pass: slots E * gA .. + E - 1 of run cA, as they lie (16 consecutive words of this lane)
@@ -415,6 +430,14 @@ namespace icicle_hip {
         }
       } else if (!DIF) {
         // ================= column pass, DIT =================
+        if (RN == 1 && LN) {
+          if (rn_rowfac) { // (uniform over the block) this row's own factors, see the note at rn_rowfac
+            wip[0] = xin[E];
+#pragma unroll
+            for (int m = 1; m < E; m++)
+              wip[m] = S::mul(wip[m - 1], xin[E + 1]);
+          }
+        }
 #pragma unroll
         for (int u = 0; u < G0; u++) {
           const uint32_t gi = gB * G0 + u;
@@ -633,7 +656,7 @@ namespace icicle_hip {
       //    for those very loads (that is what rounds 1-2 shipped, profiles/r02_notes.md);
       //  * the copy xin <- xnext stays behind the stores (sched_barrier): hoisted into the second round it needs the
       //    loads half an iteration early.
-      constexpr int EX = E + (LN ? 1 : 0); // LN: one more word per row (see load_row)
+      constexpr int EX = E + (LN ? (RN == 1 ? 2 : 1) : 0); // LN: one (RN: two) more words per row (see load_row)
       uint32_t xin[EX], xnext[EX];
       if (nrows) {
         load_row(rloc0, xin);
@@ -652,7 +675,7 @@ namespace icicle_hip {
       }
     } else { // (three-round variants, s >= 9, are already at 110-150 VGPRs: they load each row when it is needed)
       for (uint32_t rr = 0; rr < nrows; rr++) {
-        uint32_t xin[E + (LN ? 1 : 0)];
+        uint32_t xin[E + (LN ? (RN == 1 ? 2 : 1) : 0)];
         load_row(rloc0 + rr, xin);
         process_row(rr, xin);
       }

@@ -318,10 +318,10 @@ def test_ntt_bit_reversed_input_consumed_natively(env, hip, logn):
     rng = np.random.default_rng(7000 + logn)
     n = 1 << logn
     cases = [(1, False, N.INVERSE, 1), (3, False, N.FORWARD, 1), (5, False, N.INVERSE, int(rng.integers(2, F.p))),
-             (32, True, N.INVERSE, 1), (7, True, N.FORWARD, 1), (37, True, N.INVERSE, int(rng.integers(2, F.p))),
+             (32, True, N.INVERSE, 1), (64, True, N.FORWARD, 1), (7, True, N.FORWARD, 1), (37, True, N.INVERSE, int(rng.integers(2, F.p))),
              (2, False, N.FORWARD, int(rng.integers(2, F.p)))]
     if logn > 16:
-        cases = cases[:2] + [cases[3], cases[5]]
+        cases = cases[:2] + [cases[3], cases[4], cases[6]]
     for batch, columns, direction, coset in cases:
         x = rng.integers(0, F.p, size=n * batch, dtype=np.uint32)
         cfg = hip.NTTConfigU32.default()

@@ -131,6 +131,45 @@ def ntt_layout_case(field, logn, batch, layout, ordering=0):
     N.release_domain(field)
 
 
+def ntt_polymul_case(field, logn, batch):
+    """the polynomial-product pipeline the orderings exist for: two kNR forward transforms, a point-wise product
+    in bit-reversed order, one kRN inverse transform -- no reordering anywhere, everything device resident"""
+    from icicle_amd import vecops as V
+    from icicle_amd._lib import VecOpsConfig
+
+    n = 1 << logn
+    N.init_domain(field, N.get_root_of_unity(field, n))
+    p = {"babybear": 0x78000001, "koalabear": 0x7F000001}[field]
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    a = torch.randint(0, p, (batch, n), dtype=torch.int32, device=dev, generator=g)
+    b = torch.randint(0, p, (batch, n), dtype=torch.int32, device=dev, generator=g)
+    fa, fb, c = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    cf = NTTConfigU32.default()
+    cf.batch_size, cf.is_async, cf.ordering = batch, True, N.kNR
+    ci = NTTConfigU32.default()
+    ci.batch_size, ci.is_async, ci.ordering = batch, True, N.kRN
+    vc = VecOpsConfig.default()
+    vc.is_async = True
+
+    def run():
+        N.ntt(field, a.data_ptr(), N.FORWARD, cf, out=fa.data_ptr(), size=n)
+        N.ntt(field, b.data_ptr(), N.FORWARD, cf, out=fb.data_ptr(), size=n)
+        V.vector_mul(field, fa.data_ptr(), fb.data_ptr(), vc, out=fa.data_ptr(), size=batch * n)
+        N.ntt(field, fa.data_ptr(), N.INVERSE, ci, out=c.data_ptr(), size=n)
+
+    ms = time_it(run)
+    one = time_it(lambda: N.ntt(field, a.data_ptr(), N.FORWARD, NTT_NN(batch), out=fa.data_ptr(), size=n))
+    print(f"polymul {field:10s} 2^{logn:<2d} x {batch:<4d} kNR + kNR + vector_mul + kRN(inverse): {ms:8.3f} ms   (one kNN forward: {one:7.3f} ms -> pipeline / 3 transforms = {ms / 3 / one:5.2f} x kNN)", flush=True)
+    N.release_domain(field)
+
+
+def NTT_NN(batch):
+    cfg = NTTConfigU32.default()
+    cfg.batch_size, cfg.is_async = batch, True
+    return cfg
+
+
 def ntt_scalar_case(field, logn, batch):
     """NTT over the curve's 256-bit scalar field; inputs are any words < 2^253 (valid canonical elements)"""
     n = 1 << logn
@@ -332,6 +371,10 @@ if __name__ == "__main__":
         for layout in ("rows", "columns"):  # bit-reversed output / input
             ntt_layout_case("babybear", 22, 64, layout, ordering=1)
             ntt_layout_case("babybear", 22, 64, layout, ordering=2)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "polymul":
+        for field, logn, b in (("babybear", 24, 64), ("babybear", 22, 64), ("koalabear", 22, 64), ("babybear", 16, 1024)):
+            ntt_polymul_case(field, logn, b)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "criterion":
         criterion_sweep()
