@@ -565,6 +565,10 @@ namespace icicle_hip {
     // Interleaved transforms (columns_batch, extension field): lane-native tiles, see ntt_fast.hpp. ltot transforms sit
     // word by word at element stride es = ltot; one row group per batch row (row-major) or a single one (columns_batch).
     static const bool lanes_on = !(getenv("ICICLE_HIP_NTT_LANES") && atoi(getenv("ICICLE_HIP_NTT_LANES")) == 0);
+    // (A ragged lane count -- 100 columns -- is NOT slow because of its masked last slice: with the 4 surplus lanes split off into a
+    //  row-major side batch the three full slices took as long as the four did, 0.85 vs 0.84 ms at 2^20 x 100. Rows of 100 words are
+    //  400 bytes apart, so every 128-byte access straddles three 64-byte sectors instead of two: 2.9 TB/s per pass against 4.8 for the
+    //  row batch. Built, measured, removed: profiles/r05_notes.md.)
     const uint32_t ltot = cfg->columns_batch ? (uint32_t)batch * lanes : lanes;
     const bool lane_native = lanes_on && fast && ltot > 1;
     const uint32_t row_groups = cfg->columns_batch ? 1u : (uint32_t)batch;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One BabyBear NTT case on the GPU (profiling helper): tools/ntt_one.py LOGN BATCH [reps]"""
+"""One BabyBear NTT case on the GPU (profiling helper): tools/ntt_one.py LOGN BATCH [reps]   (NTT_ONE_COLUMNS=1: columns_batch,
+NTT_ONE_ORDERING=<0..5>)"""
 import os
 import sys
 
@@ -21,6 +22,8 @@ y = torch.empty_like(x)
 cfg = NTTConfigU32.default()
 cfg.batch_size = batch
 cfg.is_async = True
+cfg.columns_batch = os.environ.get("NTT_ONE_COLUMNS", "0") == "1"
+cfg.ordering = int(os.environ.get("NTT_ONE_ORDERING", "0"))
 for _ in range(reps):
     N.ntt("babybear", x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n)
 torch.cuda.synchronize()
