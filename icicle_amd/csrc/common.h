@@ -116,6 +116,7 @@ namespace icicle_hip {
     bool busy = false;
     hipEvent_t last_use = nullptr;
     hipStream_t last_stream = nullptr;
+    double released_at = 0; // host clock (seconds) of the last release: idle arenas decay (runtime.hip arena_decay_locked)
   };
   Arena* arena_acquire(size_t bytes, hipStream_t st); // nullptr on allocation failure
   void arena_release(Arena* a, hipStream_t st);

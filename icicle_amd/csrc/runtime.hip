@@ -4,6 +4,7 @@
 // behavioural requirements read off icicle/tests/test_device_api.cpp:17-259).
 #include "common.h"
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -110,10 +111,36 @@ namespace icicle_hip {
     }
     return freed;
   }
+  // Decay of the cached workspace (8-12 GiB stayed cached after a 2^26 MSM until an allocation failed
+  // or the caller asked): an arena nobody has leased for ICICLE_HIP_WORKSPACE_DECAY_S seconds (default 30, 0 = keep forever)
+  // and whose last user has finished is given back the next time any entry point leases or releases a temporary -- a
+  // loop of calls keeps its arenas, a process that moved on to other work gets the memory back without asking.
+  static double now_seconds()
+  {
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+  }
+  static void arena_decay_locked(int dev)
+  {
+    static const double decay = getenv("ICICLE_HIP_WORKSPACE_DECAY_S") ? atof(getenv("ICICLE_HIP_WORKSPACE_DECAY_S")) : 30.0;
+    if (decay <= 0) return;
+    const double t = now_seconds();
+    for (Arena* a : arenas()) {
+      if (a->busy || a->device != dev || !a->base || t - a->released_at < decay) continue;
+      if (a->last_use && hipEventQuery(a->last_use) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      (void)hipFree(a->base);
+      a->base = nullptr;
+      a->cap = 0;
+    }
+  }
   Arena* arena_acquire(size_t bytes, hipStream_t st)
   {
     const int dev = current_device_id();
     std::lock_guard<std::mutex> g(g_arena_mtx);
+    arena_decay_locked(dev);
     Arena* best = nullptr;
     Arena* empty = nullptr;
     for (Arena* a : arenas()) {
@@ -165,6 +192,7 @@ namespace icicle_hip {
     (void)hipEventRecord(a->last_use, st);
     a->last_stream = st;
     a->busy = false;
+    a->released_at = now_seconds();
   }
   void arena_trim(int device)
   {

@@ -491,3 +491,35 @@ def test_msm_mixed_window_widths(hip, cname, nwin):
         lib.destroy_config_extension(ext)
     assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(sc, bases)))
     assert refc.is_on_curve(got[0])
+
+
+def test_idle_workspace_decays(hip):
+    """the temporaries of a large call stayed cached until an allocation failed or the caller asked. Arenas idle
+    for ICICLE_HIP_WORKSPACE_DECAY_S seconds (default 30) are now given back by the next call that leases a temporary."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import ctypes, time, numpy as np
+import icicle_amd
+from icicle_amd import msm as M, ntt as N, runtime
+from icicle_amd._lib import lib, check
+runtime.set_device(0)
+n = 1 << 18
+bases = M.generate_affine_points("bn254", n, k0=3)
+sc = np.random.default_rng(1).integers(0, 1 << 32, size=(n, 8), dtype=np.uint64).astype(np.uint32); sc[:, 7] &= 0x0FFFFFFF
+M.msm("bn254", sc, bases)
+c = ctypes.c_size_t()
+check(lib.icicle_hip_workspace_bytes(ctypes.byref(c))); big = c.value
+time.sleep(1.6)
+x = np.arange(16, dtype=np.uint32)
+N.init_domain("babybear", N.get_root_of_unity("babybear", 16)); N.ntt("babybear", x, N.FORWARD)   # any call that leases a temporary
+check(lib.icicle_hip_workspace_bytes(ctypes.byref(c))); small = c.value
+print("DECAY", big, small)
+assert big > (32 << 20) and small < big // 4, (big, small)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ICICLE_HIP_WORKSPACE_DECAY_S="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0 and "DECAY" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
