@@ -343,6 +343,10 @@ icicle_error_t icicle_hip_workspace_bytes(size_t* bytes);
  *                                    MANDATORY before the address is reused unless the memory came from icicle_malloc
  *                                    (icicle_free releases the copies) --, or versioned with
  *   "hip_bases_generation"     int   msm: caller's content id, part of the cache key (a new value stages fresh copies)
+ *   "hip_msm_windows"          int   msm (single MSM, precompute_factor 1, c = 0, full-width scalars): W windows whose widths add up
+ *                                    to the scalar bits, the top ones one bit wider, with the reference's negate-if-top-bit-set trick
+ *                                    (cpu_msm.hpp:276-277). The cost model picks such a plan by itself from 2^23 terms up (BN254 2^26:
+ *                                    10 x 21 + 2 x 22 bits); the key forces one at any size (parity tests, A/B runs)
  *   "hip_force_rccl"           bool  msm, ntt: take the RCCL exchanges even with one device slot -- all-gather, and the grouped
  *                                    ncclSend / ncclRecv of the bucket exchange and of the split transform as sends to
  *                                    the own rank of a size-1 communicator (test hook: the real librccl on one GPU)

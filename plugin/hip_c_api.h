@@ -160,8 +160,11 @@ struct HipExt {
   {
     if (!e) return;
     const bool nd = e->has("hip_num_devices"), xb = e->has("hip_msm_exchange_buckets"), rb = e->has("hip_bases_resident"), fr = e->has("hip_force_rccl");
-    if (!nd && !xb && !rb && !fr) return;
+    const bool bg = e->has("hip_bases_generation"), mw = e->has("hip_msm_windows");
+    if (!nd && !xb && !rb && !fr && !bg && !mw) return;
     h = icicle_hip_create_config_extension();
+    if (bg) icicle_hip_config_extension_set_int(h, "hip_bases_generation", e->get<int>("hip_bases_generation"));
+    if (mw) icicle_hip_config_extension_set_int(h, "hip_msm_windows", e->get<int>("hip_msm_windows"));
     if (nd) icicle_hip_config_extension_set_int(h, "hip_num_devices", e->get<int>("hip_num_devices"));
     if (xb) icicle_hip_config_extension_set_bool(h, "hip_msm_exchange_buckets", e->get<bool>("hip_msm_exchange_buckets"));
     if (rb) icicle_hip_config_extension_set_bool(h, "hip_bases_resident", e->get<bool>("hip_bases_resident"));
