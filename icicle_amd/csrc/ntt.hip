@@ -630,7 +630,7 @@ namespace icicle_hip {
         // (only with full slices: grouping multiplies the mostly idle rows of a ragged last slice as well -- 2^20 x 100: 0.84 -> 0.89 ms)
         const bool full = lane_native && fast && ltot % (1u << lsh) == 0;
         // (RN: every pass can group adjacent logical columns -- the factor behind a pass is rebuilt per row, ntt_fast.hpp rn_rowfac)
-        const bool allowed = full && !cvar_here && (rn_native ? P >= 2 : ((p == 0 && P >= 2) || (p == P - 1 && !nl.out_rev)));
+        const bool allowed = full && !cvar_here && (rn_native ? P >= 2 : ((p == 0 && P >= 2) || p == P - 1)); // (round 5: the bit-reversed-output store too)
         const bool middle = full && !rn_native && P == 3 && p == 1; // groups over the outer index instead (ntt_plan.h agrp)
         const uint32_t rows_now = row_groups * ((ltot + (1u << lsh) - 1) >> lsh);
         uint32_t want = 1;
@@ -672,6 +672,7 @@ namespace icicle_hip {
           nlp.agrp = ag_rows;
           nlp.cst_in = ag_rows > 1 ? pd.in_base_a * nl.es : (uint64_t)tcl * pd.in_st * nl.es;
           nlp.cst_out = (pd.is_last && ag_rows == 1 && !rn_native) ? (uint64_t)tcl * nl.es : nlp.cst_in; // (RN passes are in place: same layout both sides)
+          if (pd.is_last && nl.out_rev && !rn_native) nlp.cst_out = 0; // (the bit-reversed store computes the column's place itself, ntt_fast.hpp)
           nlp.nrows_launch = row_groups * nlp.lanes * nlp.cgrp;
         }
         const unsigned threads = (unsigned)(tw * (L / epb));

@@ -616,13 +616,16 @@ namespace icicle_hip {
             const uint32_t bits = nl.logn - SS, lt = 31 - __clz(T);
             const uint64_t k0b = (pd.pidx <= 1) ? ((uint64_t)ct * TC) : (((uint64_t)ct * TC) + (uint64_t)pd.n0 * a);
             if (LN) { // word e of the tile = (lane, row r, logical column c), lanes fastest: runs of TL words
+              // (column groups: launch row cs of the block holds logical columns k0b + cs * tcl + c; the column enters the bit
+              //  reversal, so it cannot be a pointer offset: the host sets cst_out = 0 for this store)
               const uint32_t nthr = T * NG16, lim = lane_limit(rloc);
               uint32_t* po = out + row_offset(rloc, nl.dst_rel != 0, true);
+              const uint64_t kcol = k0b + (uint64_t)((nl.row0 + rloc) % cgrp) * nl.tcl;
 #pragma unroll
               for (int it = 0; it < E; it++) {
                 const uint32_t e = (uint32_t)it * nthr + threadIdx.x;
                 const uint32_t lane = e & lmask, r = (e >> lsh) & (L - 1u), c = e >> (lsh + SS);
-                if (lane < lim) po[(bitrev64(k0b + c, bits) * L + r) * es + lane] = tile[r * TP + ((c << lsh) | lane)];
+                if (lane < lim) po[(bitrev64(kcol + c, bits) * L + r) * es + lane] = tile[r * TP + ((c << lsh) | lane)];
               }
             } else if (T >= 16) {
               const uint32_t r = threadIdx.x % L, th = threadIdx.x / L;
