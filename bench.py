@@ -402,19 +402,40 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (bench.py cannot
     # run rocprofv3 on itself); only attached when the workload matches the profiled one. FETCH_SIZE is calibrated on
     # a kernel with the same access pattern and a known byte count (icicle_hip_ubench_gather under the same counter).
+    # The PMC file carries the SHA-256 of the kernel sources it was taken on (tools/pmc_json.py); the traffic is attached only
+    # when the sources THIS run executes hash the same -- a counter value of another build says nothing about this one.
     pmc = {}
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    try:
+        import glob
+
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]
+        with open(newest) as f:
+            pmc = json.load(f)
+        pmc["_file"] = os.path.basename(newest)
+    except Exception:
+        pmc = {}
+
+    def sources_sha16(names):
+        import hashlib
+
+        h = hashlib.sha256()
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                pmc = json.load(f)
-            pmc["_file"] = name
-            break
+            for nm in names:
+                with open(os.path.join(ROOT, "icicle_amd", "csrc", nm), "rb") as f:
+                    h.update(f.read())
         except Exception:
-            pmc = {}
+            return None
+        return h.hexdigest()[:16]
+
+    msm_sha = sources_sha16(["msm_impl.hpp", "msm_plan.h", "ec.hpp", "bigfield.hpp", "mont_asm.hpp"])
+    ntt_sha = sources_sha16(["ntt_fast.hpp", "ntt.hip", "ntt_plan.h", "smallfield.hpp"])
     if args.size_log2 == 26 and args.msm_c == 0 and not strong and "msm_bn254_2^26" in pmc:
-        m = pmc["msm_bn254_2^26"]
-        roofline["traffic"] = (m["fetch_size_kb_raw"] * m["fetch_correction"] + m["write_size_kb"]) * 1024 / 1e9
-        roofline["traffic_unit"] = f"GB per launch (FETCH_SIZE x calibration + WRITE_SIZE, profiles/{pmc['_file']})"
+        if pmc.get("msm_sources_sha16") == msm_sha and msm_sha:
+            m = pmc["msm_bn254_2^26"]
+            roofline["traffic"] = (m["fetch_size_kb_raw"] * m["fetch_correction"] + m["write_size_kb"]) * 1024 / 1e9
+            roofline["traffic_unit"] = f"GB per launch (FETCH_SIZE x calibration + WRITE_SIZE, profiles/{pmc['_file']}, kernel sources {msm_sha})"
+        else:
+            roofline["traffic_note"] = f"profiles/{pmc.get('_file')} was taken on other kernel sources ({pmc.get('msm_sources_sha16')} != {msm_sha}): not attached"
     # secondary: integer-ALU view. mixed adds per MSM = n * windows; 8M + 2S field operations each. The roof is
     # measured in this run: the same ec.hpp mixed add with every operand in registers (no memory traffic at all).
     pc, pw = ctypes.c_int(), ctypes.c_int()
@@ -553,9 +574,12 @@ def main():
                          "avg_launch_ms": ntt_call_ms, "launches": cnt.value},
         }
         if logn == 24 and rows == 64 and "ntt_babybear_2^24x64_one_direction" in pmc:
-            m = pmc["ntt_babybear_2^24x64_one_direction"]
-            out["ntt"]["roofline"]["traffic"] = m["passes"] * (m["fetch_size_kb_raw_per_pass"] * m["fetch_correction"] + m["write_size_kb_per_pass"]) * 1024 / 1e9
-            out["ntt"]["roofline"]["traffic_unit"] = f"GB per direction (3 pass launches; FETCH_SIZE calibrated on the 4 GiB each pass provably reads, WRITE_SIZE exact; profiles/{pmc['_file']})"
+            if pmc.get("ntt_sources_sha16") == ntt_sha and ntt_sha:
+                m = pmc["ntt_babybear_2^24x64_one_direction"]
+                out["ntt"]["roofline"]["traffic"] = m["passes"] * (m["fetch_size_kb_raw_per_pass"] * m["fetch_correction"] + m["write_size_kb_per_pass"]) * 1024 / 1e9
+                out["ntt"]["roofline"]["traffic_unit"] = f"GB per direction (3 pass launches; FETCH_SIZE calibrated on the 4 GiB each pass provably reads, WRITE_SIZE exact; profiles/{pmc['_file']}, kernel sources {ntt_sha})"
+            else:
+                out["ntt"]["roofline"]["traffic_note"] = f"profiles/{pmc.get('_file')} was taken on other kernel sources ({pmc.get('ntt_sources_sha16')} != {ntt_sha}): not attached"
         N.release_domain("babybear")
 
     # ---------------- N > 1 only: ONE large NTT split over the ranks (4-step, all-to-all over RCCL/xGMI) -----

@@ -978,6 +978,42 @@ namespace icicle_hip {
     }
   }
 
+  // Small windows (nb <= 512 buckets: batches of small MSMs, e.g. the reference's published 2^12 x 2^10 shape with c = 8): a
+  // 64-lane chunk per window spends most of its additions in the lane scans -- 128 buckets = 2 rows x 2 adds + 18 scan steps per
+  // wave. Here a window gets LW = nb / rows lanes (a power of two, 4 .. 32) and a wave reduces 64 / LW windows at once with the
+  // same formula on LW-lane segments: S = T + LW * sum_l tri0_l + sum_l X_l (k0 = 0: the chunk is the whole window).
+  // 1024 x 2^12 BN254: bucket reduction 4.47 -> see profiles/r05_notes.md.
+  template <class C>
+  __global__ __launch_bounds__(64) void k_reduce_small(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ winsum, uint32_t nb, uint32_t lw_log, uint32_t nwindows)
+  {
+    using E = EC<C>;
+    const uint32_t lane = threadIdx.x, LW = 1u << lw_log, rows = nb >> lw_log;
+    const uint32_t sl = lane & (LW - 1u);
+    const size_t wp = (size_t)blockIdx.x * (64u >> lw_log) + (lane >> lw_log);
+    const bool act = wp < nwindows;
+    const typename E::Proj* b = buckets + (act ? wp : 0) * nb;
+    typename E::Proj line = E::proj_identity(), tri0 = E::proj_identity();
+    for (int i = (int)rows - 1; i >= 0; i--) {
+      tri0 = E::add(tri0, line);
+      if (act) line = E::add(line, b[(uint32_t)i * LW + sl]);
+    }
+    typename E::Proj suf = line; // inclusive suffix sum over the segment: lane sl gets sum_{sl' >= sl} line
+    for (uint32_t d = 1; d < LW; d <<= 1) {
+      const typename E::Proj o = proj_shfl_down(suf, (int)d);
+      if (sl + d < LW) suf = E::add(suf, o);
+    }
+    typename E::Proj x = proj_shfl_down(suf, 1); // exclusive
+    if (sl == LW - 1u) x = E::proj_identity();
+    for (uint32_t q = 0; q < lw_log; q++)
+      tri0 = E::dbl(tri0); // LW * tri0
+    typename E::Proj v = E::add(x, tri0);
+    for (uint32_t d = LW >> 1; d >= 1; d >>= 1) { // segment sum, valid in sl == 0
+      const typename E::Proj o = proj_shfl_down(v, (int)d);
+      if (sl < d) v = E::add(v, o);
+    }
+    if (act && sl == 0) winsum[wp] = E::add(v, suf);
+  }
+
   // per window: S = sum_c (V_c + T_c) + chunk * sum_c c * T_c over the nsegr <= blockDim chunks of this device's slice
   // (c = global chunk index = seg_lo + local index)
   template <class C>
@@ -1083,6 +1119,29 @@ namespace icicle_hip {
         E::store_proj_canonical(result + (size_t)b * 3 * E::N32, sh[0]);
     }
   }
+  // Window combine of a BATCH: Horner per MSM, one DPP quad each. k_final scales every window by its own doubling chain -- 16 x
+  // the doublings of a Horner walk, which is what a single MSM wants (the chains run side by side: the floor is ONE chain) and
+  // what a batch does not: 1024 MSMs x 32 windows kept 2048 waves busy for 1.8 ms. With a quad per MSM the batch is 64 waves and
+  // ends after one walk of ~250 quad doublings + one quad addition per window.
+  template <class C>
+  __global__ __launch_bounds__(64) void k_final_horner(const typename EC<C>::Proj* __restrict__ winsum, uint32_t* __restrict__ result, int wpf, WinWidths ww, int nmsm)
+  {
+    using E = EC<C>;
+    const uint32_t role = threadIdx.x & 3u;
+    const int b = blockIdx.x * 16 + (int)(threadIdx.x >> 2);
+    const bool act = b < nmsm;
+    const typename E::Proj* ws = winsum + (size_t)(act ? b : 0) * wpf;
+    typename E::Proj acc = ws[wpf - 1];
+    for (int w = wpf - 2; w >= 0; w--) { // acc = 2^width(w) * acc + S_w (the same trip counts in every lane)
+      typename E::Jac j = E::to_jac(acc);
+      const int nd = ww.width(w);
+      for (int i = 0; i < nd; i++)
+        j = E::dbl_jac_quad(j, role);
+      acc = E::add_quad(E::from_jac(j), ws[w], role);
+    }
+    if (act && role == 0) E::store_proj_canonical(result + (size_t)b * 3 * E::N32, acc);
+  }
+
   // result[b] = sum of the ng group partials of MSM b (partials[g * nmsm + b]), canonical words
   template <class C>
   __global__ __launch_bounds__(64) void k_final_combine(const typename EC<C>::Proj* __restrict__ partials, uint32_t* __restrict__ result, int ng, int nmsm)
@@ -1696,7 +1755,16 @@ namespace icicle_hip {
         typename E::Proj* cV = chunkV + (size_t)w0 * nseg;
         typename E::Proj* cT = chunkT + (size_t)w0 * nseg;
         const size_t nblocks = (size_t)nlo_w * nseg_lo + (size_t)(nw - nlo_w) * nsegr;
-        if (nblocks) {
+        // whole small windows: several per wave (k_reduce_small); rows per lane: 8, or 4 for the tiniest windows
+        static const bool small_on = !(getenv("ICICLE_HIP_MSM_REDUCE_SMALL") && atoi(getenv("ICICLE_HIP_MSM_REDUCE_SMALL")) == 0);
+        if (small_on && direct && nlo_w == 0 && nb >= 16 && nb <= 512 && nw >= 64) {
+          uint32_t lw_log = 2;
+          while ((nb >> lw_log) > 8 && lw_log < 5)
+            lw_log++;
+          const uint32_t per_wave = 64u >> lw_log;
+          k_reduce_small<C><<<(unsigned)(((size_t)nw + per_wave - 1) / per_wave), 64, 0, sq>>>(buckets + (size_t)w0 * nb, win, nb, lw_log, (uint32_t)nw);
+          LAUNCH_CHECK("k_reduce_small", sq);
+        } else if (nblocks) {
           k_reduce_wave<C><<<(unsigned)nblocks, 64, 0, sq>>>(buckets + (size_t)w0 * nb, cV, cT, direct ? win : nullptr, nb, nb, mrow, seg_lo, nsegr, nlo_w, nseg_lo);
           LAUNCH_CHECK("k_reduce_wave", sq);
         }
@@ -1749,7 +1817,11 @@ namespace icicle_hip {
           E::store_proj_canonical((uint32_t*)results_v, acc);
           return ICICLE_SUCCESS;
         }
-        {
+        static const bool horner_on = !(getenv("ICICLE_HIP_MSM_BATCH_HORNER") && atoi(getenv("ICICLE_HIP_MSM_BATCH_HORNER")) == 0);
+        if (horner_on && bb >= 64 && wpf >= 2) {
+          k_final_horner<C><<<(unsigned)((bb + 15) / 16), 64, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, ww, bb);
+          LAUNCH_CHECK("k_final_horner", st);
+        } else {
           const int nbw = (wpf + FINAL_WINDOWS_PER_BLOCK - 1) / FINAL_WINDOWS_PER_BLOCK;
           k_final<C><<<dim3((unsigned)nbw, (unsigned)bb), 64, 0, st>>>(d_win.as<typename E::Proj>(), d_res + (size_t)b0 * RW, wpf, ww, 0, wpf, nbw > 1 ? d_part.as<typename E::Proj>() : nullptr, 0, bb);
           LAUNCH_CHECK("k_final", st);

@@ -214,3 +214,16 @@ def test_g2_device_resident_large(hip, cname):
     m = 1 << 12
     _check(hip, cname, raw[:m].copy(), bases[:m].copy(), refc)
     st.destroy()
+
+
+@pytest.mark.parametrize("cname", ["bn254"])
+def test_g2_batch_of_many_small_msms(hip, cname):
+    """batch >= 64: the window combine runs as one Horner walk per MSM on a DPP quad (k_final_horner) and, for windows of <= 512
+    buckets, the bucket reduction packs several windows into a wave (k_reduce_small) -- both over Fq2 here"""
+    C = pyref.G2_CURVES[cname]
+    refc = ref.RefCurve(cname, g2=True)
+    rng = np.random.default_rng(77)
+    n, batch = 96, 70
+    bases = refc.generate_affine_points(n)
+    scalars = to_words(rand_scalars(rng, n * batch, C.base.r), 8)
+    _check(hip, cname, scalars, bases, refc, batch=batch, shared=True)

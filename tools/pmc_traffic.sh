@@ -22,7 +22,7 @@ for r in rows:
     agg[n].append(float(r["Counter_Value"]))
 for n, v in agg.items():
     if any(k in n for k in ("k_accumulate", "k_ntt_fast", "k_diag_gather", "k_a_scatter", "k_b_scatter", "k_digits")):
-        print(f"{sys.argv[2]:10s} {n[-70:]:70s} launches {len(v):3d}  avg {sum(v) / len(v):14.0f} KiB  max {max(v):14.0f}")
+        print(f"{sys.argv[2]:10s} {n[-110:]:110s} launches {len(v):3d}  avg {sum(v) / len(v):14.0f} KiB  max {max(v):14.0f}")
 PY
   rm -rf $O
 done
