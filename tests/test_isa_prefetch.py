@@ -22,8 +22,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "icicle_amd", "lib", "libicicle_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
-COL = "_ZN10icicle_hip10k_ntt_fastINS_15babybear_paramsELi4ELi2ELb0ELb0ELb0ELb0ELb0ELb0ELb0EEEvPKjPjS3_S3_NS_8PassDescENS_9NttLaunchEj"
-ROW = "_ZN10icicle_hip10k_ntt_fastINS_15babybear_paramsELi4ELi2ELb1ELb0ELb0ELb0ELb1ELb0ELb0EEEvPKjPjS3_S3_NS_8PassDescENS_9NttLaunchEj"
+COL = "_ZN10icicle_hip10k_ntt_fastINS_15babybear_paramsELi4ELi2ELb0ELb0ELb0ELb0ELb0ELb0ELb0ELi0EEEvPKjPjS3_S3_NS_8PassDescENS_9NttLaunchEj"
+RUN = "_ZN10icicle_hip10k_ntt_fastINS_15babybear_paramsELi4ELi2ELb0ELb0ELb0ELb0ELb0ELb0ELb0ELi2EEEvPKjPjS3_S3_NS_8PassDescENS_9NttLaunchEj"  # RN run pass (round 5)
+ROW = "_ZN10icicle_hip10k_ntt_fastINS_15babybear_paramsELi4ELi2ELb1ELb0ELb0ELb0ELb1ELb0ELb0ELi0EEEvPKjPjS3_S3_NS_8PassDescENS_9NttLaunchEj"
 
 
 @pytest.fixture(scope="module")

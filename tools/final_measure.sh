@@ -9,7 +9,7 @@ mkdir -p "$O"
 cd "$R"
 export TMPDIR=/tmp
 if [ "${1:-}" != "notests" ]; then
-  timeout 1500 python -m pytest tests -q -m gpu --durations=12 > "$O/gpu_pytest.txt" 2>&1; echo "pytest rc=$?" | tee -a "$O/summary.txt"
+  timeout 2400 python -m pytest tests -q -m gpu --durations=12 > "$O/gpu_pytest.txt" 2>&1; echo "pytest rc=$?" | tee -a "$O/summary.txt"
 fi
 python bench.py 2>"$O/bench.err" | grep '^{"metric"' > "$O/bench.json"; echo "bench rc=$?" | tee -a "$O/summary.txt"
 python tools/bench_brief.py plain < "$O/bench.json"
@@ -23,6 +23,6 @@ find "$O/prof" -name '*.db' -delete
 head -16 "$O/kernel_stats.txt"
 bash "$R/tools/pmc_traffic.sh" > "$O/pmc_traffic.txt" 2>&1; cat "$O/pmc_traffic.txt"
 cd "$R"
-{ python tools/perf_matrix.py; python tools/perf_matrix.py ntt; python tools/perf_matrix.py layouts; python tools/perf_matrix.py midsize; python tools/perf_matrix.py distributions; python tools/perf_matrix.py g2; python tools/perf_matrix.py scalar-ntt; python tools/perf_matrix.py ecntt; python tools/perf_matrix.py precompute; python tools/perf_matrix.py criterion; python tools/perf_matrix.py curves; python tools/ntt_gold_time.py; } 2>/dev/null | grep -v amdgpu.ids > "$O/perf_matrix.txt"
+{ python tools/perf_matrix.py; python tools/perf_matrix.py ntt; python tools/perf_matrix.py layouts; python tools/perf_matrix.py polymul; python tools/exp_ntt_rn.py; python tools/exp_msm_midsize.py; python tools/perf_matrix.py midsize; python tools/perf_matrix.py distributions; python tools/perf_matrix.py g2; python tools/perf_matrix.py scalar-ntt; python tools/perf_matrix.py ecntt; python tools/perf_matrix.py precompute; python tools/perf_matrix.py criterion; python tools/perf_matrix.py curves; python tools/ntt_gold_time.py; } 2>/dev/null | grep -v amdgpu.ids > "$O/perf_matrix.txt"
 cat "$O/perf_matrix.txt"
 tail -20 "$O/gpu_pytest.txt" 2>/dev/null
