@@ -199,6 +199,9 @@ namespace icicle_hip {
       // the bucket exchange needs a whole batch in one launch group of msm_run_single; decided here, from the shape
       // alone, so that every device takes the same branch (fallback: partial-sum exchange)
       if (exchange_buckets && (size_t)batch * pl.wpf > 60000) exchange_buckets = false;
+      // Partial sums need no common window size: without a base table and without the bucket exchange every shard plans for
+      // itself, which lets the large ones take the mixed-width plans of round 5 (msm_plan.h; 2^26-term shards: 12 windows)
+      if (pf == 1 && !exchange_buckets && cfg->c <= 0) sub.c = 0;
     }
     sub.are_scalars_on_device = sub.are_points_on_device = sub.are_results_on_device = true;
     sub.is_async = true;
