@@ -105,6 +105,30 @@ def test_transforms_beyond_2_24_against_the_four_step_identity(hip, fname, logn)
         N.ntt(fname, y.data_ptr(), N.INVERSE, cfg, out=z.data_ptr(), size=n)
         torch.cuda.synchronize()
         assert torch.equal(z, x)
+        # kRN consumed natively (round 5): sub-transforms of 2^9 points -- the three-round variants of the run pass and of the
+        # direct-load column passes -- are only reachable from 2^25 up. kRN(x) must equal kNN(bit_reverse(x)), both directions,
+        # and kRN(inverse) of the bit-reversed-output forward transform (kNR) must give x back (the polynomial-product pattern).
+        from icicle_amd import vecops as V
+
+        xr = torch.empty_like(x)
+        vcfg = hip.VecOpsConfig.default()
+        vcfg.is_async = True
+        V.bit_reverse(fname, x.data_ptr(), vcfg, out=xr.data_ptr(), size=n)
+        crn = hip.NTTConfigU32.default()
+        crn.is_async, crn.ordering = True, N.kRN
+        for direction in (N.FORWARD, N.INVERSE):
+            a1, a2 = torch.empty_like(x), torch.empty_like(x)
+            N.ntt(fname, xr.data_ptr(), direction, crn, out=a1.data_ptr(), size=n)
+            N.ntt(fname, x.data_ptr(), direction, cfg, out=a2.data_ptr(), size=n)
+            torch.cuda.synchronize()
+            assert torch.equal(a1, a2), (fname, logn, direction, "kRN differs from kNN of the reordered input")
+        cnr = hip.NTTConfigU32.default()
+        cnr.is_async, cnr.ordering = True, N.kNR
+        N.ntt(fname, x.data_ptr(), N.FORWARD, cnr, out=a1.data_ptr(), size=n)
+        N.ntt(fname, a1.data_ptr(), N.INVERSE, crn, out=a1.data_ptr(), size=n)  # in place
+        torch.cuda.synchronize()
+        assert torch.equal(a1, x)
+        del a1, a2, xr
         # two rows at once (the batch loop of the wide passes)
         if logn == 25:
             x2 = torch.stack([x, torch.roll(x, 1)])
