@@ -523,6 +523,18 @@ namespace icicle_hip {
     // sub-transforms of 2^8 points (three passes at 2^24). Two passes of 2^12 (1024-thread blocks, 4-column tiles)
     // and 64-column tiles were built and measured in round 1 and lost: profiles/r01_notes.md.
     split_logn(logn, 8, parts, &P);
+    {
+      // Which pass takes the extra bit of a size that is not a multiple of three: split_logn gives it to the first ones (9,8,8 at
+      // 2^25). Measured (profiles/r05_ntt_big_parts.txt, ICICLE_HIP_NTT_PARTS_ORDER = 0 / 1 / 2 = first / last / middle): at 2^25 the
+      // MIDDLE pass is the place for the 512-row sub-transform, 8,9,8: 6.48 -> 6.02 ms (x 32 rows); every other size measured
+      // (2^20, 2^22, 2^26, 2^27) is best or within 3 % with the default, so only 2^25 changes.
+      static const int order = getenv("ICICLE_HIP_NTT_PARTS_ORDER") ? atoi(getenv("ICICLE_HIP_NTT_PARTS_ORDER")) : -1;
+      if (P == 3 && (order == 1)) std::swap(parts[0], parts[2]);
+      if (P == 3 && (order == 2 || (order < 0 && logn == 25))) {
+        std::swap(parts[0], parts[1]);
+        if (parts[0] > parts[2]) std::swap(parts[0], parts[2]);
+      }
+    }
     // P >= 2: passes 0..P-2 run in a work buffer (the last pass permutes across tiles, so it can
     // never be in place; this also makes input == output legal, test_mod_arithmetic_api.h:627,679)
     TempBuf d_work;
