@@ -429,6 +429,9 @@ namespace icicle_hip {
     --it;
     const TableInfo& t = it->second;
     if (a >= it->first + t.bytes || t.pf != pf || t.entry_bytes != entry_bytes || (a - it->first) % (entry_bytes * pf) != 0) return 0;
+    // a host table is only recognised at its START: the caller vouches for the memory behind `bases` (at least pf entries), not
+    // for the recorded range around it -- that allocation may be gone, and the fingerprint must not be read from unmapped pages
+    if (!t.on_device && a != it->first) return 0;
     if (!t.on_device && memcmp(t.print, (const char*)it->first + entry_bytes, std::min<size_t>(32, entry_bytes)) != 0) {
       g_tables.erase(it); // the host memory holds something else by now
       return 0;
