@@ -137,8 +137,8 @@ typedef struct {
  * (backend/cpu/src/curve/cpu_msm.hpp:470-485). The output is device memory whenever the pointer says so, even with
  * are_results_on_device left false (the Rust wrapper never sets it for this call).
  * Window size with a table: pass the same config.c > 0 to both calls, or leave both at 0 -- then msm() takes the c the table
- * was built with from a per-process record of the tables msm_precompute_bases wrote (any aligned slice of such a table
- * works, whatever msm_size / batch_size), and only for a table it has never seen (copied, loaded from disk) derives c from
+ * was built with from a per-process record of the tables msm_precompute_bases wrote (any aligned slice of a device-resident
+ * table works, a host-resident one is recognised at its start; whatever msm_size / batch_size), and only for a table it has never seen (copied, loaded from disk) derives c from
  * msm_size, scalar bits and precompute_factor exactly as msm_precompute_bases does from nof_bases -- the reference's rule
  * (cpu_msm.hpp:466 vs :207), correct when the two sizes are equal. */
 icicle_error_t bn254_msm(const void* scalars, const void* bases, int msm_size, const icicle_msm_config_t* config, void* results); /* src/msm.cpp:12 */
