@@ -304,6 +304,170 @@ def test_msm_on_a_table_of_another_size_finds_its_window(hip, cname):
     assert np.array_equal(refc.to_affine(got), refc.to_affine(refc.msm(sc, bases, batch=16, shared=False)))
 
 
+def test_generated_points_are_distinct_multiples_of_g(hip):
+    from icicle_amd import msm as M
+
+    C = pyref.BN254
+    pts = M.generate_affine_points("bn254", 100, k0=5)
+    exp = points_to_array(C, pyref.gen_points(C, 100, k0=5))
+    assert np.array_equal(pts, exp)
+
+
+@pytest.mark.parametrize("cname,logn,top", [("bn254", 26, 0x30644E72)])  # (config 3 runs whole: test_gpu_fullsize_configs.py)
+def test_msm_full_size_split_property(hip, cname, logn, top):
+    """BASELINE config 1 size (2^26 BN254) and the per-GPU share of config 3 (BLS12-381 2^28 over 8 GPUs = 2^25),
+    inputs resident in HBM: the size-independent property MSM(all) == MSM(first half) + MSM(second half), with the
+    halves combined by the reference's own ecadd, AND the reference CPU backend run on the full inputs."""
+    import ctypes
+    import torch
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib, check
+
+    refc = ref.RefCurve(cname)
+    L = M.LIMBS[cname]
+    n = 1 << logn
+    dev = torch.device("cuda", 0)
+    bases = torch.empty((n, 2 * L), dtype=torch.int32, device=dev)
+    check(getattr(lib, f"{cname}_hip_generate_affine_points")(bases.data_ptr(), n, 12345, True, None))
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    sc = torch.randint(-(2 ** 31), 2 ** 31, (n, 8), dtype=torch.int32, device=dev, generator=g)
+    sc[:, 7] = torch.randint(0, top, (n,), dtype=torch.int32, device=dev, generator=g)
+    torch.cuda.synchronize()
+
+    def run(lo, hi):
+        cfg = hip.MSMConfig.default()
+        out = np.zeros((1, 3 * L), dtype=np.uint32)
+        M.msm(cname, sc[lo:hi].data_ptr(), bases[lo:hi].data_ptr(), cfg, results=out, msm_size=hi - lo)
+        return out
+
+    full, a, b = run(0, n), run(0, n // 2), run(n // 2, n)
+    s = np.zeros(3 * L, dtype=np.uint32)
+    getattr(refc.lib, f"{cname}_ecadd")(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(s.ctypes.data))
+    assert np.array_equal(refc.to_affine(full), refc.to_affine(s.reshape(1, 3 * L)))
+    assert refc.is_on_curve(full[0])
+    # ... and the byte compare itself: the reference CPU backend on the FULL inputs (about a minute on the GPU box's
+    # 256 host cores; BASELINE configs[1] says "bit-exact vs CPU", so it is compared, not inferred)
+    hs = np.ascontiguousarray(sc.cpu().numpy().view(np.uint32))
+    hb = np.ascontiguousarray(bases.cpu().numpy().view(np.uint32))
+    exp = refc.msm(hs, hb)
+    assert np.array_equal(refc.to_affine(full), refc.to_affine(exp)), f"{cname} 2^{logn}: GPU result differs from the reference CPU backend"
+    assert refc.projective_eq(full[0], exp[0])
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_skewed_large_overflow_segments(hip, cname):
+    """2^18 scalars, almost all equal to 1 or 2 (msm/tests.rs:256-304 style skew): two buckets hold ~2^17
+    points each, far beyond the per-thread segment, so the overflow-segment path carries the result."""
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(31)
+    n = 1 << 18
+    bases = M.generate_affine_points(cname, n, k0=999)
+    vals = rng.integers(1, 3, size=n)
+    sc = np.zeros((n, 8), dtype=np.uint32)
+    sc[:, 0] = vals
+    sc[::1000] = to_words(rand_scalars(rng, len(sc[::1000]), C.r), 8)
+    _check(hip, cname, sc, bases, refc)
+    _check(hip, cname, sc, bases, refc, c=16)
+
+
+def test_concurrent_host_threads(hip):
+    """four host threads issue MSMs and NTTs at the same time (ctypes releases the GIL during the call): every
+    call leases its own temporaries, so the results must be those of the serial runs"""
+    import threading
+
+    from icicle_amd import msm as M
+    from icicle_amd import ntt as N
+    from icicle_amd import runtime
+
+    C = pyref.BN254
+    rng = np.random.default_rng(91)
+    n = 3000
+    bases = points_to_array(C, cached_points(C, n))
+    scal = [to_words(rand_scalars(rng, n, C.r), 8) for _ in range(4)]
+    serial = [M.msm("bn254", s, bases) for s in scal]
+    F = pyref.BABYBEAR
+    N.init_domain("babybear", N.get_root_of_unity("babybear", 1 << 14))
+    xs = [rng.integers(0, F.p, size=1 << 14, dtype=np.uint32) for _ in range(4)]
+    serial_ntt = [N.ntt("babybear", x, N.FORWARD) for x in xs]
+    out, out_ntt, errs = [None] * 4, [None] * 4, []
+
+    def work(i):
+        try:
+            runtime.set_device(0)  # the active device is per host thread (icicle_set_device)
+            for _ in range(5):
+                out[i] = M.msm("bn254", scal[i], bases)
+                out_ntt[i] = N.ntt("babybear", xs[i], N.FORWARD)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    N.release_domain("babybear")
+    assert not errs, errs
+    refc = ref.RefCurve("bn254")
+    for i in range(4):
+        assert np.array_equal(refc.to_affine(out[i]), refc.to_affine(serial[i]))
+        assert np.array_equal(out_ntt[i], serial_ntt[i])
+
+
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_large_batch_fused_digit_histogram(hip, cname):
+    """batch >= 512 with enough scalar chunks takes the fused k_digits_count path (digits + pass-A histogram in one
+    kernel; otherwise only reached by the 2^26 run): 600 MSMs of 2^10 terms, shared and per-MSM bases, every result
+    against the reference CPU backend (the perf matrix benchmarks this shape: 1024 x 2^12)."""
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(37)
+    n, batch = 1 << 10, 600
+    from icicle_amd import msm as M
+
+    bases = M.generate_affine_points(cname, n, k0=4242)
+    words = rng.integers(0, 1 << 32, size=(n * batch, 8), dtype=np.uint64).astype(np.uint32)
+    words[:, 7] &= 0x0FFFFFFF  # < r for both curves
+    words[::97] = 0
+    _check(hip, cname, words, bases, refc, batch=batch, shared=True)
+    nb2 = 520
+    bases2 = M.generate_affine_points(cname, n * nb2, k0=99)
+    _check(hip, cname, np.ascontiguousarray(words[: n * nb2]), bases2, refc, batch=nb2, shared=False)
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_inplace_asm_products_with_aliased_and_constant_operands(hip, curve_id):
+    """ADVICE r02: the in-place asm products overwrite their read-write operand while the other operands are still read;
+    with early-clobber operands an aliased input (a <- a * a) or a constant one must still give the out-of-place value.
+    4096 pseudo-random operand sets per curve, checked on the device."""
+    import ctypes
+    from icicle_amd._lib import lib, check
+
+    bad = ctypes.c_int(-1)
+    check(lib.icicle_hip_selftest_inplace_products(curve_id, ctypes.byref(bad)), "selftest")
+    assert bad.value == 0
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12_381"])
+def test_msm_window_size_22_forced(hip, cname):
+    """config.c = 22 (12 windows of a 254 / 255-bit scalar; pass B of the sort then ranks into 2^11 bins, two per thread):
+    never chosen by the plan -- it measured slower, profiles/r04_msm_csweep.txt -- but a caller may ask for it. 2^18 uniform
+    scalars plus the skewed mix (two hot buckets -> overflow segments) against the reference CPU backend."""
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(2222)
+    n = (1 << 18) - 7
+    bases = M.generate_affine_points(cname, n, k0=31337)
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    _check(hip, cname, sc, bases, refc, c=22)
+    sc[: n // 2, 1:] = 0
+    sc[: n // 2, 0] = rng.integers(1, 3, size=n // 2)
+    _check(hip, cname, sc, bases, refc, c=22)
+
+
 @pytest.mark.parametrize("cname", CURVES)
 @pytest.mark.parametrize("nwin", [12, 13, 17, 23, 31, 40])
 def test_msm_mixed_window_widths(hip, cname, nwin):
