@@ -298,6 +298,11 @@ const char* icicle_hip_version(void);
 /* The window plan msm() would use for this size / config: c = window bits, nwin = number of c-bit windows of a
  * scalar_bits-bit scalar (signed digits, so ceil((scalar_bits + 1) / c)). For operation counts in benchmarks. */
 icicle_error_t icicle_hip_msm_plan(int msm_size, int scalar_bits, const icicle_msm_config_t* config, int* c, int* nwin);
+/* The whole plan, for tests and benchmarks: out[0..7] = c (bits of the widest windows), nwin, n_lo (number of windows that are one bit
+ * narrower -- the mixed-width plans picked from 2^23 terms up), negate (1 = scalars with the top bit set are replaced by r - s and
+ * their point negated, icicle/backend/cpu/src/curve/cpu_msm.hpp:276-277), buckets per window slot, buckets in use, segment size,
+ * windows per precomputed-table entry. force_windows = MSMConfig.ext "hip_msm_windows" (0: the cost model decides, as msm() does). */
+icicle_error_t icicle_hip_msm_plan_info(int msm_size, int scalar_bits, const icicle_msm_config_t* config, int force_windows, int* out);
 /* Device-side synthetic input generator for benchmarks: fills `out` (device or host per flag) with
  * `n` DISTINCT affine points (k0 + i) * G in the reference's canonical affine layout. */
 icicle_error_t bn254_hip_generate_affine_points(void* out, int n, uint64_t k0, bool out_on_device, icicleStreamHandle stream);

@@ -1,5 +1,6 @@
 import os
 import sys
+import time
 
 import pytest
 
@@ -10,6 +11,19 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "refjob(*keys, order=0): the test joins background reference-CPU jobs of tests/refpool.py; it runs at the end of the session, lower order first")
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_collection_modifyitems(config, items):
+    """Tests that join a background reference job run LAST (shortest reference leg first), so the GPU works through the rest
+    of the suite while the host cores compute the expected values (tests/refpool.py)."""
+    late = [it for it in items if it.get_closest_marker("refjob")]
+    if late:
+        rest = [it for it in items if not it.get_closest_marker("refjob")]
+        late.sort(key=lambda it: it.get_closest_marker("refjob").kwargs.get("order", 0))
+        items[:] = rest + late
+    config._refjob_items = late
 
 
 @pytest.fixture(scope="session")
@@ -29,3 +43,47 @@ def hip():
     assert runtime.get_device_count() >= 1, "no HIP device visible"
     runtime.set_device(0)
     return icicle_amd
+
+
+@pytest.fixture(scope="session")
+def refpool(request):
+    """The session's background pool of reference-CPU jobs: every job a SELECTED test names with @pytest.mark.refjob is started
+    here (inputs generated on the GPU, downloaded once, handed to the reference on background lanes)."""
+    from tests.refpool import RefPool
+
+    pool = RefPool()
+    items = getattr(request.config, "_refjob_items", [])
+    wanted, registry = [], {}
+    for it in items:
+        registry.update(getattr(it.module, "REF_JOBS", {}))
+        for k in it.get_closest_marker("refjob").args:
+            if k not in wanted:
+                wanted.append(k)
+    if wanted:
+        import torch
+
+        hip_ = request.getfixturevalue("hip")
+        dev = torch.device("cuda", 0)
+        t0 = time.time()
+        starters = []  # (a starter may serve several keys: it runs once)
+        for k in sorted(wanted, key=lambda k: registry[k][0]):
+            if registry[k][1] not in starters:
+                starters.append(registry[k][1])
+        for fn in starters:
+            fn(pool, hip_, dev)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        pool.start()
+        pool.setup_s = time.time() - t0
+    yield pool
+    if pool.timings:
+        sys.stderr.write("\n[refpool] reference-CPU legs (s): " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(pool.timings.items())) + f"; setup {getattr(pool, 'setup_s', 0):.1f}\n")
+    pool.close()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _refpool_autostart(request):
+    """start the background reference jobs before the first test of a session that will need them"""
+    if getattr(request.config, "_refjob_items", []):
+        request.getfixturevalue("refpool")
+    yield

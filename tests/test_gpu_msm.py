@@ -313,20 +313,13 @@ def test_generated_points_are_distinct_multiples_of_g(hip):
     assert np.array_equal(pts, exp)
 
 
-@pytest.mark.parametrize("cname,logn,top", [("bn254", 26, 0x30644E72)])  # (config 3 runs whole: test_gpu_fullsize_configs.py)
-def test_msm_full_size_split_property(hip, cname, logn, top):
-    """BASELINE config 1 size (2^26 BN254) and the per-GPU share of config 3 (BLS12-381 2^28 over 8 GPUs = 2^25),
-    inputs resident in HBM: the size-independent property MSM(all) == MSM(first half) + MSM(second half), with the
-    halves combined by the reference's own ecadd, AND the reference CPU backend run on the full inputs."""
-    import ctypes
+def _full_size_inputs(dev, cname="bn254", logn=26, top=0x30644E72):
     import torch
     from icicle_amd import msm as M
     from icicle_amd._lib import lib, check
 
-    refc = ref.RefCurve(cname)
     L = M.LIMBS[cname]
     n = 1 << logn
-    dev = torch.device("cuda", 0)
     bases = torch.empty((n, 2 * L), dtype=torch.int32, device=dev)
     check(getattr(lib, f"{cname}_hip_generate_affine_points")(bases.data_ptr(), n, 12345, True, None))
     g = torch.Generator(device=dev)
@@ -334,6 +327,33 @@ def test_msm_full_size_split_property(hip, cname, logn, top):
     sc = torch.randint(-(2 ** 31), 2 ** 31, (n, 8), dtype=torch.int32, device=dev, generator=g)
     sc[:, 7] = torch.randint(0, top, (n,), dtype=torch.int32, device=dev, generator=g)
     torch.cuda.synchronize()
+    return sc, bases
+
+
+def _job_full_size(pool, hip, dev):
+    """the reference CPU backend on the FULL 2^26 inputs (BASELINE configs[1] says "bit-exact vs CPU": compared, not inferred);
+    a background job of tests/refpool.py"""
+    sc, bases = _full_size_inputs(dev)
+    pool.submit_msm("bn254_26_uniform", "bn254", np.ascontiguousarray(sc.cpu().numpy().view(np.uint32)), np.ascontiguousarray(bases.cpu().numpy().view(np.uint32)))
+
+
+REF_JOBS = {"bn254_26_uniform": (4, _job_full_size)}
+
+
+@pytest.mark.refjob("bn254_26_uniform", order=15)
+@pytest.mark.parametrize("cname,logn,top", [("bn254", 26, 0x30644E72)])  # (config 3 runs whole: test_gpu_fullsize_configs.py)
+def test_msm_full_size_split_property(hip, refpool, cname, logn, top):
+    """BASELINE config 1 size (2^26 BN254), inputs resident in HBM: the size-independent property MSM(all) == MSM(first half) +
+    MSM(second half), with the halves combined by the reference's own ecadd, AND the reference CPU backend run on the full inputs."""
+    import ctypes
+    import torch
+    from icicle_amd import msm as M
+
+    refc = ref.RefCurve(cname)
+    L = M.LIMBS[cname]
+    n = 1 << logn
+    dev = torch.device("cuda", 0)
+    sc, bases = _full_size_inputs(dev, cname, logn, top)
 
     def run(lo, hi):
         cfg = hip.MSMConfig.default()
@@ -346,11 +366,8 @@ def test_msm_full_size_split_property(hip, cname, logn, top):
     getattr(refc.lib, f"{cname}_ecadd")(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), ctypes.c_void_p(s.ctypes.data))
     assert np.array_equal(refc.to_affine(full), refc.to_affine(s.reshape(1, 3 * L)))
     assert refc.is_on_curve(full[0])
-    # ... and the byte compare itself: the reference CPU backend on the FULL inputs (about a minute on the GPU box's
-    # 256 host cores; BASELINE configs[1] says "bit-exact vs CPU", so it is compared, not inferred)
-    hs = np.ascontiguousarray(sc.cpu().numpy().view(np.uint32))
-    hb = np.ascontiguousarray(bases.cpu().numpy().view(np.uint32))
-    exp = refc.msm(hs, hb)
+    del sc, bases
+    exp = refpool.result("bn254_26_uniform")  # ... and the byte compare itself: the reference on the full inputs
     assert np.array_equal(refc.to_affine(full), refc.to_affine(exp)), f"{cname} 2^{logn}: GPU result differs from the reference CPU backend"
     assert refc.projective_eq(full[0], exp[0])
 

@@ -10,6 +10,8 @@
   the overflow-segment path at full size.
 
 tools/perf_matrix.py distributions times the same inputs (profiles/r04_perf_matrix.txt)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -47,8 +49,20 @@ def make_inputs(dist, logn, dev, seed=26):
     return sc, bases
 
 
+def _host(t):
+    return np.ascontiguousarray(t.cpu().numpy().view(np.uint32))
+
+
+def _job_dist(dist):
+    def start(pool, hip, dev):
+        sc, bases = make_inputs(dist, 26, dev)
+        pool.submit_msm(f"bn254_26_{dist}", "bn254", _host(sc), _host(bases))
+    return start
+
+
+@pytest.mark.refjob("bn254_26_period100", "bn254_26_skewed", order=20)
 @pytest.mark.parametrize("dist", ["period100", "skewed"])
-def test_bn254_2_26_other_distributions_vs_reference(hip, dist):
+def test_bn254_2_26_other_distributions_vs_reference(hip, refpool, dist):
     import torch
     from icicle_amd import msm as M
 
@@ -62,9 +76,95 @@ def test_bn254_2_26_other_distributions_vs_reference(hip, dist):
     out = np.zeros((1, 24), dtype=np.uint32)
     M.msm("bn254", sc.data_ptr(), bases.data_ptr(), hip.MSMConfig.default(), results=out, msm_size=1 << logn)
     assert refc.is_on_curve(out[0])
-    hs = np.ascontiguousarray(sc.cpu().numpy().view(np.uint32))
-    hb = np.ascontiguousarray(bases.cpu().numpy().view(np.uint32))
     del sc, bases
-    exp = refc.msm(hs, hb)
+    exp = refpool.result(f"bn254_26_{dist}")  # the reference CPU backend on the full inputs (background job, tests/refpool.py)
     assert np.array_equal(refc.to_affine(out), refc.to_affine(exp)), f"BN254 2^{logn} ({dist}): GPU result differs from the reference CPU backend"
     assert refc.projective_eq(out[0], exp[0])
+
+
+# ---- the AUTO-selected mixed-width plans (VERDICT r05 missing #4 / item 1a). From 2^23 terms up make_plan (msm_plan.h) picks window
+# widths that add up to the scalar bits with the negate-if-top-bit trick (cpu_msm.hpp:259-314): 2^23 / 2^24 / 2^25 BN254 run 14 / 13 /
+# 13 windows, some one bit narrower. Rounds 1-5 compared such plans with the reference only when FORCED at 5000 terms, at 2^26 and on
+# BLS12-381 shards; here config.c = 0 at exactly those sizes, full inputs, against the reference CPU backend.
+AUTO_SIZES = [23, 24, 25]
+
+
+def _job_auto(logn):
+    def start(pool, hip, dev):
+        sc, bases = make_inputs("uniform", logn, dev, seed=600 + logn)
+        pool.submit_msm(f"bn254_auto_{logn}", "bn254", _host(sc), _host(bases))
+    return start
+
+
+@pytest.mark.refjob(*[f"bn254_auto_{k}" for k in AUTO_SIZES], order=10)
+@pytest.mark.parametrize("logn", AUTO_SIZES)
+def test_bn254_auto_mixed_width_plans_vs_reference(hip, refpool, logn):
+    import torch
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib
+
+    refc = ref.RefCurve("bn254")
+    dev = torch.device("cuda", 0)
+    sc, bases = make_inputs("uniform", logn, dev, seed=600 + logn)
+    n = 1 << logn
+    cfg = hip.MSMConfig.default()
+    assert cfg.c == 0 and cfg.precompute_factor == 1
+    # the plan the library picks for this call must BE a mixed-width one (otherwise this test would not test what it says)
+    plan = (ctypes.c_int * 8)()
+    assert lib.icicle_hip_msm_plan_info(n, 254, ctypes.byref(cfg), 0, plan) == 0
+    c, nwin, n_lo, negate = plan[0], plan[1], plan[2], plan[3]
+    assert negate == 1 and 0 < n_lo < nwin and n_lo * (c - 1) + (nwin - n_lo) * c == 254, list(plan)
+    out = np.zeros((1, 24), dtype=np.uint32)
+    M.msm("bn254", sc.data_ptr(), bases.data_ptr(), cfg, results=out, msm_size=n)
+    # the same MSM with the result left on the device (k_final instead of the host-side window combine)
+    cfg_d = hip.MSMConfig.default()
+    cfg_d.are_results_on_device = True
+    d_out = torch.zeros(24, dtype=torch.int32, device=dev)
+    M.msm("bn254", sc.data_ptr(), bases.data_ptr(), cfg_d, results=d_out.data_ptr(), msm_size=n)
+    torch.cuda.synchronize()
+    out_d = d_out.cpu().numpy().view(np.uint32).reshape(1, 24)
+    del sc, bases
+    assert refc.is_on_curve(out[0]) and refc.is_on_curve(out_d[0])
+    exp = refpool.result(f"bn254_auto_{logn}")
+    assert np.array_equal(refc.to_affine(out), refc.to_affine(exp)), f"BN254 2^{logn}, auto plan {list(plan)[:4]}: GPU result differs from the reference CPU backend"
+    assert np.array_equal(refc.to_affine(out_d), refc.to_affine(exp)), f"BN254 2^{logn}, auto plan, device-resident result"
+    assert refc.projective_eq(out[0], exp[0])
+
+
+def _job_forced22(pool, hip, dev):
+    sc, bases = make_inputs("skewed", 22, dev, seed=2222)
+    pool.submit_msm("bn254_forced_22_skewed", "bn254", _host(sc), _host(bases))
+
+
+@pytest.mark.refjob("bn254_forced_22_skewed", order=5)
+def test_bn254_2_22_forced_mixed_plan_skewed_vs_reference(hip, refpool):
+    """hip_msm_windows-forced mixed plans at 2^22 (below the size the model picks them at) on the Rust suite's skewed mix: ~23 %
+    ones / ~14 % zeros, so bucket 1 of window 0 takes ~10^6 points (overflow segments) while the negation trick flips the rest"""
+    import torch
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib
+
+    refc = ref.RefCurve("bn254")
+    dev = torch.device("cuda", 0)
+    sc, bases = make_inputs("skewed", 22, dev, seed=2222)
+    exp = None
+    for nwin in (13, 14, 15):
+        ext = lib.create_config_extension()
+        lib.config_extension_set_int(ext, b"hip_msm_windows", nwin)
+        try:
+            cfg = hip.MSMConfig.default()
+            cfg.ext = ext
+            out = np.zeros((1, 24), dtype=np.uint32)
+            M.msm("bn254", sc.data_ptr(), bases.data_ptr(), cfg, results=out, msm_size=1 << 22)
+        finally:
+            lib.destroy_config_extension(ext)
+        if exp is None:
+            exp = refpool.result("bn254_forced_22_skewed")
+        assert np.array_equal(refc.to_affine(out), refc.to_affine(exp)), f"BN254 2^22 skewed, {nwin} mixed-width windows"
+        assert refc.is_on_curve(out[0])
+
+
+REF_JOBS = {"bn254_26_period100": (5, _job_dist("period100")), "bn254_26_skewed": (6, _job_dist("skewed")),
+            "bn254_forced_22_skewed": (1, _job_forced22)}
+for _k in AUTO_SIZES:
+    REF_JOBS[f"bn254_auto_{_k}"] = (2, _job_auto(_k))

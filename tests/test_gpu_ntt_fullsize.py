@@ -8,49 +8,63 @@ from oracle import pyref, ref
 pytestmark = pytest.mark.gpu
 
 
-def test_babybear_config2_full_size_vs_oracle(hip):
+def _config2_inputs(dev):
+    """x (the forward batch) and w (an independent batch for the inverse compare): 64 rows of 2^24 uniform elements each"""
+    import torch
+
+    F = pyref.BABYBEAR
+    g = torch.Generator(device=dev)
+    g.manual_seed(2024)
+    x = torch.randint(0, F.p, (64, 1 << 24), dtype=torch.int32, device=dev, generator=g)
+    w = torch.randint(0, F.p, (64, 1 << 24), dtype=torch.int32, device=dev, generator=g)
+    return x, w
+
+
+def _job_config2(pool, hip, dev):
+    """reference legs of config 2 in a worker process (tests/refpool.py; ~30 s per 64-row direction on 256 host threads plus
+    the 2^24 domain): forward of x, inverse of w, and the coset kNR forward / kRN inverse chain on row 2 of x"""
+    from icicle_amd import ntt as N
+
+    x, w = _config2_inputs(dev)
+    pool.submit_ntt("config2_fwd", "babybear", x.cpu().numpy().view(np.uint32).reshape(-1), 24, 0, batch=64, lane="ntt_a")
+    pool.submit_ntt("config2_inv", "babybear", w.cpu().numpy().view(np.uint32).reshape(-1), 24, 1, batch=64, lane="ntt_a")
+    pool.submit_ntt("config2_coset", "babybear", x[2].cpu().numpy().view(np.uint32), 24, 0, ordering=N.kNR, coset_gen=31, chain=[(1, N.kRN, 31)], lane="ntt_a")
+
+
+@pytest.mark.refjob("config2_fwd", "config2_inv", "config2_coset", order=30)
+def test_babybear_config2_full_size_vs_oracle(hip, refpool):
     """BASELINE config 2 itself -- BabyBear 2^24 x 64, device resident -- byte-compared with the reference CPU
     backend (memcmp rule: icicle/tests/test_mod_arithmetic_api.h:694): all 64 rows of the kNN forward output, all 64 rows of
     a kNN inverse, and one row each of a coset kNR forward and a kRN inverse at the same size (all of them 3-pass plans)."""
     import torch
     from icicle_amd import ntt as N
 
-    F = pyref.BABYBEAR
     logn, rows = 24, 64
     n = 1 << logn
     N.init_domain("babybear", N.get_root_of_unity("babybear", n))
-    rf = ref.RefNttField("babybear")
-    rf.init_domain(rf.get_root_of_unity(n))
     try:
         dev = torch.device("cuda", 0)
-        g = torch.Generator(device=dev)
-        g.manual_seed(2024)
-        x = torch.randint(0, F.p, (rows, n), dtype=torch.int32, device=dev, generator=g)
+        x, w = _config2_inputs(dev)
         y = torch.empty_like(x)
         cfg = hip.NTTConfigU32.default()
         cfg.batch_size, cfg.is_async = rows, True
         N.ntt("babybear", x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n)
         torch.cuda.synchronize()
-        # ALL 64 forward rows and ALL 64 inverse rows against the reference (VERDICT r04 item 8; ~30 s per direction on the
-        # GPU box's 256 host threads, as bench.py's cpu_baseline leg shows). The inverse is fed the REFERENCE's forward output of an
+        # ALL 64 forward rows and ALL 64 inverse rows against the reference (VERDICT r04 item 8). The inverse is fed an
         # independent batch w (not x's own transform), so it is a comparison of its own and not a round trip.
-        hx = np.ascontiguousarray(x.cpu().numpy().view(np.uint32)).reshape(-1)
         hy = np.ascontiguousarray(y.cpu().numpy().view(np.uint32)).reshape(-1)
-        exp = rf.ntt(hx, n, 0, batch=rows)
-        assert np.array_equal(hy, exp), "forward kNN 2^24 x 64: rows differ from the reference CPU backend"
+        assert np.array_equal(hy, refpool.result("config2_fwd")), "forward kNN 2^24 x 64: rows differ from the reference CPU backend"
         del hy
-        w = torch.randint(0, F.p, (rows, n), dtype=torch.int32, device=dev, generator=g)
         N.ntt("babybear", w.data_ptr(), N.INVERSE, cfg, out=y.data_ptr(), size=n)
         torch.cuda.synchronize()
-        hw = np.ascontiguousarray(w.cpu().numpy().view(np.uint32)).reshape(-1)
-        assert np.array_equal(np.ascontiguousarray(y.cpu().numpy().view(np.uint32)).reshape(-1), rf.ntt(hw, n, 1, batch=rows)), "inverse kNN 2^24 x 64: rows differ from the reference CPU backend"
-        del hw, w
+        assert np.array_equal(np.ascontiguousarray(y.cpu().numpy().view(np.uint32)).reshape(-1), refpool.result("config2_inv")), "inverse kNN 2^24 x 64: rows differ from the reference CPU backend"
+        del w
+        refpool.drop("config2_fwd"), refpool.drop("config2_inv")
         # inverse of the forward output, in place: the round trip
         N.ntt("babybear", x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n)
         N.ntt("babybear", y.data_ptr(), N.INVERSE, cfg, out=y.data_ptr(), size=n)
         torch.cuda.synchronize()
         assert torch.equal(x, y)
-        del exp, hx
         # coset + kNR forward, kRN inverse on a 4-row batch of the same size; row 2 against the oracle
         cfg4 = hip.NTTConfigU32.default()
         cfg4.batch_size, cfg4.is_async = 4, True
@@ -59,18 +73,16 @@ def test_babybear_config2_full_size_vs_oracle(hip):
         y4 = torch.empty((4, n), dtype=torch.int32, device=dev)
         N.ntt("babybear", x[:4].data_ptr(), N.FORWARD, cfg4, out=y4.data_ptr(), size=n)
         torch.cuda.synchronize()
-        row = np.ascontiguousarray(x[2].cpu().numpy().view(np.uint32))
-        e = rf.ntt(row, n, 0, ordering=N.kNR, coset_gen=31)
+        e, back = refpool.result("config2_coset")
         assert np.array_equal(y4[2].cpu().numpy().view(np.uint32), e), "coset kNR forward 2^24"
         cfg4.ordering = N.kRN
         z4 = torch.empty_like(y4)
         N.ntt("babybear", y4.data_ptr(), N.INVERSE, cfg4, out=z4.data_ptr(), size=n)
         torch.cuda.synchronize()
-        assert np.array_equal(z4[2].cpu().numpy().view(np.uint32), rf.ntt(e, n, 1, ordering=N.kRN, coset_gen=31))
+        assert np.array_equal(z4[2].cpu().numpy().view(np.uint32), back)
         assert torch.equal(z4, x[:4])
     finally:
         N.release_domain("babybear")
-        rf.release_domain()
 
 
 @pytest.mark.parametrize("fname", ["babybear"])  # (KoalaBear's two-adicity is 24)
@@ -143,38 +155,50 @@ def test_transforms_beyond_2_24_against_the_four_step_identity(hip, fname, logn)
         N.release_domain(fname)
 
 
+def _big_input(dev, logn):
+    import torch
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + logn)
+    return torch.randint(0, pyref.BABYBEAR.p, (1 << logn,), dtype=torch.int32, device=dev, generator=g)
+
+
+def _job_big(pool, hip, dev):
+    for logn in (25, 27):  # the worker pays for a domain of that size: tens of seconds at 2^25, about two minutes at 2^27
+        pool.submit_ntt(f"bb_fwd_{logn}", "babybear", _big_input(dev, logn).cpu().numpy().view(np.uint32), logn, 0, lane="ntt_b")
+
+
+@pytest.mark.refjob("bb_fwd_25", "bb_fwd_27", order=60)
 @pytest.mark.parametrize("logn", [25, 27])
-def test_transforms_beyond_2_24_vs_oracle(hip, logn):
-    """VERDICT r03 (parity gap 2): the 512-row column passes of 2^25 and the 1024-thread / 32-column variant of 2^27 compared
-    with the reference CPU backend itself, not only with this backend's four-step composition: one forward kNN row `memcmp`'d,
-    and the inverse of the reference's output must give the input back. (The CPU side pays for a domain of that size: tens of
-    seconds at 2^25, about two minutes at 2^27 -- BabyBear's largest transform.)"""
+def test_transforms_beyond_2_24_vs_oracle(hip, refpool, logn):
+    """VERDICT r03 (parity gap 2): the 512-row column passes of 2^25 and the plan of 2^27 compared with the reference CPU
+    backend itself, not only with this backend's four-step composition: one forward kNN row `memcmp`'d, and the inverse of the
+    reference's output must give the input back. (The CPU side pays for a domain of that size -- tens of seconds at 2^25,
+    about two minutes at 2^27, BabyBear's largest transform: a background job of tests/refpool.py.)"""
     import torch
     from icicle_amd import ntt as N
 
-    F = pyref.BABYBEAR
     n = 1 << logn
     N.init_domain("babybear", N.get_root_of_unity("babybear", n))
-    rf = ref.RefNttField("babybear")
-    rf.init_domain(rf.get_root_of_unity(n))
     try:
         dev = torch.device("cuda", 0)
-        g = torch.Generator(device=dev)
-        g.manual_seed(1000 + logn)
-        x = torch.randint(0, F.p, (n,), dtype=torch.int32, device=dev, generator=g)
+        x = _big_input(dev, logn)
         y = torch.empty_like(x)
         cfg = hip.NTTConfigU32.default()
         cfg.is_async = True
         N.ntt("babybear", x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n)
         torch.cuda.synchronize()
-        hx = np.ascontiguousarray(x.cpu().numpy().view(np.uint32))
-        exp = rf.ntt(hx, n, 0)
+        exp = np.array(refpool.result(f"bb_fwd_{logn}"))
         assert np.array_equal(y.cpu().numpy().view(np.uint32), exp), f"forward 2^{logn}: differs from the reference CPU backend"
         z = torch.empty_like(x)
         ye = torch.from_numpy(exp.view(np.int32)).to(dev)
         N.ntt("babybear", ye.data_ptr(), N.INVERSE, cfg, out=z.data_ptr(), size=n)
         torch.cuda.synchronize()
         assert torch.equal(z, x)
+        refpool.drop(f"bb_fwd_{logn}")
     finally:
         N.release_domain("babybear")
-        rf.release_domain()
+
+
+REF_JOBS = {"config2_fwd": (10, _job_config2), "config2_inv": (10, _job_config2), "config2_coset": (10, _job_config2),
+            "bb_fwd_25": (20, _job_big), "bb_fwd_27": (20, _job_big)}
