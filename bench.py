@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--cpu-msm-log2", type=int, default=0, help="CPU baseline MSM size; 0 = the full workload when the host has >= 64 cores, else 2^20")
     ap.add_argument("--cpu-ntt-log2", type=int, default=0, help="CPU baseline NTT size; 0 = the full size when the host has >= 64 cores, else 2^20")
     ap.add_argument("--no-inproc", action="store_true", help="N > 1: skip the single-process hip_num_devices=N measurement")
+    ap.add_argument("--no-shard-extras", action="store_true", help="N = 1: skip the config3_shard / config4_shard objects (per-GPU shares of BASELINE configs[3] and [4])")
     ap.add_argument("--inproc-only", action="store_true", help=argparse.SUPPRESS)  # internal: the launcher's second leg
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: one 2^size MSM per GPU (the N shards form one 2^size*N MSM); strong: ONE 2^size MSM cut over the N GPUs")
@@ -112,6 +113,15 @@ class GlooViaHost:
 
     def destroy_process_group(self):
         self._d.destroy_process_group()
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def get_backend(self):
+        return self._d.get_backend()
+
+    def all_gather_object(self, out, obj):
+        self._d.all_gather_object(out, obj)
 
 
 def visible_gpus():
@@ -172,6 +182,19 @@ def launch_self(args):
         except Exception as e:  # the second leg never costs the primary line
             out["inproc"] = {"error": repr(e)}
     print(json.dumps(out))
+
+
+def _inproc_collectives(lib):
+    """what the in-library communicator layer saw (icicle_hip_collectives_info): library version, devices asked for, ncclCommCount,
+    rank order verified, communicator sets created"""
+    v = (ctypes.c_int * 5)()
+    try:
+        if lib.icicle_hip_collectives_info(v, 5) != 0:
+            return {"error": "icicle_hip_collectives_info failed"}
+    except Exception as e:
+        return {"error": repr(e)}
+    return {"nccl_version_code": v[0], "devices_requested": v[1], "nccl_comm_count": v[2], "ranks_and_count_as_expected": {1: True, 0: False}.get(v[3]),
+            "communicator_sets_created": v[4]}
 
 
 def inproc_main(args):
@@ -260,6 +283,10 @@ def inproc_main(args):
         th = tot.cpu().numpy().view(np.uint32)
         res["result_ok"] = bool(not th[16:24].any() and w[16:24].any())  # sum - result == identity, and the result itself is a finite point
         del bases, scalars, parts
+    except Exception as e:  # the MSM leg's failure keeps the NTT leg below
+        res["error"] = "msm leg: " + repr(e)
+    res["collectives"] = _inproc_collectives(lib)
+    try:
         if not args.no_ntt:
             logn, rows = args.ntt_log2, args.ntt_batch * G
             nn = 1 << logn
@@ -294,9 +321,10 @@ def inproc_main(args):
             lib.destroy_config_extension(ext2)
             N.release_domain("babybear")
     except Exception as e:
-        res["error"] = repr(e)
+        res["ntt"] = {"error": repr(e)}
     finally:
         lib.destroy_config_extension(ext)
+    res["collectives_after_ntt"] = _inproc_collectives(lib)
     print(json.dumps(res))
 
 
@@ -381,6 +409,29 @@ def main():
     lib.icicle_hip_kernel_timing(0, True, ctypes.byref(tot), ctypes.byref(cnt))
     lib.icicle_hip_enable_kernel_timing(False)
     msm_ms = dt / args.steps * 1e3
+    # ---- what the collectives layer saw: recorded in the line, and the gathered result must be the SAME bytes
+    # on every rank (each rank sums the all-gathered partials itself: same inputs, same deterministic kernel)
+    collectives = {"world_size": world, "backend": None, "rccl_version": None}
+    try:
+        collectives["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:
+        collectives["rccl_version"] = f"unavailable: {e!r}"
+    if world > 1:
+        try:
+            collectives["world_size"] = dist.get_world_size()
+            collectives["backend"] = dist.get_backend()
+            mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(),
+                    "icicle_device": runtime.get_active_device() if hasattr(runtime, "get_active_device") else None}
+            seen = [None] * world
+            dist.all_gather_object(seen, mine)
+            collectives["ranks"] = seen
+            allres = torch.empty((world, res.numel()), dtype=res.dtype, device=dev)
+            dist.all_gather_into_tensor(allres.reshape(-1), res.contiguous().reshape(-1))
+            same = torch.tensor([1.0 if bool((allres == res.reshape(1, -1)).all()) else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            collectives["result_identical_on_all_ranks"] = bool(same.item() == 1.0)
+        except Exception as e:
+            collectives["error"] = repr(e)
     # bucket accumulation of ONE MSM = the sum of its k_accumulate launches (one per window group of the pipelined schedule)
     acc_ms = tot.value / max(1, args.steps)
     acc_launches = cnt.value
@@ -473,7 +524,10 @@ def main():
                                + "batch 1, inputs resident in HBM, precompute_factor 1",
                    "sharding": "bases/scalars sharded per rank; RCCL all_gather of partial sums + projective add"},
         "roofline": roofline,
+        "collectives": collectives,
     }
+    if world > 1 and collectives.get("result_identical_on_all_ranks") is False:
+        out["error"] = "the all-gathered MSM result differs between ranks"
     if REHEARSAL:
         out["rehearsal"] = f"{world} ranks sharing GPU 0, collectives over gloo on host copies: timings mean nothing"
 
@@ -573,6 +627,24 @@ def main():
                          "frac": ntt_bytes / (ntt_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": ntt_call_ms, "launches": cnt.value},
         }
+        # VALU-issue roof beside the HBM fraction: the butterfly arithmetic of the passes with every operand in
+        # registers, measured in this run. Unit: 16 elements through one 8-stage pass (2 radix-16 register rounds + 16 products with
+        # the factor behind the pass); a direction is rows * N * log2(N) / 128 of them.
+        try:
+            rate = ctypes.c_double()
+            check(lib.icicle_hip_ubench_ntt_pass(0, ctypes.byref(rate)), "ubench_ntt_pass")
+            units = rows * nn * logn / 128.0
+            alu_frac = units / (ntt_call_ms * 1e-3) / rate.value
+            hbm_copy_frac = ntt_bytes * ((logn + 7) // 8) / (ntt_call_ms * 1e-3) / 1e9 / 6290.0
+            out["ntt"]["roofline"]["alu"] = {
+                "pass_units": units, "pass_units_per_s": units / (ntt_call_ms * 1e-3), "roof": rate.value, "frac": alu_frac,
+                "roof_ms_per_direction": units / rate.value * 1e3,
+                "roof_is": "16-element x 8-stage pass units/s, operands in registers, measured in this run (icicle_hip_ubench_ntt_pass: k_ntt_fast's own ntt_stages code)",
+                "hbm_passes": (logn + 7) // 8, "hbm_traffic_frac_of_measured_copy": hbm_copy_frac,
+                "binds": "alu" if alu_frac >= hbm_copy_frac else "hbm",
+                "binds_note": "frac = share of the VALU-issue roof; hbm_traffic_frac_of_measured_copy = (passes x algorithmic bytes) / time / 6.29 TB/s (the guide's measured float4 copy)"}
+        except Exception as e:
+            out["ntt"]["roofline"]["alu"] = {"error": repr(e)}
         if logn == 24 and rows == 64 and "ntt_babybear_2^24x64_one_direction" in pmc:
             if pmc.get("ntt_sources_sha16") == ntt_sha and ntt_sha:
                 m = pmc["ntt_babybear_2^24x64_one_direction"]
@@ -625,6 +697,99 @@ def main():
         finally:
             split_done.set()
             watchdog.cancel()
+
+    # ---------------- N = 1: the per-GPU shares of BASELINE configs[3] and [4] ----------------
+    # configs[3] = BLS12-381 MSM 2^28 over 8 GPUs -> 2^25 terms per GPU; configs[4] = KoalaBear NTT 2^22 x 1024 over 8 GPUs -> 128 rows
+    # per GPU. Same measurement as the headline objects (hipEvents on the launch stream, roofs measured in this run); reproducible
+    # from profiles/r06_config3_shard_* / r06_config4_shard_*. Never costs the primary line.
+    if world == 1 and not args.no_shard_extras and args.size_log2 == 26 and args.ntt_log2 == 24:
+        try:
+            n3 = 1 << 25
+            b3 = torch.empty((n3, 24), dtype=torch.int32, device=dev)
+            check(lib.bls12_381_hip_generate_affine_points(b3.data_ptr(), n3, 3, True, None), "generate")
+            g3 = torch.Generator(device=dev)
+            g3.manual_seed(381)
+            s3 = torch.randint(-(2 ** 31), 2 ** 31, (n3, 8), dtype=torch.int32, device=dev, generator=g3)
+            s3[:, 7] = torch.randint(0, 0x73EDA753, (n3,), dtype=torch.int32, device=dev, generator=g3)
+            r3 = torch.empty(36, dtype=torch.int32, device=dev)
+            c3 = MSMConfig.default()
+            c3.is_async = True
+
+            def step3():
+                M.msm("bls12_381", s3.data_ptr(), b3.data_ptr(), c3, results=r3.data_ptr(), msm_size=n3)
+
+            step3()
+            lib.icicle_hip_enable_kernel_timing(True)
+            for which in (0, 2, 3):
+                lib.icicle_hip_kernel_timing(which, True, ctypes.byref(tot), ctypes.byref(cnt))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step3()
+            torch.cuda.synchronize()
+            dt3 = (time.perf_counter() - t0) / args.steps * 1e3
+            ph3 = {}
+            for which, name in ((0, "accumulate"), (2, "sort_exposed_ms"), (3, "tail_exposed_ms")):
+                lib.icicle_hip_kernel_timing(which, True, ctypes.byref(tot), ctypes.byref(cnt))
+                ph3[name] = tot.value / max(1, args.steps)
+            lib.icicle_hip_enable_kernel_timing(False)
+            check(lib.icicle_hip_msm_plan(n3, 255, ctypes.byref(c3), ctypes.byref(pc), ctypes.byref(pw)), "msm_plan")
+            check(lib.icicle_hip_ubench_mixed_add(1, ctypes.byref(rate)), "ubench_mixed_add")
+            bytes3 = n3 * (32 + 96) + 144
+            madds3 = n3 * pw.value
+            out["config3_shard"] = {
+                "workload": "BLS12-381 G1 MSM, 2^25 terms = one GPU's share of BASELINE configs[3] (2^28 over 8 GPUs), inputs resident in HBM",
+                "ms_per_msm": dt3, "steps": args.steps, "phases_ms": {**ph3, "whole_msm": dt3},
+                "kernel": "k_accumulate<bls12_381_g1>", "hbm": {"algorithmic_bytes": bytes3, "achieved_GBps": bytes3 / (ph3["accumulate"] * 1e-3) / 1e9, "frac": bytes3 / (ph3["accumulate"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "alu": {"window_bits": pc.value, "windows": pw.value, "mixed_adds": madds3, "mixed_adds_per_s": madds3 / (ph3["accumulate"] * 1e-3), "roof": rate.value,
+                        "frac": madds3 / (ph3["accumulate"] * 1e-3) / rate.value, "roof_is": "BLS12-381 XYZZ mixed adds/s, operands in registers, measured in this run (icicle_hip_ubench_mixed_add(1))"}}
+            del b3, s3, r3
+            torch.cuda.empty_cache()
+            check(lib.icicle_hip_release_workspace(), "release_workspace")
+        except Exception as e:
+            out["config3_shard"] = {"error": repr(e)}
+        try:
+            l4, rows4 = 22, 128
+            n4 = 1 << l4
+            N.init_domain("koalabear", N.get_root_of_unity("koalabear", n4))
+            g4 = torch.Generator(device=dev)
+            g4.manual_seed(422)
+            x4 = torch.randint(0, 0x7F000001, (rows4, n4), dtype=torch.int32, device=dev, generator=g4)
+            y4, z4 = torch.empty_like(x4), torch.empty_like(x4)
+            c4 = NTTConfigU32.default()
+            c4.batch_size, c4.is_async = rows4, True
+
+            def step4():
+                N.ntt("koalabear", x4.data_ptr(), N.FORWARD, c4, out=y4.data_ptr(), size=n4)
+                N.ntt("koalabear", y4.data_ptr(), N.INVERSE, c4, out=z4.data_ptr(), size=n4)
+
+            lib.icicle_hip_enable_kernel_timing(True)
+            for _ in range(4):
+                step4()
+            lib.icicle_hip_kernel_timing(1, True, ctypes.byref(tot), ctypes.byref(cnt))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step4()
+            torch.cuda.synchronize()
+            dt4 = (time.perf_counter() - t0) / args.steps * 1e3
+            lib.icicle_hip_kernel_timing(1, True, ctypes.byref(tot), ctypes.byref(cnt))
+            lib.icicle_hip_enable_kernel_timing(False)
+            call4 = tot.value / max(1, cnt.value)
+            bytes4 = 2 * rows4 * n4 * 4
+            check(lib.icicle_hip_ubench_ntt_pass(1, ctypes.byref(rate)), "ubench_ntt_pass")
+            units4 = rows4 * n4 * l4 / 128.0
+            out["config4_shard"] = {
+                "workload": "KoalaBear NTT 2^22 x 128 rows = one GPU's share of BASELINE configs[4] (1024 rows over 8 GPUs), kNN forward + inverse, device resident",
+                "ms_per_round_trip": dt4, "ms_per_direction": call4, "ntt_per_s": 2 * rows4 / (dt4 * 1e-3), "roundtrip_ok": bool(torch.equal(x4, z4)), "steps": args.steps,
+                "kernel": "k_ntt_fast<koalabear> (the 3 pass launches of one direction)",
+                "hbm": {"algorithmic_bytes": bytes4, "achieved_GBps": bytes4 / (call4 * 1e-3) / 1e9, "frac": bytes4 / (call4 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "alu": {"pass_units": units4, "pass_units_per_s": units4 / (call4 * 1e-3), "roof": rate.value, "frac": units4 / (call4 * 1e-3) / rate.value,
+                        "roof_is": "16-element x 8-stage pass units/s, operands in registers, measured in this run (icicle_hip_ubench_ntt_pass(1))"}}
+            del x4, y4, z4
+            N.release_domain("koalabear")
+        except Exception as e:
+            out["config4_shard"] = {"error": repr(e)}
 
     # ---------------- CPU baseline: the reference CPU backend on this box's host cores ----------------
     # On a host with >= 64 cores (the GPU boxes have 256) the baseline is timed on the REAL workload: the full 2^26 MSM

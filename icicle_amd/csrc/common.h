@@ -80,6 +80,22 @@ namespace icicle_hip {
     return a.type == hipMemoryTypeDevice;
   }
 
+  // true when [p, p + bytes) provably runs past the END of the device allocation that holds p (hipMemGetAddressRange). Host memory
+  // and pointers the runtime cannot place give false: only a provable overrun is refused. (A sub-allocating caller -- a caching
+  // allocator -- is bounded by ITS block, so this is a lower bound on safety, not a guarantee.)
+  inline bool overruns_device_allocation(const void* p, size_t bytes)
+  {
+    if (!points_to_device_memory(p)) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    const uintptr_t off = (uintptr_t)p - (uintptr_t)base;
+    return off > size || bytes > size - off;
+  }
+
   // opaque ConfigExtension (reference: include/icicle/config_extension.h:12-46)
   struct ConfigExt {
     std::unordered_map<std::string, std::variant<int, bool>> kv;
@@ -169,6 +185,10 @@ namespace icicle_hip {
     int (*GroupStart)();
     int (*GroupEnd)();
     const char* (*GetErrorString)(int);
+    // optional (diagnostics only: what the communicator layer saw, icicle_hip_collectives_info)
+    int (*CommCount)(void* comm, int* count);
+    int (*CommUserRank)(void* comm, int* rank);
+    int (*GetVersion)(int* version);
   };
   const RcclApi* rccl_api(); // entry points of the selected NCCL-ABI library (default librccl.so); nullptr when it cannot be loaded
   // One communicator per device slot of `devs` (ncclCommInitAll), created once per device list and cached. Collectives

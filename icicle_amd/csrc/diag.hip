@@ -5,9 +5,13 @@
 //   icicle_hip_ubench_gather     random 64-byte gathers per second (4 x 16 B loads per lane, the access pattern of
 //                                k_accumulate's base fetch) over a region of the given size; also the known-byte-count
 //                                kernel the FETCH_SIZE counter is calibrated on (tools/pmc_traffic.sh)
-// Neither touches user data. tools/ubench/msm_ubench.hip holds the wider design-decision sweeps.
+//   icicle_hip_ubench_ntt_pass   the arithmetic of one 8-stage NTT pass per second with every operand in registers: per 16 elements two
+//                                radix-16 register rounds (ntt_fast.hpp ntt_stages, the code of k_ntt_fast) and the 16 products with the
+//                                factor behind the pass -- the VALU-issue roof of a transform, no memory, no LDS
+// None touches user data. tools/ubench/msm_ubench.hip holds the wider design-decision sweeps.
 #include "common.h"
 #include "ec.hpp"
+#include "ntt_fast.hpp"
 
 namespace icicle_hip {
 
@@ -27,32 +31,31 @@ namespace icicle_hip {
     using E = EC<C>;
     using F = typename E::F;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    auto seed_fe = [&](uint32_t s) {
-      typename F::fe r;
-#pragma unroll
-      for (int i = 0; i < F::N; i++) {
-        s = diag_mix(s + i);
-        r.l[i] = s & RB_MASK;
-      }
-      r.l[F::N - 1] &= 0xfffff; // well below p
-      BF_SET_BOUND(r, 1);
-      return r;
-    };
+    // The loop is k_accumulate's own (msm_impl.hpp): an empty accumulator, a fresh operand every step -- built from two live
+    // words where the real kernel gathers it from HBM --, load_plain + cneg + madd, to_proj at the end. (Rounds 1-5 kept a
+    // seeded accumulator and the operand live across the addition: 18 registers more than the real kernel, 144 B of scratch at
+    // the same launch bounds -- a roof measured on a spilling kernel reads low.)
+    constexpr int PW = 2 * E::N32;
     typename E::XYZZ acc;
-    acc.x = seed_fe(t + seed), acc.y = seed_fe(t * 3 + seed), acc.zz = seed_fe(t + 5), acc.zzz = seed_fe(t + 9);
-    bool empty = false;
-    typename E::Aff p;
-    p.x = seed_fe(t + 11), p.y = seed_fe(t + 13);
+    bool empty = true;
+    uint32_t sx = diag_mix(t + seed), sy = diag_mix(t * 3 + seed + 13);
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
-      p.x.l[0] = (p.x.l[0] + 0x1234567u) & RB_MASK; // a different operand every step
-      p.y.l[1] ^= (uint32_t)it;
-      E::madd(acc, empty, E::cneg(p, (it & 1) != 0));
+      sx += 0x1234567u, sy ^= (uint32_t)(it + 1) * 0x9e3779b9u;
+      uint32_t w[PW];
+#pragma unroll
+      for (int k = 0; k < E::N32; k++) {
+        w[k] = sx + (uint32_t)k * 0x3c6ef37u;
+        w[E::N32 + k] = sy ^ ((uint32_t)k * 0x51ed27fu);
+      }
+      w[E::N32 - 1] &= 0x00ffffffu, w[PW - 1] &= 0x00ffffffu; // below p
+      E::madd(acc, empty, E::cneg(E::load_plain(w), (it & 1) != 0));
     }
-    uint32_t r = empty;
+    const typename E::Proj pr = E::to_proj(acc, empty);
+    uint32_t r = 0;
 #pragma unroll
     for (int i = 0; i < F::N; i++)
-      r ^= acc.x.l[i] ^ acc.y.l[i] ^ acc.zz.l[i] ^ acc.zzz.l[i];
+      r ^= pr.x.l[i] ^ pr.y.l[i] ^ pr.z.l[i];
     out[t] = r;
   }
 
@@ -71,6 +74,70 @@ namespace icicle_hip {
       acc.w += d.x;
     }
     out[t] = acc;
+  }
+
+  // One "pass unit" = 16 elements through an 8-stage pass: radix-16 round, radix-16 round, product with the inter-pass factor. Same
+  // block shape and register budget as the two-round k_ntt_fast instantiations (512 threads, 4 waves per SIMD).
+  template <class PR>
+  __global__ __launch_bounds__(512, 4) void k_diag_ntt_pass(uint32_t* __restrict__ out, int iters, uint32_t seed)
+  {
+    using S = SmallField<PR>;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x[16], w0[15], w1[15], wip[16];
+    uint32_t s = diag_mix(t + seed);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      s = diag_mix(s + i);
+      x[i] = s % PR::P;
+      s = diag_mix(s + 77);
+      wip[i] = s % PR::P;
+    }
+#pragma unroll
+    for (int i = 0; i < 15; i++) {
+      s = diag_mix(s + 3);
+      w0[i] = s % PR::P;
+      s = diag_mix(s + 5);
+      w1[i] = s % PR::P;
+    }
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+      ntt_stages<S, 4, false, true>(x, w0);
+      ntt_stages<S, 4, false, true>(x, w1);
+#pragma unroll
+      for (int m = 0; m < 16; m++)
+        x[m] = S::mul(x[m], wip[m]);
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      r ^= x[i];
+    out[t] = r;
+  }
+
+  template <class PR>
+  static icicle_error_t ntt_pass_bench(double* rate)
+  {
+    ICICLE_TRY(bind_current_device());
+    const int blocks = 256 * 16, iters = 512;
+    TempBuf o;
+    HIP_TRY(o.alloc((size_t)blocks * 512 * 4, nullptr), ICICLE_ALLOCATION_FAILED);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0), ICICLE_INVALID_ARGUMENT);
+    HIP_TRY(hipEventCreate(&e1), ICICLE_INVALID_ARGUMENT);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+      (void)hipEventRecord(e0, nullptr);
+      k_diag_ntt_pass<PR><<<blocks, 512>>>(o.as<uint32_t>(), iters, 11 + rep);
+      (void)hipEventRecord(e1, nullptr);
+      HIP_TRY(hipEventSynchronize(e1), ICICLE_SYNCHRONIZATION_FAILED);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *rate = (double)blocks * 512 * iters / (best * 1e-3);
+    return ICICLE_SUCCESS;
   }
 
   template <class C>
@@ -187,6 +254,19 @@ extern "C" icicle_error_t icicle_hip_ubench_mixed_add(int curve, double* adds_pe
   try {
     if (curve == 0) return madd_bench<bn254_g1>(adds_per_second);
     if (curve == 1) return madd_bench<bls12_381_g1>(adds_per_second);
+  } catch (...) {
+  }
+  return ICICLE_INVALID_ARGUMENT;
+}
+
+// field 0 = BabyBear, 1 = KoalaBear; *pass_units_per_second: one unit = 16 elements through one 8-stage pass (2 radix-16 register
+// rounds + 16 inter-pass products). A 2^24-point transform of 3 passes is 3 * 2^20 units per row.
+extern "C" icicle_error_t icicle_hip_ubench_ntt_pass(int field, double* pass_units_per_second)
+{
+  if (!pass_units_per_second) return ICICLE_INVALID_POINTER;
+  try {
+    if (field == 0) return ntt_pass_bench<babybear_params>(pass_units_per_second);
+    if (field == 1) return ntt_pass_bench<koalabear_params>(pass_units_per_second);
   } catch (...) {
   }
   return ICICLE_INVALID_ARGUMENT;

@@ -1179,101 +1179,157 @@ namespace icicle_hip {
   }
 
   // msm_precompute_bases: out[pf*i + j] = 2^(j*shift) * P_i  (cpu_msm.hpp:455-480), shift = c*wpf.
-  // One Jacobian doubling chain per base (dbl-2009-l, 2M + 5S) and ONE field inversion per thread: a thread walks `pt`
-  // bases, keeps the (pf-1)*pt Jacobian outputs (X, Y, Z and the running product of the Z's) in its scratch arrays and
-  // converts them with Montgomery's trick -- rounds 1-3 paid a Fermat inversion (~314 products, as much as 45 doublings) per
-  // OUTPUT point: 59 % of the kernel at pf = 8. What is left is the doublings themselves: ~254 (pf-1)/pf per base, ~960
-  // v_mad_u64_u32 each (profiles/r04_notes.md has the arithmetic: 2^24 bases x pf 4 = 3.1e12 mads = 135 ms at the issue roof).
-  constexpr int PRECOMP_MAX_OUT = 32; // outputs per thread held for the shared inversion
+  // Two kernels, neither with a private array (rounds 3-5 kept up to 32 Jacobian outputs per thread in dynamically indexed arrays:
+  // 4.7 - 14.5 KB of scratch per lane, which is what capped the resident waves and left the kernel at 211 ms for 2^24 x 4 against
+  // the 135 ms its doublings cost at the issue roof):
+  //   k_precompute_chains  one thread per base: the Jacobian doubling chain (dbl-2009-l, 2M + 5S per step, ~254 (pf-1)/pf steps per
+  //                        base, ~960 v_mad_u64_u32 each). After every `shift` doublings the point goes to memory: X and Y (reduced
+  //                        Montgomery words) into the table slot it will finally occupy, Z into a side buffer. Nothing is kept.
+  //   k_precompute_affine  Montgomery's trick over runs of PRECOMP_RUN consecutive table entries: prefix products of the Z's to a
+  //                        second side buffer on the way up, ONE inversion per run (rounds 1-3 paid ~314 products per entry), then
+  //                        x = X / Z^2, y = Y / Z^3 on the way down, converted to the caller's layout in place.
+  // The side buffers hold Z and the prefix for one chunk of bases at a time (msm_precompute_run); their traffic (~5 field elements
+  // per entry) is noise beside 254 doublings.
+  constexpr int PRECOMP_RUN = 8;
   template <class C>
-  __device__ __forceinline__ void store_point_words(uint32_t* __restrict__ dst, const uint32_t* w)
+  __device__ __forceinline__ void store_point_words(uint32_t* __restrict__ dst, const uint32_t* w, bool aligned16)
   {
-    constexpr int PW = 2 * EC<C>::N32; // 16 / 24 / 32 / 48 words: always a multiple of 4, points are PW*4-byte aligned
+    constexpr int PW = 2 * EC<C>::N32; // 16 / 24 / 32 / 48 words: always a multiple of 4
+    if (aligned16) {
 #pragma unroll
-    for (int k = 0; k < PW; k += 4)
-      *reinterpret_cast<uint4*>(dst + k) = make_uint4(w[k], w[k + 1], w[k + 2], w[k + 3]);
+      for (int k = 0; k < PW; k += 4)
+        *reinterpret_cast<uint4*>(dst + k) = make_uint4(w[k], w[k + 1], w[k + 2], w[k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < PW; k++)
+        dst[k] = w[k];
+    }
   }
   template <class C>
-  __global__ __launch_bounds__(64) void k_precompute(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n, int pf, int shift, bool refmont, int pt, bool aligned16)
+  __device__ __forceinline__ void load_point_words(uint32_t* w, const uint32_t* __restrict__ src, bool aligned16)
+  {
+    constexpr int PW = 2 * EC<C>::N32;
+    if (aligned16) {
+#pragma unroll
+      for (int k = 0; k < PW; k += 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + k);
+        w[k] = v.x, w[k + 1] = v.y, w[k + 2] = v.z, w[k + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PW; k++)
+        w[k] = src[k];
+    }
+  }
+  // bases [i0, i0 + cnt) of the table; zbuf is indexed from the chunk's first entry: zbuf[((i - i0) * (pf - 1) + j - 1) * N32]
+  template <class C, int MINW>
+  __global__ __launch_bounds__(64, MINW) void k_precompute_chains(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ zbuf, long long i0, int cnt, int pf, int shift, bool refmont, bool in16, bool out16)
+  {
+    using E = EC<C>;
+    using F = typename E::F;
+    constexpr int PW = 2 * E::N32;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt) return;
+    const long long i = i0 + t;
+    uint32_t w[PW];
+    load_point_words<C>(w, in + (size_t)i * PW, in16);
+    store_point_words<C>(out + (size_t)i * pf * PW, w, out16); // entry 0 is the base itself
+    typename E::Jac jp;
+    bool ident = E::words_are_zero(w); // the identity is (0, 0) in the reference's affine layout
+    if (!ident) {
+      jp.x = refmont ? F::from_refmont(w) : F::from_canonical(w);
+      jp.y = refmont ? F::from_refmont(w + E::N32) : F::from_canonical(w + E::N32);
+      jp.z = F::one();
+    }
+    for (int j = 1; j < pf; j++) {
+      if (!ident) {
+        for (int sft = 0; sft < shift; sft++)
+          jp = E::dbl_jac(jp);
+        ident = F::is_zero(jp.z); // a point of order two doubles to Z = 0 (and stays there)
+      }
+      uint32_t* zdst = zbuf + ((size_t)t * (pf - 1) + (j - 1)) * E::N32;
+      if (ident) { // Z = 0 marks the entry for k_precompute_affine
+#pragma unroll
+        for (int k = 0; k < E::N32; k++)
+          zdst[k] = 0;
+        continue;
+      }
+      F::pack(w, F::reduce(jp.x));
+      F::pack(w + E::N32, F::reduce(jp.y));
+      store_point_words<C>(out + ((size_t)i * pf + j) * PW, w, out16);
+      uint32_t zw[E::N32];
+      F::pack(zw, F::reduce(jp.z));
+#pragma unroll
+      for (int k = 0; k < E::N32; k++)
+        zdst[k] = zw[k];
+    }
+  }
+  // entries q of the chunk (q = (i - i0) * (pf - 1) + j - 1, q < nq): one thread per run of PRECOMP_RUN consecutive q
+  template <class C, int MINW>
+  __global__ __launch_bounds__(64, MINW) void k_precompute_affine(uint32_t* __restrict__ out, const uint32_t* __restrict__ zbuf, uint32_t* __restrict__ pbuf, long long i0, long long nq, int pf, bool refmont, bool out16)
   {
     using E = EC<C>;
     using F = typename E::F;
     using fe = typename F::fe;
     constexpr int PW = 2 * E::N32;
-    const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * pt;
-    if (i0 >= n) return;
-    fe xs[PRECOMP_MAX_OUT], ys[PRECOMP_MAX_OUT], zs[PRECOMP_MAX_OUT], pre[PRECOMP_MAX_OUT]; // (dynamically indexed: scratch)
-    int slot[PRECOMP_MAX_OUT];                                                              // output point index of entry k
-    int cnt = 0;
+    const long long q0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * PRECOMP_RUN;
+    if (q0 >= nq) return;
+    const int m = (int)(nq - q0 < PRECOMP_RUN ? nq - q0 : PRECOMP_RUN);
     fe acc = F::one();
-    auto put = [&](long long idx, const uint32_t* w) {
-      uint32_t* dst = out + (size_t)idx * PW;
-      if (aligned16) {
-        store_point_words<C>(dst, w);
-      } else {
-        for (int k = 0; k < PW; k++)
-          dst[k] = w[k];
-      }
-    };
-    // converts the held outputs (one inversion for all of them) and writes them; also called when the arrays are full
-    // (precompute_factor > 33: the outputs of one base then take several rounds)
-    auto flush = [&]() {
-      if (cnt == 0) return;
-      fe inv = F::inv(acc);
-      for (int k = cnt - 1; k >= 0; k--) {
-        const fe zi = F::mul(inv, pre[k]); // 1 / Z_k
-        inv = F::mul(inv, zs[k]);
-        const fe zi2 = F::sqr(zi);
-        const fe x = F::mul(xs[k], zi2), y = F::mul(ys[k], F::mul(zi2, zi));
-        uint32_t o[PW];
-        if (refmont) {
-          F::to_refmont(o, x);
-          F::to_refmont(o + E::N32, y);
-        } else {
-          F::to_canonical(o, x);
-          F::to_canonical(o + E::N32, y);
-        }
-        put(i0 * pf + slot[k], o);
-      }
-      cnt = 0;
-      acc = F::one();
-    };
-    for (int q = 0; q < pt && i0 + q < n; q++) {
-      const long long i = i0 + q;
-      uint32_t w[PW];
-      for (int k = 0; k < PW; k++)
-        w[k] = in[(size_t)i * PW + k];
-      put(i * pf, w);
-      const bool zero_in = E::words_are_zero(w);
-      typename E::Jac jp;
-      if (!zero_in) {
-        jp.x = refmont ? F::from_refmont(w) : F::from_canonical(w);
-        jp.y = refmont ? F::from_refmont(w + E::N32) : F::from_canonical(w + E::N32);
-        jp.z = F::one();
-      }
-      for (int j = 1; j < pf; j++) {
-        bool ident = zero_in;
-        if (!ident) {
-          for (int sft = 0; sft < shift; sft++)
-            jp = E::dbl_jac(jp);
-          ident = F::is_zero(jp.z); // a point of order two doubles to Z = 0 (and stays there)
-        }
-        if (ident) { // the identity is (0, 0) in the reference's affine layout
-          uint32_t zw[PW];
-          for (int k = 0; k < PW; k++)
-            zw[k] = 0;
-          put(i * pf + j, zw);
-          continue;
-        }
-        if (cnt == PRECOMP_MAX_OUT) flush();
-        xs[cnt] = jp.x, ys[cnt] = jp.y, zs[cnt] = jp.z;
-        pre[cnt] = acc; // product of the Z's before this one
-        acc = F::mul(acc, jp.z);
-        slot[cnt] = q * pf + j;
-        cnt++;
-      }
+    for (int k = 0; k < m; k++) { // prefix products (of the non-zero Z's) before entry k
+      uint32_t zw[E::N32];
+#pragma unroll
+      for (int e = 0; e < E::N32; e++)
+        zw[e] = zbuf[(size_t)(q0 + k) * E::N32 + e];
+      uint32_t pw[E::N32];
+      F::pack(pw, F::reduce(acc));
+#pragma unroll
+      for (int e = 0; e < E::N32; e++)
+        pbuf[(size_t)(q0 + k) * E::N32 + e] = pw[e];
+      uint32_t any = 0;
+#pragma unroll
+      for (int e = 0; e < E::N32; e++)
+        any |= zw[e];
+      if (any) acc = F::mul(acc, F::unpack(zw));
     }
-    flush();
+    fe inv = F::inv(acc);
+    for (int k = m - 1; k >= 0; k--) {
+      const long long q = q0 + k;
+      const long long slot = (i0 + q / (pf - 1)) * pf + 1 + q % (pf - 1);
+      uint32_t* dst = out + (size_t)slot * PW;
+      uint32_t zw[E::N32], w[PW];
+#pragma unroll
+      for (int e = 0; e < E::N32; e++)
+        zw[e] = zbuf[(size_t)q * E::N32 + e];
+      uint32_t any = 0;
+#pragma unroll
+      for (int e = 0; e < E::N32; e++)
+        any |= zw[e];
+      if (!any) {
+#pragma unroll
+        for (int e = 0; e < PW; e++)
+          w[e] = 0;
+        store_point_words<C>(dst, w, out16);
+        continue;
+      }
+      uint32_t pw[E::N32];
+#pragma unroll
+      for (int e = 0; e < E::N32; e++)
+        pw[e] = pbuf[(size_t)q * E::N32 + e];
+      const fe zi = F::mul(inv, F::unpack(pw)); // 1 / Z_k
+      inv = F::mul(inv, F::unpack(zw));
+      const fe zi2 = F::sqr(zi);
+      load_point_words<C>(w, dst, out16);
+      const fe x = F::mul(F::unpack(w), zi2), y = F::mul(F::unpack(w + E::N32), F::mul(zi2, zi));
+      if (refmont) {
+        F::to_refmont(w, x);
+        F::to_refmont(w + E::N32, y);
+      } else {
+        F::to_canonical(w, x);
+        F::to_canonical(w + E::N32, y);
+      }
+      store_point_words<C>(dst, w, out16);
+    }
   }
 
   // synthetic distinct points (k0 + i) * G, i < n; each thread produces L consecutive points
@@ -1920,6 +1976,14 @@ namespace icicle_hip {
     // DeviceSlice by type and the input may be one: a flag left at "host" is checked against the pointer itself.
     const bool in_on_device = cfg->are_points_on_device || points_to_device_memory(in_v);
     const bool out_on_device = cfg->are_results_on_device || points_to_device_memory(out_v);
+    // nof_bases is the size of ONE MSM (see above): with per-MSM bases this call reads and writes batch_size times that. A caller
+    // that meant nof_bases as the TOTAL (the reading the reference's CPU backend takes, cpu_msm.hpp:470-485, and rounds 1-4 of this
+    // backend took) would be read and written batch_size times past its buffers: refused where the device allocation proves it
+    // (ADVICE r05). INTEGRATION.md states the convention.
+    if ((in_on_device && overruns_device_allocation(in_v, (size_t)n * PW * 4)) || (out_on_device && overruns_device_allocation(out_v, (size_t)n * pf * PW * 4))) {
+      fprintf(stderr, "[icicle_hip] msm_precompute_bases: nof_bases = %d x batch_size %d (bases per MSM, are_points_shared_in_batch = false) x precompute_factor %d does not fit the device buffers handed in\n", n_one, batch, pf);
+      return ICICLE_INVALID_ARGUMENT;
+    }
     if (!in_on_device) {
       HIP_TRY(d_in_tmp.alloc((size_t)n * PW * 4, st), ICICLE_ALLOCATION_FAILED);
       HIP_TRY(hipMemcpyAsync(d_in_tmp.ptr(), in_v, (size_t)n * PW * 4, hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
@@ -1929,14 +1993,33 @@ namespace icicle_hip {
       HIP_TRY(d_out_tmp.alloc((size_t)n * pf * PW * 4, st), ICICLE_ALLOCATION_FAILED);
       d_out = d_out_tmp.as<uint32_t>();
     }
-    // bases per thread sharing one inversion: as many as the scratch arrays hold, at most 4, and never so many that the
-    // grid no longer fills the chip
-    int pt = std::max(1, std::min(4, pf > 1 ? PRECOMP_MAX_OUT / (pf - 1) : 1));
-    while (pt > 1 && (long long)n / pt < 64 * 1024)
-      pt--;
-    const long long nthr = ((long long)n + pt - 1) / pt;
-    k_precompute<C><<<(unsigned)((nthr + 63) / 64), 64, 0, st>>>(d_in, d_out, n, pf, pl.c * pl.wpf, cfg->are_points_montgomery_form, pt, ((uintptr_t)d_out & 15) == 0);
-    LAUNCH_CHECK("k_precompute", st);
+    // register budget of the two kernels (waves per SIMD the allocator must leave room for): a doubling chain keeps three
+    // coordinates and four or five temporaries: 3 waves for 9-limb fields, 2 for 14-limb fields and BN254's Fq2, 1 for BLS12's Fq2
+    constexpr bool BIGPT = sizeof(typename E::XYZZ) > 256; // G2
+    constexpr int MINW = BIGPT ? (sizeof(typename E::XYZZ) <= 288 ? 2 : 1) : (E::F::N <= 9 ? 3 : 2);
+    const bool in16 = ((uintptr_t)d_in & 15) == 0, out16 = ((uintptr_t)d_out & 15) == 0;
+    if (pf == 1) {
+      HIP_TRY(hipMemcpyAsync(d_out, d_in, (size_t)n * PW * 4, hipMemcpyDeviceToDevice, st), ICICLE_COPY_FAILED);
+    } else {
+      // side buffers (Z and the prefix products) for one chunk of bases: at most ~1 GiB together, at least a chip-filling launch
+      const size_t per_base = (size_t)(pf - 1) * E::N32 * 4 * 2;
+      long long chunk = std::max<long long>(256 * 1024, (long long)((1ull << 30) / per_base));
+      chunk = std::min<long long>(chunk, n);
+      TempBuf side;
+      HIP_TRY(side.alloc((size_t)chunk * per_base, st), ICICLE_ALLOCATION_FAILED);
+      uint32_t* zbuf = side.as<uint32_t>();
+      uint32_t* pbuf = zbuf + (size_t)chunk * (pf - 1) * E::N32;
+      const int shift = pl.c * pl.wpf;
+      for (long long i0 = 0; i0 < n; i0 += chunk) {
+        const int cnt = (int)std::min<long long>(chunk, n - i0);
+        k_precompute_chains<C, MINW><<<(unsigned)((cnt + 63) / 64), 64, 0, st>>>(d_in, d_out, zbuf, i0, cnt, pf, shift, cfg->are_points_montgomery_form, in16, out16);
+        LAUNCH_CHECK("k_precompute_chains", st);
+        const long long nq = (long long)cnt * (pf - 1);
+        const long long runs = (nq + PRECOMP_RUN - 1) / PRECOMP_RUN;
+        k_precompute_affine<C, MINW><<<(unsigned)((runs + 63) / 64), 64, 0, st>>>(d_out, zbuf, pbuf, i0, nq, pf, cfg->are_points_montgomery_form, out16);
+        LAUNCH_CHECK("k_precompute_affine", st);
+      }
+    }
     HIP_TRY(hipGetLastError(), ICICLE_INVALID_ARGUMENT);
     if (!out_on_device) {
       HIP_TRY(hipMemcpyAsync(out_v, d_out, (size_t)n * pf * PW * 4, hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);

@@ -279,6 +279,9 @@ namespace icicle_hip {
     api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+    api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
+    api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
     return api.CommInitAll && api.AllGather && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
   }
 
@@ -311,6 +314,12 @@ namespace icicle_hip {
 
   const RcclApi* rccl_api() { return rccl_api_at(collectives_path()); }
 
+  // what the communicator layer reported for the most recently CREATED communicator set (icicle_hip_collectives_info):
+  // [0] library version (ncclGetVersion; -1 not bound), [1] devices asked for, [2] ncclCommCount of slot 0 (-1 not bound),
+  // [3] 1 when every slot p reported ncclCommUserRank == p and ncclCommCount == devices, 0 when one did not, -1 not bound,
+  // [4] number of communicator sets created so far in this process
+  static std::atomic<int> g_coll_info[5] = {{-1}, {0}, {-1}, {-1}, {0}};
+
   icicle_error_t rccl_comms_for(const std::vector<int>& devs, RcclCommSet** set)
   {
     static std::mutex mtx;
@@ -331,10 +340,35 @@ namespace icicle_hip {
         delete cs;
         return ICICLE_INVALID_DEVICE;
       }
+      // first contact with a real multi-GPU communicator happens on a node this code has never met: check what it reports
+      int ver = -1, cnt0 = -1, consistent = -1;
+      if (api->GetVersion && api->GetVersion(&ver) != 0) ver = -1;
+      if (api->CommCount && api->CommUserRank) {
+        consistent = 1;
+        for (size_t p = 0; p < devs.size(); p++) {
+          int c = -1, r = -1;
+          if (api->CommCount(cs->comms[p], &c) != 0 || api->CommUserRank(cs->comms[p], &r) != 0 || c != (int)devs.size() || r != (int)p) consistent = 0;
+          if (p == 0) cnt0 = c;
+        }
+      }
+      g_coll_info[0] = ver, g_coll_info[1] = (int)devs.size(), g_coll_info[2] = cnt0, g_coll_info[3] = consistent;
+      g_coll_info[4]++;
+      if (consistent == 0) {
+        fprintf(stderr, "[icicle_hip] the communicators of ncclCommInitAll(%zu devices) report another size / rank order (count %d)\n", devs.size(), cnt0);
+        for (void* c : cs->comms)
+          if (c && api->CommDestroy) api->CommDestroy(c);
+        delete cs;
+        return ICICLE_INVALID_DEVICE;
+      }
       it = cache.emplace(key, cs).first;
     }
     *set = it->second;
     return ICICLE_SUCCESS;
+  }
+  void collectives_info(int* out, int n)
+  {
+    for (int i = 0; i < n && i < 5; i++)
+      out[i] = g_coll_info[i].load();
   }
 
   // ---- multi-device plumbing -------------------------------------------------------------------
@@ -632,6 +666,15 @@ icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset)
   return ICICLE_SUCCESS;
 }
 icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset) { return icicle_hip_multi_stats2(out5, 5, reset); }
+// What the collectives library reported for the most recently created communicator set (up to 5 values): version
+// (ncclGetVersion), devices asked for, ncclCommCount, 1 / 0 = every slot's ncclCommUserRank and ncclCommCount as expected / not,
+// communicator sets created so far. -1 = the library does not export the call.
+icicle_error_t icicle_hip_collectives_info(int* out, int n)
+{
+  if (!out || n <= 0) return ICICLE_INVALID_ARGUMENT;
+  collectives_info(out, n);
+  return ICICLE_SUCCESS;
+}
 
 // plugin helper: select the GPU for the calling thread without going through icicle_set_device
 // (whose name belongs to the reference runtime when both libraries live in one process)

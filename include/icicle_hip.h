@@ -331,6 +331,11 @@ icicle_error_t icicle_hip_enable_kernel_timing(bool enable);
  * pattern of its base fetch; also the known-byte-count kernel the FETCH_SIZE counter is calibrated on). */
 icicle_error_t icicle_hip_ubench_mixed_add(int curve, double* adds_per_second);
 icicle_error_t icicle_hip_ubench_gather(uint64_t region_bytes, uint64_t gathers, double* gathers_per_second);
+/* VALU-issue roof of the NTT pass kernels, measured on the spot (field 0 = babybear, 1 = koalabear): "pass units" per second, one
+ * unit = 16 elements through one 8-stage pass with every operand in registers (two radix-16 register rounds of k_ntt_fast's own
+ * butterfly code + the 16 products with the factor behind the pass; no memory, no LDS). A three-pass 2^24-point transform is
+ * 3 * 2^20 units per row (reference semantics of the butterflies: icicle/backend/cpu/include/ntt_cpu.h:129-225). */
+icicle_error_t icicle_hip_ubench_ntt_pass(int field, double* pass_units_per_second);
 /* Device self-test of the in-place asm field products with aliased and constant operands (curve 0 = bn254, 1 = bls12_381):
  * *mismatches must be 0 (tests/test_gpu_msm.py). */
 icicle_error_t icicle_hip_selftest_inplace_products(int curve, int* mismatches);
@@ -364,6 +369,11 @@ icicle_error_t icicle_hip_msm_release_resident_bases(const void* bases);
  * first min(n, 6) of them; icicle_hip_multi_stats writes exactly the first FIVE (out[5], the contract since round 3). */
 icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset);
 icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset);
+/* What the collectives library (RCCL, or the one set with icicle_hip_set_collectives_library) reported for the most recently created
+ * communicator set of the in-process multi-GPU path: out[0] ncclGetVersion, out[1] devices asked for, out[2] ncclCommCount,
+ * out[3] 1 when every slot p reported ncclCommUserRank == p and ncclCommCount == devices (a set that does not is refused with
+ * INVALID_DEVICE), out[4] communicator sets created so far. -1 where the library does not export the call. Writes min(n, 5) values. */
+icicle_error_t icicle_hip_collectives_info(int* out, int n);
 /* The multi-device paths take their collectives from a library with the NCCL C ABI (ncclCommInitAll, ncclCommDestroy,
  * ncclAllGather, ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd, ncclGetErrorString), bound with dlopen: librccl.so by default,
  * or the library at `path` (NULL / "" = default again; ICICLE_HIP_RCCL_LIB in the environment does the same) -- another RCCL

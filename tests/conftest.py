@@ -26,6 +26,14 @@ def pytest_collection_modifyitems(config, items):
     config._refjob_items = late
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    pool = getattr(config, "_refpool", None)
+    if pool is not None and (pool.timings or getattr(pool, "setup_s", 0)):
+        terminalreporter.write_line("[refpool] reference-CPU legs (s): " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(pool.timings.items()))
+                                    + f"; setup {getattr(pool, 'setup_s', 0):.1f}; finished (s after session start): "
+                                    + ", ".join(f"{k} {v:.0f}" for k, v in sorted(getattr(pool, 'finished_at', {}).items())))
+
+
 @pytest.fixture(scope="session")
 def hip():
     """The product library bound to GPU 0. GPU tests fail loudly (no CPU fallback) if it is absent."""
@@ -74,10 +82,10 @@ def refpool(request):
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
         pool.start()
+        pool.pin_foreground()
         pool.setup_s = time.time() - t0
+    request.config._refpool = pool
     yield pool
-    if pool.timings:
-        sys.stderr.write("\n[refpool] reference-CPU legs (s): " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(pool.timings.items())) + f"; setup {getattr(pool, 'setup_s', 0):.1f}\n")
     pool.close()
 
 

@@ -257,4 +257,22 @@ int ncclRecv(void* recv, size_t count, int dtype, int peer, void* comm, hipStrea
 int ncclGroupStart() { return lb_group_start(); }
 int ncclGroupEnd() { return lb_group_end(); }
 const char* ncclGetErrorString(int e) { return lb_error_string(e); }
+int ncclCommCount(void* comm, int* count)
+{
+  if (!comm || !count) return 4; // ncclInvalidArgument
+  *count = static_cast<LbComm*>(comm)->w->n;
+  return 0;
+}
+int ncclCommUserRank(void* comm, int* rank)
+{
+  if (!comm || !rank) return 4;
+  *rank = static_cast<LbComm*>(comm)->rank;
+  return 0;
+}
+int ncclGetVersion(int* version)
+{
+  if (!version) return 4;
+  *version = 0; // (a stand-in has no RCCL version)
+  return 0;
+}
 }

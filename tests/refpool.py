@@ -13,6 +13,11 @@ Lanes:
   * NTT jobs run in worker PROCESSES (tests/ref_ntt_worker.py): the reference keeps ONE twiddle domain per field and
     process, and the foreground tests of the same session init / release it at other sizes. Inputs and outputs travel
     as .npy files in a scratch directory (page cache), jobs of one lane run in submission order.
+Host cores are PARTITIONED between the lanes and the foreground (the first measurement ran every lane on all 256 threads of the
+box: the foreground's subprocess tests took 15 x longer and the suite gained nothing): each lane pins itself -- and thereby
+the worker threads the reference spawns, which inherit the mask -- to its share, and the pytest process keeps the rest. The
+reference CPU MSM scales poorly beyond a few dozen threads anyway (256 threads are 8 x faster than 8), so the shares cost
+the background legs little. Below 32 cores nothing is pinned.
 Nothing here is imported by the product.
 """
 import json
@@ -29,15 +34,55 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# share of the host cores per lane (fractions of os.cpu_count(); the foreground keeps the first quarter)
+LANE_SHARE = {"fg": (0.0, 0.25), "msm_big": (0.25, 0.60), "msm": (0.60, 0.80), "ntt_a": (0.80, 0.90), "ntt_b": (0.90, 1.0)}
+
+
+_ALL_CORES = None  # the cores this process could use before anything was pinned
+
+
+def lane_cores(lane):
+    """cores of `lane` (None: no pinning on this host)"""
+    global _ALL_CORES
+    if (os.cpu_count() or 1) < 32 or not hasattr(os, "sched_setaffinity"):
+        return None
+    if _ALL_CORES is None:
+        try:
+            _ALL_CORES = sorted(os.sched_getaffinity(0))
+        except Exception:
+            return None
+    lo, hi = LANE_SHARE.get(lane, LANE_SHARE["msm"])
+    n = len(_ALL_CORES)
+    return _ALL_CORES[int(lo * n):max(int(lo * n) + 1, int(hi * n))] or None
+
+
+def pin_to_lane(lane):
+    """pin the CALLING thread (pid 0 = this thread on Linux) to the lane's cores; threads it spawns inherit the mask"""
+    cores = lane_cores(lane)
+    if cores:
+        try:
+            os.sched_setaffinity(0, cores)
+        except OSError:
+            pass
+    return cores
+
 
 class RefPool:
     def __init__(self):
         self._futures = {}
         self._lanes = {}
         self._dir = None
+        self._fg_before = None
+        try:
+            self._fg_before = os.sched_getaffinity(0)
+            lane_cores("fg")  # records the cores available to this process before anything is pinned (main thread, unpinned)
+        except Exception:
+            pass
         self._ntt = {}  # lane -> {"jobs": [...], "proc": Popen}
         self._started = {}
         self.timings = {}  # key -> seconds the reference call took (MSM lanes), for the session summary
+        self.finished_at = {}  # key -> seconds after the pool was created (MSM lanes: when the call returned; NTT: when joined)
+        self._t0 = time.time()
 
     # ---------------------------------------------------------------- MSM: in-process threads
     def _lane(self, name):
@@ -50,9 +95,11 @@ class RefPool:
         from oracle import ref
 
         def run():
+            pin_to_lane(lane)
             t0 = time.time()
             out = ref.RefCurve(curve).msm(scalars, bases, **kw)
             self.timings[key] = time.time() - t0
+            self.finished_at[key] = time.time() - self._t0
             return out
 
         assert key not in self._futures, key
@@ -61,7 +108,14 @@ class RefPool:
     # ---------------------------------------------------------------- NTT: worker processes
     def scratch(self):
         if self._dir is None:
-            self._dir = tempfile.mkdtemp(prefix="icicle_refpool_")
+            base = None
+            try:  # a roomy /dev/shm (the GPU boxes: 1.5 TB) beats the container's overlay disk for multi-GiB .npy files
+                st = os.statvfs("/dev/shm")
+                if st.f_bavail * st.f_frsize > (64 << 30):
+                    base = "/dev/shm"
+            except OSError:
+                pass
+            self._dir = tempfile.mkdtemp(prefix="icicle_refpool_", dir=base)
         return self._dir
 
     def submit_ntt(self, key, field, x: np.ndarray, logn, direction, batch=1, ordering=0, coset_gen=1, lane="ntt", chain=None):
@@ -75,6 +129,10 @@ class RefPool:
         self._ntt.setdefault(lane, {"jobs": []})["jobs"].append(spec)
         self._futures[key] = ("ntt", lane, 1 + len(spec["chain"]))
 
+    def pin_foreground(self):
+        """the pytest process (and the subprocesses its tests spawn) keep the foreground share of the cores"""
+        pin_to_lane("fg")
+
     def start(self):
         """spawn the worker processes (after every submit_ntt of the session)"""
         for lane, st in self._ntt.items():
@@ -85,6 +143,9 @@ class RefPool:
                 json.dump(st["jobs"], f)
             log = open(os.path.join(d, f"lane_{lane}.log"), "w")
             env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            cores = lane_cores(lane)
+            if cores:
+                env["ICICLE_REFPOOL_CORES"] = ",".join(str(c) for c in cores)
             st["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ref_ntt_worker.py"), d, lane], stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
             self._started[lane] = True
 
@@ -133,3 +194,8 @@ class RefPool:
         if self._dir:
             shutil.rmtree(self._dir, ignore_errors=True)
             self._dir = None
+        if self._fg_before:
+            try:
+                os.sched_setaffinity(0, self._fg_before)
+            except OSError:
+                pass

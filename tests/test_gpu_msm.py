@@ -257,6 +257,32 @@ def test_msm_precompute_non_shared_batch(hip, cname):
     assert np.array_equal(refc.to_affine(got1), refc.to_affine(refc.msm(np.ascontiguousarray(sc[:100]), np.ascontiguousarray(bases[:100]))))
 
 
+def test_msm_precompute_refuses_a_total_count_that_overruns_the_device_buffers(hip):
+    """msm_precompute_bases takes nof_bases as the bases of ONE MSM (both wrappers' convention); a caller
+    that hands the TOTAL with per-MSM bases would be read / written batch_size times past its buffers. With device buffers
+    the overrun is provable (hipMemGetAddressRange) and the call returns INVALID_ARGUMENT instead of corrupting memory."""
+    from icicle_amd import msm as M
+    from icicle_amd.runtime import DeviceVec
+
+    C = pyref.BN254
+    n, batch, pf = 256, 4, 2
+    bases = points_to_array(C, cached_points(C, n * batch))
+    d_in = DeviceVec.from_host(bases)
+    d_out = DeviceVec(bases.nbytes * pf)
+    cfg = hip.MSMConfig.default()
+    cfg.precompute_factor, cfg.batch_size, cfg.are_points_shared_in_batch = pf, batch, False
+    try:
+        M.precompute_bases("bn254", d_in, cfg, output=d_out, nof_bases=n)  # the wrappers' convention: fits exactly
+        with pytest.raises(RuntimeError):
+            M.precompute_bases("bn254", d_in, cfg, output=d_out, nof_bases=n * batch)  # total count: 4 x past both buffers
+        got = d_out.to_host(shape=(n * batch * pf, 16))
+        exp = M.precompute_bases("bn254", bases, cfg)
+        assert np.array_equal(got, exp)  # the refused call wrote nothing
+    finally:
+        d_in.free()
+        d_out.free()
+
+
 @pytest.mark.parametrize("cname", CURVES)
 def test_msm_on_a_table_of_another_size_finds_its_window(hip, cname):
     """with precompute_factor > 1 and config.c = 0 both calls derive c from their OWN size, so an MSM over a prefix

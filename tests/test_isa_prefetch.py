@@ -82,3 +82,48 @@ def test_ntt_next_row_prefetch_is_not_waited_for_early(code_objects, symbol, loa
     for i in range(bar, stores[-1]):
         m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", lines[i])
         assert not (m and int(m.group(1)) == 0), f"line {i}: '{lines[i]}' drains the memory counter in the middle of a row"
+
+
+# ---- scratch lint: hot and warm kernels must not spill ---------------------------------------------------
+# A kernel that keeps private arrays or spills registers pays twice on gfx950: the traffic itself, and the wave limit the scratch
+# reservation imposes (k_precompute held 4.7 - 14.5 KB per lane through rounds 3-5 and ran at 211 ms against a 135 ms floor).
+# (regex on the demangled kernel name, bytes of scratch per lane allowed)
+SCRATCH_RULES = [
+    (r"^k_accumulate<(bn254|grumpkin)_g1, 3, false>", 0),          # the dominant MSM kernel as launched (3 waves per SIMD)
+    (r"^k_accumulate<(bls12_381|bls12_377)_g1, 2, false>", 0),     # 14-limb fields: launched at 2 waves per SIMD
+    (r"^k_accumulate<bn254_g2, 2, false>", 128),                   # (the default G2 launch: 100 B today)
+    (r"^k_precompute_(chains|affine)<\w+_g1, \d>", 0),
+    (r"^k_precompute_(chains|affine)<\w+_g2, \d>", 256),
+    (r"^k_(reduce_wave|reduce_small|reduce_window|final|final_horner|final_combine|fold_overflow|proj_sum|bucket_add|generate)<\w+_g1>", 0),
+    (r"^k_(digits|digits_count|a_scatter|b_scatter|a_count|b_count|bsize_count|bsize_scatter|plan_overflow|tables_from_a|b_plan|scan_sums|scan_apply)\b", 0),
+    (r"^k_diag_(madd|ntt_pass)<", 0),                              # the in-run roofs must not be measured on a spilling kernel
+    # NTT passes of the headline shapes: plain / inverse two-round column and row passes, 4- and 16-byte lanes, lane-native tiles
+    (r"^k_ntt_fast<\w+_params, 4, 2, (false|true), (false|true), false, false, (false|true), false, (false|true), 0>", 0),
+    (r"^k_ntt_fast<\w+_params, \d, \d, false, false, false, false, false, false, (false|true), [12]>", 0),  # native bit-reversed input
+]
+
+
+def test_listed_kernels_do_not_use_scratch(tmp_path):
+    import importlib.util
+    import sys
+
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    spec = importlib.util.spec_from_file_location("kernel_regs", os.path.join(ROOT, "tools", "kernel_regs.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = [k for co in kr.code_objects(LIB, str(tmp_path)) for k in kr.kernels(co)]
+    dm = kr.demangle([r["name"] for r in rows])
+    seen = {i: 0 for i in range(len(SCRATCH_RULES))}
+    bad = []
+    for r in rows:
+        name = re.sub(r"\(.*", "", dm[r["name"]]).replace("icicle_hip::", "").replace("void ", "")
+        for i, (pat, limit) in enumerate(SCRATCH_RULES):
+            if re.search(pat, name):
+                seen[i] += 1
+                sc = int(r.get("private_segment_fixed_size", 0))
+                if sc > limit:
+                    bad.append(f"{name}: {sc} B of scratch per lane (allowed {limit}), {r.get('vgpr_count')} VGPRs")
+    assert not bad, "\n".join(bad)
+    unmatched = [SCRATCH_RULES[i][0] for i, c in seen.items() if c == 0]
+    assert not unmatched, f"rules that match no kernel of the library (renamed?): {unmatched}"

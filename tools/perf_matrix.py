@@ -209,10 +209,12 @@ def msm_precompute_case(curve, logn, pf, batch=1, c=0):
     t_pre = 0.0
     if pf > 1:
         table = torch.empty((n * pf, 2 * L), dtype=torch.int32, device=dev)
-        t0 = time.perf_counter()
-        M.precompute_bases(curve, bases.data_ptr(), cfg, output=table.data_ptr(), nof_bases=n)
-        torch.cuda.synchronize()
-        t_pre = (time.perf_counter() - t0) * 1e3
+        t_pre = 1e30
+        for _ in range(2):  # (the first call also pays for the code object load and the workspace lease)
+            t0 = time.perf_counter()
+            M.precompute_bases(curve, bases.data_ptr(), cfg, output=table.data_ptr(), nof_bases=n)
+            torch.cuda.synchronize()
+            t_pre = min(t_pre, (time.perf_counter() - t0) * 1e3)
     ms = time_it(lambda: M.msm(curve, sc.data_ptr(), table.data_ptr(), cfg, results=res.data_ptr(), msm_size=n))
     import ctypes
     pc, pw = ctypes.c_int(), ctypes.c_int()
