@@ -204,7 +204,7 @@ API_SYMBOLS = (
     + [f"{pre}{f}_extension_matrix_transpose" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + [GOLD]]
     + ["icicle_hip_msm_plan", "icicle_hip_msm_plan_info", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
        "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_ubench_ntt_pass", "icicle_hip_selftest_inplace_products", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
-       "icicle_hip_msm_release_resident_bases", "icicle_hip_multi_stats", "icicle_hip_multi_stats2", "icicle_hip_collectives_info", "icicle_hip_test_set_virtual_devices",
+       "icicle_hip_msm_release_resident_bases", "icicle_hip_multi_stats", "icicle_hip_multi_stats2", "icicle_hip_collectives_info", "icicle_hip_test_set_virtual_devices", "icicle_hip_test_set_no_peer_access",
        "icicle_hip_set_collectives_library", "icicle_hip_test_inject_failure",
        "icicle_hip_create_config_extension", "icicle_hip_destroy_config_extension", "icicle_hip_config_extension_set_int",
        "icicle_hip_config_extension_set_bool"]
@@ -310,6 +310,7 @@ lib.icicle_hip_test_inject_failure.argtypes = [ctypes.c_int, ctypes.c_int]
 
 def multi_stats(reset=False):
     """dict of the multi-device / pipelined-path counters (icicle_hip_multi_stats)"""
-    out = (ctypes.c_uint64 * 6)()
-    check(lib.icicle_hip_multi_stats2(out, 6, reset), "multi_stats")
-    return dict(zip(("staged_base_bytes", "staged_scalar_bytes", "exchanged_bucket_bytes", "resident_base_hits", "threaded_calls", "exchange_messages"), [int(v) for v in out]))
+    out = (ctypes.c_uint64 * 7)()
+    check(lib.icicle_hip_multi_stats2(out, 7, reset), "multi_stats")
+    return dict(zip(("staged_base_bytes", "staged_scalar_bytes", "exchanged_bucket_bytes", "resident_base_hits", "threaded_calls", "exchange_messages", "peer_staged_copies"),
+                    [int(v) for v in out]))

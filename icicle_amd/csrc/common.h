@@ -224,8 +224,23 @@ namespace icicle_hip {
   // per-process counters of what the multi-device / pipelined paths moved (icicle_hip_multi_stats)
   struct MultiStats {
     std::atomic<uint64_t> staged_base_bytes{0}, staged_scalar_bytes{0}, exchanged_bucket_bytes{0}, resident_base_hits{0}, threaded_calls{0}, exchange_messages{0};
+    std::atomic<uint64_t> peer_staged_copies{0}; // cross-device copies that took the no-peer-access route (hipMemcpyPeerAsync)
   };
   MultiStats& multi_stats();
+  // ---- copies between the caller's device and a worker's device (in-process multi-GPU paths) ----------------------------------
+  // A worker thread (device `self`) moves operands from / results to memory of the calling thread's device (`home`). Where the
+  // platform lets `self` address `home` (hipDeviceEnablePeerAccess succeeds or was on already: xGMI inside one MI355X node) the
+  // copy is ONE hipMemcpy*Async(hipMemcpyDefault). Where it is refused -- IOMMU / ACS settings, a container without the peer's
+  // render node, more than the supported peers -- or when icicle_hip_test_set_no_peer_access(true) says so, every copy whose
+  // other side is DEVICE memory goes through hipMemcpyPeerAsync row by row, which the HIP runtime stages through host memory
+  // when the two devices are not peers (slower, never wrong). Host-side operands take the plain copy either way.
+  struct PeerRoute {
+    int self = 0, home = 0;
+    bool direct = true; // self may address home's memory
+  };
+  PeerRoute peer_route(int self, int home); // call on the worker thread after binding `self`; enables peer access on first use
+  // rows x width bytes; `other_is_src`: src lies on `home` (or the host), dst on `self`; otherwise the reverse
+  hipError_t peer_copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, const PeerRoute& r, bool other_is_src, hipStream_t st);
   // a long-lived non-blocking side stream of the calling thread's device (operand staging runs beside the compute stream)
   hipStream_t side_stream(int which);
 

@@ -305,6 +305,36 @@ namespace icicle_hip {
       return r;
     }
 
+    // The same doubling for THROUGHPUT chains over a prime field (msm_precompute_bases: one chain per lane, millions of lanes):
+    // a third of dbl_jac's instructions are range management, not products -- four below4() = eight conditional subtractions of
+    // ~40 instructions each beside 954 multiply-adds. Over Fq (R / p >= 128, products accept operands up to 64 p) only D needs
+    // to come back below 4 p; the coordinates then live in X < 9.2 p, Y < 17.8 p, Z < 2.8 p, a fixed point of the step (walked
+    // through by the bound tracker in tests/host_math_harness.cpp, op 6):
+    //   A = X^2 < 1.7, B = Y^2 < 3.5, C = B^2 < 1.1, t = (X + B)^2 < 2.3, D = 2 (t - A - C + 4p) < 12.6 -> below4,
+    //   E = 3A < 5, F = E^2 < 1.2, X3 = F - 2D + 8p < 9.2, Y3 = E (D - X3 + 16p) - 8C + 16p < 17.8, Z3 = 2 Y Z < 2.8.
+    // Not for Fq2 (its products want operands below 16 p, BN254's TIGHT mode below 4 p: dbl_jac); the caller reduces the results
+    // (F::reduce takes < 32 p).
+    static HD Jac dbl_jac_lazy(const Jac& p)
+    {
+      if constexpr (C::EXT_DEGREE == 2) { // (Fq2 products take their operands below 16 p, BN254's below 4 p)
+        return dbl_jac(p);
+      } else {
+        fe A = F::sqr(p.x);
+        fe B = F::sqr(p.y);
+        fe CC = F::sqr(B);
+        fe t = F::sqr(F::add(p.x, B));
+        fe D = F::below4(F::dbl(F::template sub<4>(t, F::add(A, CC))));
+        fe E = F::add(F::dbl(A), A);
+        fe Fv = F::sqr(E);
+        Jac r;
+        r.x = F::template sub<8>(Fv, F::dbl(D));
+        fe m = F::mul(E, F::template sub<16>(D, r.x));
+        r.y = F::template sub<16>(m, F::dbl(F::dbl(F::dbl(CC))));
+        r.z = F::dbl(F::mul(p.y, p.z));
+        return r;
+      }
+    }
+
 #if defined(__HIPCC__)
     // ---- doubling spread over the four lanes of a DPP quad (k_final's Horner chains) -----------------------------
     // A chain of ~250 dependent doublings on ONE wave is pure latency (7 dependent products per step, ~4.4 us each on

@@ -765,8 +765,9 @@ namespace icicle_hip {
   }
 
   // PAD: the kernel claims 176 VGPRs instead of the 155 it needs, so that exactly TWO of its waves fit a SIMD (3 x 176 > 512)
-  // and 160 registers per lane stay free for a co-resident wave of the next window group's sort (pipelined schedule). Two
-  // waves per SIMD run this kernel as fast as three (60.14 vs 60.10 ms, profiles/r03_notes.md): nothing is left to hide.
+  // and 160 registers per lane stay free for a co-resident wave of the next window group's sort (pipelined schedule, off by
+  // default). Really at two waves per SIMD the kernel is ~4.5 % SLOWER than at three (profiles/r05_notes.md section 3b; round 3's
+  // "60.14 vs 60.10 ms" compared launch bounds of a kernel whose 155 VGPRs let three waves in either way): the default launch is MINW = 3.
   template <class C, int MINW, bool PAD = false>
   __global__ __launch_bounds__(128, MINW) void k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ ovf_part, const OvfSeg* __restrict__ ovf, const uint32_t* __restrict__ ovf_count, const uint32_t* __restrict__ perm, uint32_t ovf_cap, uint32_t nb, size_t nbk, size_t cap, uint32_t seg, int wpf, size_t bases_stride)
   {
@@ -935,8 +936,12 @@ namespace icicle_hip {
   }
 
   template <class C>
-  __global__ __launch_bounds__(64) void k_reduce_wave(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ chunkV, typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum_direct, uint32_t nb_stride, uint32_t nb_wide, uint32_t m, uint32_t seg_lo, uint32_t nsegr, uint32_t nlo_w, uint32_t nseg_lo)
+  __global__ __launch_bounds__(64) void k_reduce_wave(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ chunkV, typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum_direct, uint32_t nb_stride, uint32_t nb_wide, uint32_t m_wide, uint32_t seg_lo, uint32_t nsegr, uint32_t nlo_w, uint32_t nseg_lo, uint32_t m_lo)
   {
+    // m_wide / m_lo: rows per lane of a wide / narrow window's chunks (a chunk = 64 m buckets). Round 5 gave both kinds the same m, so
+    // a narrow window had half the chunks: 10 x 128 + 2 x 256 = 1792 waves at 2^26 on 1024 SIMDs that hold two of them each -- three
+    // quarters of the SIMDs ran two waves back to back, the rest one. With m_lo = m_wide / 2 every window has the same number of
+    // chunks (3072 waves of two sizes, dealt out as SIMDs free up).
     // nb_stride: buckets between the slots of consecutive windows. The first nlo_w windows of the launch are the NARROW
     // windows of a mixed-width plan: they use the first nb_wide / 2 buckets of their slot = nseg_lo chunks; the others use
     // nb_wide buckets, chunks [seg_lo, seg_lo + nsegr). One launch for both kinds: a window set of ~1800 waves fits the chip
@@ -947,11 +952,12 @@ namespace icicle_hip {
     const uint32_t nlo_blocks = nlo_w * nseg_lo;
     size_t wp;
     uint32_t ch, nb, lch;
+    uint32_t m;
     if (blockIdx.x < nlo_blocks) {
-      wp = blockIdx.x / nseg_lo, lch = blockIdx.x % nseg_lo, ch = lch, nb = nb_wide / 2;
+      wp = blockIdx.x / nseg_lo, lch = blockIdx.x % nseg_lo, ch = lch, nb = nb_wide / 2, m = m_lo;
     } else {
       const uint32_t r = blockIdx.x - nlo_blocks;
-      wp = nlo_w + r / nsegr, lch = r % nsegr, ch = seg_lo + lch, nb = nb_wide;
+      wp = nlo_w + r / nsegr, lch = r % nsegr, ch = seg_lo + lch, nb = nb_wide, m = m_wide;
     }
     const size_t oi = wp * nsegr + lch;
     const uint32_t k0 = ch * 64u * m;
@@ -1017,10 +1023,11 @@ namespace icicle_hip {
   // per window: S = sum_c (V_c + T_c) + chunk * sum_c c * T_c over the nsegr <= blockDim chunks of this device's slice
   // (c = global chunk index = seg_lo + local index)
   template <class C>
-  __global__ __launch_bounds__(ReduceWindowLanes<C>::value) void k_reduce_window(const typename EC<C>::Proj* __restrict__ chunkV, const typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum, uint32_t nsegr_wide, uint32_t seg_lo_wide, uint32_t log_chunk, uint32_t nlo_w, uint32_t nseg_lo)
+  __global__ __launch_bounds__(ReduceWindowLanes<C>::value) void k_reduce_window(const typename EC<C>::Proj* __restrict__ chunkV, const typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum, uint32_t nsegr_wide, uint32_t seg_lo_wide, uint32_t log_chunk_wide, uint32_t nlo_w, uint32_t nseg_lo, uint32_t log_chunk_lo)
   {
-    // (windows [0, nlo_w) of the launch: narrow windows of a mixed-width plan, nseg_lo chunks from 0; chunk rows are nsegr_wide apart)
+    // (windows [0, nlo_w) of the launch: narrow windows of a mixed-width plan, nseg_lo chunks of 2^log_chunk_lo buckets from 0; chunk rows are nsegr_wide apart)
     const uint32_t nsegr = blockIdx.x < nlo_w ? nseg_lo : nsegr_wide, seg_lo = blockIdx.x < nlo_w ? 0u : seg_lo_wide;
+    const uint32_t log_chunk = blockIdx.x < nlo_w ? log_chunk_lo : log_chunk_wide;
     using E = EC<C>;
     constexpr int RWL = ReduceWindowLanes<C>::value;
     __shared__ typename E::Proj sh[RWL];
@@ -1185,12 +1192,14 @@ namespace icicle_hip {
   //   k_precompute_chains  one thread per base: the Jacobian doubling chain (dbl-2009-l, 2M + 5S per step, ~254 (pf-1)/pf steps per
   //                        base, ~960 v_mad_u64_u32 each). After every `shift` doublings the point goes to memory: X and Y (reduced
   //                        Montgomery words) into the table slot it will finally occupy, Z into a side buffer. Nothing is kept.
-  //   k_precompute_affine  Montgomery's trick over runs of PRECOMP_RUN consecutive table entries: prefix products of the Z's to a
+  //   k_precompute_affine  Montgomery's trick over runs of 8 / 32 consecutive table entries: prefix products of the Z's to a
   //                        second side buffer on the way up, ONE inversion per run (rounds 1-3 paid ~314 products per entry), then
   //                        x = X / Z^2, y = Y / Z^3 on the way down, converted to the caller's layout in place.
   // The side buffers hold Z and the prefix for one chunk of bases at a time (msm_precompute_run); their traffic (~5 field elements
   // per entry) is noise beside 254 doublings.
-  constexpr int PRECOMP_RUN = 8;
+  // Entries per inversion: 8 while the table is small (a run is a serial walk: short runs keep the chip busy), 32 once there are
+  // enough runs to fill it -- ~380 products per inversion are 48 per entry at 8 and 12 at 32, against ~590 in the entry's doublings.
+  constexpr int PRECOMP_RUN_SMALL = 8, PRECOMP_RUN_LARGE = 32;
   template <class C>
   __device__ __forceinline__ void store_point_words(uint32_t* __restrict__ dst, const uint32_t* w, bool aligned16)
   {
@@ -1244,7 +1253,7 @@ namespace icicle_hip {
     for (int j = 1; j < pf; j++) {
       if (!ident) {
         for (int sft = 0; sft < shift; sft++)
-          jp = E::dbl_jac(jp);
+          jp = E::dbl_jac_lazy(jp); // (G1: two conditional subtractions per step instead of eight, ec.hpp)
         ident = F::is_zero(jp.z); // a point of order two doubles to Z = 0 (and stays there)
       }
       uint32_t* zdst = zbuf + ((size_t)t * (pf - 1) + (j - 1)) * E::N32;
@@ -1264,17 +1273,17 @@ namespace icicle_hip {
         zdst[k] = zw[k];
     }
   }
-  // entries q of the chunk (q = (i - i0) * (pf - 1) + j - 1, q < nq): one thread per run of PRECOMP_RUN consecutive q
+  // entries q of the chunk (q = (i - i0) * (pf - 1) + j - 1, q < nq): one thread per run of `run` consecutive q
   template <class C, int MINW>
-  __global__ __launch_bounds__(64, MINW) void k_precompute_affine(uint32_t* __restrict__ out, const uint32_t* __restrict__ zbuf, uint32_t* __restrict__ pbuf, long long i0, long long nq, int pf, bool refmont, bool out16)
+  __global__ __launch_bounds__(64, MINW) void k_precompute_affine(uint32_t* __restrict__ out, const uint32_t* __restrict__ zbuf, uint32_t* __restrict__ pbuf, long long i0, long long nq, int pf, bool refmont, bool out16, int run)
   {
     using E = EC<C>;
     using F = typename E::F;
     using fe = typename F::fe;
     constexpr int PW = 2 * E::N32;
-    const long long q0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * PRECOMP_RUN;
+    const long long q0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * run;
     if (q0 >= nq) return;
-    const int m = (int)(nq - q0 < PRECOMP_RUN ? nq - q0 : PRECOMP_RUN);
+    const int m = (int)(nq - q0 < run ? nq - q0 : run);
     fe acc = F::one();
     for (int k = 0; k < m; k++) { // prefix products (of the non-zero Z's) before entry k
       uint32_t zw[E::N32];
@@ -1805,7 +1814,11 @@ namespace icicle_hip {
         // rest wide; one launch of each kernel serves both (a uniform plan has n_lo = 0: no narrow windows). (bb == 1 whenever n_lo > 0)
         const int split = std::min(std::max(pl.n_lo, w0), w0 + nw);
         const uint32_t nlo_w = (uint32_t)(split - w0);
-        const uint32_t nseg_lo = std::max<uint32_t>(1, (nb / 2) / m);
+        // narrow windows: half the rows per lane, so that they have as many chunks as the wide ones (see k_reduce_wave)
+        static const bool balance = !(getenv("ICICLE_HIP_MSM_REDUCE_BALANCE") && atoi(getenv("ICICLE_HIP_MSM_REDUCE_BALANCE")) == 0);
+        const uint32_t mrow_lo = (balance && nlo_w > 0 && mrow >= 2 && !hook) ? mrow / 2 : mrow;
+        const uint32_t nseg_lo = std::max<uint32_t>(1, (nb / 2) / (64 * mrow_lo));
+        const uint32_t log_chunk_lo = mrow_lo == mrow ? log_chunk : log_chunk - 1;
         const bool direct = (nseg == 1 && nsegr == 1 && seg_lo == 0);
         typename E::Proj* win = d_win.as<typename E::Proj>() + w0;
         typename E::Proj* cV = chunkV + (size_t)w0 * nseg;
@@ -1821,14 +1834,14 @@ namespace icicle_hip {
           k_reduce_small<C><<<(unsigned)(((size_t)nw + per_wave - 1) / per_wave), 64, 0, sq>>>(buckets + (size_t)w0 * nb, win, nb, lw_log, (uint32_t)nw);
           LAUNCH_CHECK("k_reduce_small", sq);
         } else if (nblocks) {
-          k_reduce_wave<C><<<(unsigned)nblocks, 64, 0, sq>>>(buckets + (size_t)w0 * nb, cV, cT, direct ? win : nullptr, nb, nb, mrow, seg_lo, nsegr, nlo_w, nseg_lo);
+          k_reduce_wave<C><<<(unsigned)nblocks, 64, 0, sq>>>(buckets + (size_t)w0 * nb, cV, cT, direct ? win : nullptr, nb, nb, mrow, seg_lo, nsegr, nlo_w, nseg_lo, mrow_lo);
           LAUNCH_CHECK("k_reduce_wave", sq);
         }
         if (!direct) {
           unsigned rthreads = 64; // power of two (LDS tree), >= the chunks of a window
           while (rthreads < std::max(nsegr, nlo_w ? nseg_lo : 0u) && rthreads < RWL)
             rthreads <<= 1;
-          k_reduce_window<C><<<(unsigned)nw, rthreads, 0, sq>>>(cV, cT, win, nsegr, seg_lo, log_chunk, nlo_w, nseg_lo);
+          k_reduce_window<C><<<(unsigned)nw, rthreads, 0, sq>>>(cV, cT, win, nsegr, seg_lo, log_chunk, nlo_w, nseg_lo, log_chunk_lo);
           LAUNCH_CHECK("k_reduce_window", sq);
         }
         if (NG > 1) { // (bb == 1) this group's windows, scaled, into its partial slots
@@ -1858,7 +1871,9 @@ namespace icicle_hip {
         // are a 1.4 KB download that replaces the download of the result. Single MSMs only (a batch of 1024 combines runs in
         // parallel on the GPU); device-resident results keep k_final. ICICLE_HIP_MSM_HOST_COMBINE=0: always k_final.
         static const bool host_combine_env = !(getenv("ICICLE_HIP_MSM_HOST_COMBINE") && atoi(getenv("ICICLE_HIP_MSM_HOST_COMBINE")) == 0);
-        if (host_combine_env && !cfg->are_results_on_device && batch == 1 && bb == 1 && !hook && wpf <= 64) {
+        // (a device-resident result of a SYNCHRONOUS call takes the same route -- the call waits for the stream anyway -- and the 96 / 144
+        //  bytes go back up: 2^20 2.99 -> see profiles/r06_notes.md; an asynchronous call must not block, so it keeps k_final)
+        if (host_combine_env && (!cfg->are_results_on_device || !cfg->is_async) && batch == 1 && bb == 1 && !hook && wpf <= 64) {
           typename E::Proj hw[64];
           HIP_TRY(hipMemcpyAsync(hw, d_win.ptr(), (size_t)wpf * sizeof(typename E::Proj), hipMemcpyDeviceToHost, st), ICICLE_COPY_FAILED);
           KernelTimer::end(3, st);
@@ -1870,7 +1885,14 @@ namespace icicle_hip {
               j = E::dbl_jac(j);
             acc = E::add(E::from_jac(j), hw[w]);
           }
-          E::store_proj_canonical((uint32_t*)results_v, acc);
+          if (cfg->are_results_on_device) {
+            uint32_t words[RW];
+            E::store_proj_canonical(words, acc);
+            HIP_TRY(hipMemcpyAsync(results_v, words, sizeof(words), hipMemcpyHostToDevice, st), ICICLE_COPY_FAILED);
+            HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
+          } else {
+            E::store_proj_canonical((uint32_t*)results_v, acc);
+          }
           return ICICLE_SUCCESS;
         }
         static const bool horner_on = !(getenv("ICICLE_HIP_MSM_BATCH_HORNER") && atoi(getenv("ICICLE_HIP_MSM_BATCH_HORNER")) == 0);
@@ -2015,8 +2037,9 @@ namespace icicle_hip {
         k_precompute_chains<C, MINW><<<(unsigned)((cnt + 63) / 64), 64, 0, st>>>(d_in, d_out, zbuf, i0, cnt, pf, shift, cfg->are_points_montgomery_form, in16, out16);
         LAUNCH_CHECK("k_precompute_chains", st);
         const long long nq = (long long)cnt * (pf - 1);
-        const long long runs = (nq + PRECOMP_RUN - 1) / PRECOMP_RUN;
-        k_precompute_affine<C, MINW><<<(unsigned)((runs + 63) / 64), 64, 0, st>>>(d_out, zbuf, pbuf, i0, nq, pf, cfg->are_points_montgomery_form, out16);
+        const int run = nq >= (long long)PRECOMP_RUN_LARGE * 256 * 1024 ? PRECOMP_RUN_LARGE : PRECOMP_RUN_SMALL;
+        const long long runs = (nq + run - 1) / run;
+        k_precompute_affine<C, MINW><<<(unsigned)((runs + 63) / 64), 64, 0, st>>>(d_out, zbuf, pbuf, i0, nq, pf, cfg->are_points_montgomery_form, out16, run);
         LAUNCH_CHECK("k_precompute_affine", st);
       }
     }

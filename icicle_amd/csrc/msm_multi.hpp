@@ -236,10 +236,9 @@ namespace icicle_hip {
       GateTicket t_gather(use_rccl ? &gate_gather : nullptr);
       if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED; // (tickets arrive with "failed" on the way out)
       if (icicle_hip_set_device(ds.devs[p]) != ICICLE_SUCCESS) return ICICLE_INVALID_DEVICE;
-      if (ds.devs[p] != home) { // operands are pulled from the calling device: direct xGMI copies where the platform allows them
-        (void)hipDeviceEnablePeerAccess(home, 0); // (already enabled / not supported: the copies then take the runtime's own route)
-        (void)hipGetLastError();
-      }
+      // operands are pulled from the calling device: direct xGMI copies where the platform allows them, hipMemcpyPeerAsync
+      // (host-staged by the runtime) where peer access is refused -- common.h PeerRoute
+      const PeerRoute route = peer_route(ds.devs[p], home);
       // one slot: the caller's stream. Several: a long-lived stream per (device, slot) -- never a stream created and
       // destroyed per call: the workspace arenas keep last-use events recorded on whatever stream used them, and an event
       // whose stream is gone makes later hipEventSynchronize / hipStreamWaitEvent calls fail (seen in the rehearsal suite)
@@ -314,7 +313,7 @@ namespace icicle_hip {
                     return ICICLE_SYNCHRONIZATION_FAILED;
                   }
                   if (hipEventCreateWithFlags(&rs.ready, hipEventDisableTiming) != hipSuccess ||
-                      hipMemcpy2DAsync(rs.ptr, row, src, (size_t)n * pf * PW * 4, row, brows, hipMemcpyDefault, cs) != hipSuccess ||
+                      peer_copy2d(rs.ptr, row, src, (size_t)n * pf * PW * 4, row, brows, route, true, cs) != hipSuccess ||
                       hipEventRecord(rs.ready, cs) != hipSuccess) {
                     (void)hipGetLastError();
                     if (rs.ready) (void)hipEventDestroy(rs.ready);
@@ -350,14 +349,14 @@ namespace icicle_hip {
             if (s.leased) HIP_TRY(hipStreamWaitEvent(cs, s.leased, 0), ICICLE_SYNCHRONIZATION_FAILED);
             if (s.copy_sc) {
               const uint32_t* src = (const uint32_t*)scalars_v + (size_t)s.lo * SW;
-              HIP_TRY(hipMemcpy2DAsync(s.sc.ptr(), (size_t)s.ns * SW * 4, src, (size_t)n * SW * 4, (size_t)s.ns * SW * 4, batch, hipMemcpyDefault, cs), ICICLE_COPY_FAILED);
+              HIP_TRY(peer_copy2d(s.sc.ptr(), (size_t)s.ns * SW * 4, src, (size_t)n * SW * 4, (size_t)s.ns * SW * 4, batch, route, true, cs), ICICLE_COPY_FAILED);
               s.scp = (const uint32_t*)s.sc.ptr();
               multi_stats().staged_scalar_bytes += (size_t)batch * s.ns * SW * 4;
             }
             if (s.copy_b) {
               const size_t row = (size_t)s.ns * pf * PW * 4;
               const uint32_t* src = (const uint32_t*)bases_v + (size_t)s.lo * pf * PW;
-              HIP_TRY(hipMemcpy2DAsync(s.b.ptr(), row, src, (size_t)n * pf * PW * 4, row, brows, hipMemcpyDefault, cs), ICICLE_COPY_FAILED);
+              HIP_TRY(peer_copy2d(s.b.ptr(), row, src, (size_t)n * pf * PW * 4, row, brows, route, true, cs), ICICLE_COPY_FAILED);
               s.bp = (const uint32_t*)s.b.ptr();
               multi_stats().staged_base_bytes += row * brows;
             }

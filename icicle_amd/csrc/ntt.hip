@@ -584,8 +584,14 @@ namespace icicle_hip {
     const uint32_t ltot = cfg->columns_batch ? (uint32_t)batch * lanes : lanes;
     const bool lane_native = lanes_on && fast && ltot > 1;
     const uint32_t row_groups = cfg->columns_batch ? 1u : (uint32_t)batch;
+    // Ragged interleaved layouts (columns_batch with a lane count that is not a multiple of 32 words: the Rust suite's 100
+    // columns): the WORK buffer pads the lane count to the next multiple of 32, so that only the two passes that touch the
+    // caller's buffers see rows that straddle sectors (ntt_plan.h NttLaunch::es_out). ICICLE_HIP_NTT_PAD_LANES=0: off (A/B).
+    static const bool pad_on = !(getenv("ICICLE_HIP_NTT_PAD_LANES") && atoi(getenv("ICICLE_HIP_NTT_PAD_LANES")) == 0);
+    const bool pad_w = pad_on && lane_native && cfg->columns_batch && P >= 2 && !prerev && !rn_native && !grouped && ltot > 32 && ltot % 32 != 0;
+    const uint64_t es_w = pad_w ? (uint64_t)((ltot + 31) / 32) * 32 : nl.es;
     if (P >= 2 && !rn_native) {
-      HIP_TRY(d_work.alloc(grouped ? (size_t)rows_per_group * n * 4 : bytes, st), ICICLE_ALLOCATION_FAILED);
+      HIP_TRY(d_work.alloc(pad_w ? (size_t)n * es_w * 4 : (grouped ? (size_t)rows_per_group * n * 4 : bytes), st), ICICLE_ALLOCATION_FAILED);
       W = d_work.as<uint32_t>();
     }
     KernelTimer::begin(1, st);
@@ -673,6 +679,10 @@ namespace icicle_hip {
       pd.xcd_remap = (xcd_on && fast && tw < 32 && pd.ntiles >= 64 && pd.ntiles % 8 == 0) ? 1 : 0;
       if (fast) {
         NttLaunch nlp = nl;
+        if (pad_w) { // the work buffer's rows are es_w words apart, the caller's ltot
+          nlp.es = (src == W) ? es_w : nl.es;
+          nlp.es_out = (dst == W) ? es_w : nl.es;
+        }
         if (lane_native) { // launch rows = slices of 2^lsh transforms
           nlp.lsh = lsh;
           nlp.ltot = ltot;

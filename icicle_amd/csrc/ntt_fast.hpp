@@ -10,8 +10,9 @@
 namespace icicle_hip {
 
   // ---- fast pass: register-blocked radix-2 butterflies, 4 stages per LDS round trip -------------
-  // Every ordering, coset or not, any batch layout, both directions (bit-reversed INPUT arrives here after the
-  // reordering pre-pass; only single-pass transforms with reversed input are left to the generic kernel).
+  // Every ordering, coset or not, any batch layout, both directions. Bit-reversed INPUT (kRN) is consumed natively by the RN
+  // variants below (round 5); kRR and forward cosets on reversed input still arrive behind the reordering pre-pass, and only
+  // single-pass transforms with reversed input are left to the generic kernel.
   // A pass computes 2^s-point transforms on a [L x T] tile (T adjacent columns => every HBM access is
   // a run of T contiguous words). A thread owns 16 tile elements per "round" and runs up to 4 butterfly
   // stages on them in registers; the FIRST round loads its operands straight from HBM and the LAST
@@ -269,7 +270,8 @@ namespace icicle_hip {
     }
 
     // ---- per-thread HBM offsets (in elements, times the element stride) ----------------------------
-    const uint64_t es = nl.es;
+    const uint64_t es = nl.es;                            // element stride of what this pass READS
+    const uint64_t eso = nl.es_out ? nl.es_out : nl.es;   // ... and of what it WRITES (a work buffer with a padded lane count, ntt_plan.h)
     // column pass: slot (k, t) at in_base + k*sk + t*st on both sides
     // row pass   : load  (k, t) at in_base + k*1  + t*st ; store K0(t) + k_out*out_sk
     const uint64_t K0 = (pd.pidx <= 1) ? ((uint64_t)ct * TC + cB) : (((uint64_t)ct * TC + cB) + (uint64_t)pd.n0 * a);
@@ -393,10 +395,10 @@ namespace icicle_hip {
         for (int u = 0; u < G0; u++)
           ntt_stages<S, NQ0, false, true>(x + u * (1 << NQ0), w0);
         if (NR == 1) {
-          uint32_t* q = pout + (in_base + (uint64_t)cA * pd.in_st + (uint64_t)E * gA) * es;
+          uint32_t* q = pout + (in_base + (uint64_t)cA * pd.in_st + (uint64_t)E * gA) * eso;
 #pragma unroll
           for (int m = 0; m < E; m++)
-            q[(uint64_t)m * es] = rn_fac ? S::mul(x[m], wip[m]) : x[m];
+            q[(uint64_t)m * eso] = rn_fac ? S::mul(x[m], wip[m]) : x[m];
         } else {
 #pragma unroll
           for (int m = 0; m < E; m++)
@@ -414,10 +416,10 @@ namespace icicle_hip {
             }
             ntt_stages<S, 4, false, false>(y, wr[r - 1]);
             if (r == NR - 1) { // slots gA + m * L/16: 4-byte lanes along the run
-              uint32_t* q = pout + (in_base + (uint64_t)cA * pd.in_st + (uint64_t)base) * es;
+              uint32_t* q = pout + (in_base + (uint64_t)cA * pd.in_st + (uint64_t)base) * eso;
 #pragma unroll
               for (int m = 0; m < 16; m++)
-                q[((uint64_t)m << q0) * es] = rn_fac ? S::mul(y[m], wip[m]) : y[m];
+                q[((uint64_t)m << q0) * eso] = rn_fac ? S::mul(y[m], wip[m]) : y[m];
             } else {
 #pragma unroll
               for (int m = 0; m < 16; m++) {
@@ -457,11 +459,11 @@ namespace icicle_hip {
           }
           ntt_stages<S, NQ0, false, true>(x, w0);
           if (NR == 1) {
-            uint32_t* q = pout + (in_base + (uint64_t)cB * pd.in_st) * es;
+            uint32_t* q = pout + (in_base + (uint64_t)cB * pd.in_st) * eso;
             if (live) {
 #pragma unroll
               for (int m = 0; m < (1 << NQ0); m++)
-                q[(uint64_t)m * pd.in_sk * es] = (RN != 0 && !rn_fac) ? x[m] : S::mul(x[m], wip[m]);
+                q[(uint64_t)m * pd.in_sk * eso] = (RN != 0 && !rn_fac) ? x[m] : S::mul(x[m], wip[m]);
             }
           } else {
 #pragma unroll
@@ -481,8 +483,8 @@ namespace icicle_hip {
               x[m] = tile[(base + ((uint32_t)m << q0)) * TP + tB];
             ntt_stages<S, 4, false, false>(x, wr[r - 1]);
             if (r == NR - 1) {
-              uint32_t* q = pout + (in_base + (uint64_t)base * pd.in_sk + (uint64_t)cB * pd.in_st) * es;
-              const uint64_t step = (pd.in_sk << q0) * es;
+              uint32_t* q = pout + (in_base + (uint64_t)base * pd.in_sk + (uint64_t)cB * pd.in_st) * eso;
+              const uint64_t step = (pd.in_sk << q0) * eso;
               if (live) {
 #pragma unroll
                 for (int m = 0; m < 16; m++)
@@ -516,15 +518,15 @@ namespace icicle_hip {
               x[m] = S::mul(x[m], coset_out ? cfac[m] : nl.ninv_mont);
           }
           if (OUTREV) {
-            uint32_t* q = pout + K0rev * L * es;
+            uint32_t* q = pout + K0rev * L * eso;
             if (live) {
 #pragma unroll
               for (int m = 0; m < (1 << NQ0); m++)
-                q[(uint64_t)m * es] = x[m];
+                q[(uint64_t)m * eso] = x[m];
             }
           } else {
-            uint32_t* q = pout + K0 * es;
-            const uint64_t step = pd.out_sk * es;
+            uint32_t* q = pout + K0 * eso;
+            const uint64_t step = pd.out_sk * eso;
             if (live) {
 #pragma unroll
               for (int m = 0; m < (1 << NQ0); m++)
@@ -599,8 +601,8 @@ namespace icicle_hip {
                 *reinterpret_cast<uint4*>(q + (uint64_t)((wrev << 2) | brev_c<2>(g)) * step) = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
               }
             } else {
-              uint32_t* q = pout + (K0 + (uint64_t)kb * pd.out_sk) * es;
-              const uint64_t step = (pd.out_sk << KB_BITS) * es;
+              uint32_t* q = pout + (K0 + (uint64_t)kb * pd.out_sk) * eso;
+              const uint64_t step = (pd.out_sk << KB_BITS) * eso;
               if (live) {
 #pragma unroll
                 for (int m = 0; m < (1 << NQ0); m++)
@@ -625,16 +627,16 @@ namespace icicle_hip {
               for (int it = 0; it < E; it++) {
                 const uint32_t e = (uint32_t)it * nthr + threadIdx.x;
                 const uint32_t lane = e & lmask, r = (e >> lsh) & (L - 1u), c = e >> (lsh + SS);
-                if (lane < lim) po[(bitrev64(kcol + c, bits) * L + r) * es + lane] = tile[r * TP + ((c << lsh) | lane)];
+                if (lane < lim) po[(bitrev64(kcol + c, bits) * L + r) * eso + lane] = tile[r * TP + ((c << lsh) | lane)];
               }
             } else if (T >= 16) {
               const uint32_t r = threadIdx.x % L, th = threadIdx.x / L;
-              uint32_t* q = pout + (bitrev64(k0b, bits) * L + r) * es;
+              uint32_t* q = pout + (bitrev64(k0b, bits) * L + r) * eso;
 #pragma unroll
               for (int it = 0; it < E; it++) {
                 const uint32_t t = (uint32_t)it * (T >> 4) + th;
                 const uint64_t trev = (uint64_t)(__brev(t) >> (32 - lt));
-                q[((trev << (bits - lt)) * L) * es] = tile[r * TP + t];
+                q[((trev << (bits - lt)) * L) * eso] = tile[r * TP + t];
               }
             } else { // narrow tiles (tiny first factor): plain per-element addressing
               const uint32_t nthr = T * NG16;
@@ -642,7 +644,7 @@ namespace icicle_hip {
               for (int it = 0; it < E; it++) {
                 const uint32_t e = (uint32_t)it * nthr + threadIdx.x;
                 const uint32_t t = e / L, r = e % L;
-                pout[(bitrev64(k0b + t, bits) * L + r) * es] = tile[r * TP + t];
+                pout[(bitrev64(k0b + t, bits) * L + r) * eso] = tile[r * TP + t];
               }
             }
           }

@@ -55,10 +55,7 @@ namespace icicle_hip {
     auto worker = [&](int p) -> icicle_error_t {
       if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED;
       ICICLE_TRY(icicle_hip_set_device(ds.devs[p]));
-      if (ds.devs[p] != home) {
-        (void)hipDeviceEnablePeerAccess(home, 0);
-        (void)hipGetLastError();
-      }
+      const PeerRoute route = peer_route(ds.devs[p], home); // (common.h: direct xGMI copies, or hipMemcpyPeerAsync where peer access is refused)
       hipStream_t st = threaded ? side_stream(200 + p) : job.stream; // long-lived per (device, slot): see msm_multi.hpp
       if (threaded && !st) return ICICLE_STREAM_CREATION_FAILED;
       icicle_error_t rc = [&]() -> icicle_error_t {
@@ -119,7 +116,7 @@ namespace icicle_hip {
           const int rows = rows_of(j, &lo);
           if (in_direct || rows == 0) return ICICLE_SUCCESS;
           HIP_TRY(hipStreamWaitEvent(cin, s.leased, 0), ICICLE_SYNCHRONIZATION_FAILED);
-          HIP_TRY(hipMemcpyAsync(s.buf.ptr(), (const char*)job.input + (size_t)lo * job.row_bytes, (size_t)rows * job.row_bytes, hipMemcpyDefault, cin), ICICLE_COPY_FAILED);
+          HIP_TRY(peer_copy2d(s.buf.ptr(), 0, (const char*)job.input + (size_t)lo * job.row_bytes, 0, (size_t)rows * job.row_bytes, 1, route, true, cin), ICICLE_COPY_FAILED);
           HIP_TRY(hipEventRecord(s.filled, cin), ICICLE_SYNCHRONIZATION_FAILED);
           multi_stats().staged_scalar_bytes += (size_t)rows * job.row_bytes;
           return ICICLE_SUCCESS;
@@ -142,7 +139,7 @@ namespace icicle_hip {
           const int rows = rows_of(j, &lo);
           if (out_direct || rows == 0) return ICICLE_SUCCESS;
           HIP_TRY(hipStreamWaitEvent(cout, s.done, 0), ICICLE_SYNCHRONIZATION_FAILED);
-          HIP_TRY(hipMemcpyAsync((char*)job.output + (size_t)lo * job.row_bytes, s.buf.ptr(), (size_t)rows * job.row_bytes, hipMemcpyDefault, cout), ICICLE_COPY_FAILED);
+          HIP_TRY(peer_copy2d((char*)job.output + (size_t)lo * job.row_bytes, 0, s.buf.ptr(), 0, (size_t)rows * job.row_bytes, 1, route, false, cout), ICICLE_COPY_FAILED);
           HIP_TRY(hipEventRecord(s.drained, cout), ICICLE_SYNCHRONIZATION_FAILED);
           s.has_drain = true;
           return ICICLE_SUCCESS;

@@ -41,7 +41,13 @@ namespace icicle_hip {
     uint32_t nbatch;   // number of independent lane-transforms (batch * lanes)
     uint32_t lanes;    // 1 (scalar) or 4 (quartic extension)
     uint64_t bs;       // offset(b') = (b'/lanes)*bs + (b'%lanes)
-    uint64_t es;       // element stride
+    uint64_t es;       // element stride (of the pass's source)
+    // element stride of the pass's DESTINATION when it differs (0 = es). Interleaved transforms whose count is not a multiple of
+    // 32 (columns_batch with 100 columns: rows of 400 bytes) make every 128-byte access of every pass straddle three 64-byte sectors
+    // instead of two (2.9 TB/s per pass against 4.8, profiles/r05_notes.md section 5). Only the passes that touch the CALLER's
+    // buffers have to see that layout: the work buffer between the passes pads the lane count to a multiple of 32 words, so of the
+    // six memory sides of a three-pass transform four are sector-aligned (the padding lanes are never read or written).
+    uint64_t es_out = 0;
     int in_rev, out_rev; // bit-reversed logical->memory maps
     int inverse;
     uint32_t log_max;

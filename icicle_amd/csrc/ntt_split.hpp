@@ -76,10 +76,7 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
     size_t xi = 0;
     if (test_failure_armed(p, 1)) return ICICLE_ALLOCATION_FAILED;
     ICICLE_TRY(icicle_hip_set_device(ds.devs[p]));
-    if (ds.devs[p] != home) {
-      (void)hipDeviceEnablePeerAccess(home, 0);
-      (void)hipGetLastError();
-    }
+    const PeerRoute route = peer_route(ds.devs[p], home); // (common.h: direct xGMI copies, or hipMemcpyPeerAsync where peer access is refused)
     hipStream_t st = side_stream(200 + p); // long-lived per (device, slot): see msm_multi.hpp
     if (!st) return ICICLE_STREAM_CREATION_FAILED;
     icicle_error_t rc = [&]() -> icicle_error_t {
@@ -136,7 +133,7 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
       for (int bi = 0; bi < batch; bi++) {
         const uint32_t* in_b = input + (size_t)bi * n + (size_t)p * chunk;
         uint32_t* out_b = output + (size_t)bi * n + (size_t)p * chunk;
-        HIP_TRY(hipMemcpyAsync(A, in_b, chunk * 4, hipMemcpyDefault, st), ICICLE_COPY_FAILED); // rows j1 of [n1 x n2]
+        HIP_TRY(peer_copy2d(A, 0, in_b, 0, chunk * 4, 1, route, true, st), ICICLE_COPY_FAILED); // rows j1 of [n1 x n2]
         multi_stats().staged_scalar_bytes += chunk * 4;
         ICICLE_TRY(exchange(A, B, n1, n2)); // B: [n2/P][n1], row = global j2
         sub.batch_size = (int)(n2 / P);
@@ -146,7 +143,7 @@ static icicle_error_t ntt_split_run(const uint32_t* input, int size, int dir, co
         sub.batch_size = (int)(n1 / P);
         ICICLE_TRY(ntt_run<PR>(A, (int)n2, dir, &sub, A, 1)); // over j2 -> k2: X[k1 + n1 k2] at [k1][k2]
         ICICLE_TRY(exchange(A, B, n1, n2)); // B: [n2/P][n1] = X in natural order, chunk p
-        HIP_TRY(hipMemcpyAsync(out_b, B, chunk * 4, hipMemcpyDefault, st), ICICLE_COPY_FAILED);
+        HIP_TRY(peer_copy2d(out_b, 0, B, 0, chunk * 4, 1, route, false, st), ICICLE_COPY_FAILED);
       }
       HIP_TRY(hipStreamSynchronize(st), ICICLE_SYNCHRONIZATION_FAILED);
       return ICICLE_SUCCESS;

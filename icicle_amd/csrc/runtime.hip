@@ -530,6 +530,45 @@ namespace icicle_hip {
     return s;
   }
 
+  static std::atomic<bool> g_no_peer{false}; // icicle_hip_test_set_no_peer_access / ICICLE_HIP_NO_PEER_ACCESS=1
+  PeerRoute peer_route(int self, int home)
+  {
+    static const bool env_off = getenv("ICICLE_HIP_NO_PEER_ACCESS") && atoi(getenv("ICICLE_HIP_NO_PEER_ACCESS")) != 0;
+    PeerRoute r;
+    r.self = self, r.home = home;
+    if (env_off || g_no_peer.load()) {
+      r.direct = false; // (also between two slots of one physical device: the rehearsal of the refused case)
+      return r;
+    }
+    if (self == home) return r;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, self, home) != hipSuccess) can = 0;
+    const hipError_t e = can ? hipDeviceEnablePeerAccess(home, 0) : hipErrorPeerAccessUnsupported;
+    (void)hipGetLastError();
+    r.direct = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
+    if (!r.direct) {
+      static std::atomic<bool> told{false};
+      if (!told.exchange(true)) fprintf(stderr, "[icicle_hip] device %d cannot address device %d directly (%s): operands go through hipMemcpyPeerAsync (host-staged)\n", self, home, hipGetErrorString(e));
+    }
+    return r;
+  }
+  hipError_t peer_copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, const PeerRoute& r, bool other_is_src, hipStream_t st)
+  {
+    if (rows == 0 || width == 0) return hipSuccess;
+    const void* other = other_is_src ? src : (const void*)dst;
+    if (r.direct || !points_to_device_memory(other)) {
+      if (rows == 1) return hipMemcpyAsync(dst, src, width, hipMemcpyDefault, st);
+      return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDefault, st);
+    }
+    const int ddev = other_is_src ? r.self : r.home, sdev = other_is_src ? r.home : r.self;
+    for (size_t i = 0; i < rows; i++) {
+      const hipError_t e = hipMemcpyPeerAsync((char*)dst + i * dpitch, ddev, (const char*)src + i * spitch, sdev, width, st);
+      if (e != hipSuccess) return e;
+    }
+    multi_stats().peer_staged_copies += rows;
+    return hipSuccess;
+  }
+
   hipStream_t side_stream(int which)
   {
     static std::mutex mtx;
@@ -629,6 +668,12 @@ icicle_error_t icicle_hip_test_set_virtual_devices(int slots)
   g_virtual_slots.store(slots);
   return ICICLE_SUCCESS;
 }
+// rehearsal of "hipDeviceEnablePeerAccess refused": cross-device operand copies take the hipMemcpyPeerAsync route (common.h PeerRoute)
+icicle_error_t icicle_hip_test_set_no_peer_access(bool off)
+{
+  g_no_peer.store(off);
+  return ICICLE_SUCCESS;
+}
 icicle_error_t icicle_hip_set_collectives_library(const char* path)
 {
   (void)collectives_path(); // (the environment is read once, before an explicit choice overrides it)
@@ -650,9 +695,9 @@ icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset)
 {
   MultiStats& m = multi_stats();
   if (out) {
-    const uint64_t v[6] = {m.staged_base_bytes.load(), m.staged_scalar_bytes.load(), m.exchanged_bucket_bytes.load(),
-                           m.resident_base_hits.load(), m.threaded_calls.load(), m.exchange_messages.load()};
-    for (int i = 0; i < n && i < 6; i++)
+    const uint64_t v[7] = {m.staged_base_bytes.load(), m.staged_scalar_bytes.load(), m.exchanged_bucket_bytes.load(),
+                           m.resident_base_hits.load(), m.threaded_calls.load(), m.exchange_messages.load(), m.peer_staged_copies.load()};
+    for (int i = 0; i < n && i < 7; i++)
       out[i] = v[i];
   }
   if (reset) {
@@ -662,6 +707,7 @@ icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset)
     m.resident_base_hits = 0;
     m.threaded_calls = 0;
     m.exchange_messages = 0;
+    m.peer_staged_copies = 0;
   }
   return ICICLE_SUCCESS;
 }

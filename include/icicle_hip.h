@@ -385,6 +385,10 @@ icicle_error_t icicle_hip_set_collectives_library(const char* path);
  * before the bucket-exchange gate / the split transform's second exchange) or 3 (right before the result-gather gate); stage 0
  * disarms. */
 icicle_error_t icicle_hip_test_set_virtual_devices(int slots);
+/* Rehearsal of the case "hipDeviceEnablePeerAccess is refused" (also ICICLE_HIP_NO_PEER_ACCESS=1): the in-process multi-GPU paths then move
+ * device-resident operands and results with hipMemcpyPeerAsync (staged through host memory by the HIP runtime when the two devices
+ * are not peers) instead of direct hipMemcpyDefault copies. Counted in icicle_hip_multi_stats2's 7th value. */
+icicle_error_t icicle_hip_test_set_no_peer_access(bool off);
 icicle_error_t icicle_hip_test_inject_failure(int slot, int stage);
 
 /* ---- collision-free aliases used by the reference-runtime plugin (plugin/):

@@ -112,6 +112,20 @@ namespace {
       E::store_proj_canonical(out, E::from_jac(j));
       return 0;
     }
+    case 6: { // msm_precompute_bases' chain: 2^aux[0] * pts[0] via dbl_jac_lazy from Z = 1, reduced at the end (bounds tracked)
+      if (E::words_are_zero(pts)) {
+        E::store_proj_canonical(out, E::proj_identity());
+        return 0;
+      }
+      typename E::Jac j;
+      const auto a = load(pts);
+      j.x = a.x, j.y = a.y, j.z = F::one();
+      for (uint32_t i = 0; i < aux[0]; i++)
+        j = E::dbl_jac_lazy(j);
+      j.x = F::reduce(j.x), j.y = F::reduce(j.y), j.z = F::reduce(j.z);
+      E::store_proj_canonical(out, E::from_jac(j));
+      return 0;
+    }
     default: return -1;
     }
   }

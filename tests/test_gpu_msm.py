@@ -546,6 +546,63 @@ def test_msm_mixed_window_widths(hip, cname, nwin):
     assert refc.is_on_curve(got[0])
 
 
+@pytest.mark.parametrize("cname,g2", [(c, False) for c in CURVES] + [("bn254", True), ("bls12_381", True)])
+def test_window_combine_on_the_gpu_equals_the_host_side_combine(hip, cname, g2):
+    """a single MSM whose result goes to the host -- or stays on the device of a SYNCHRONOUS call -- combines its window
+    sums on one host core (the host build of ec.hpp: dbl_jac + add), an asynchronous device-resident result keeps k_final on the
+    GPU. Both routes on the same inputs, for every curve and G2, with a base table (precompute_factor 4) and with a forced
+    mixed-width plan; the host route is also checked against the reference."""
+    import torch
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname, g2=g2)
+    rng = np.random.default_rng(909)
+    n = 3001
+    bases = M.generate_affine_points(cname, n, k0=4711, g2=g2)
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    L = bases.shape[1] // 2
+    dev = torch.device("cuda", 0)
+    d_sc = torch.from_numpy(sc.view(np.int32)).to(dev)
+
+    def both(table, **cfgkw):
+        d_b = torch.from_numpy(table.view(np.int32)).to(dev)
+        outs = []
+        for on_device, is_async in ((False, False), (True, True), (True, False)):
+            cfg = hip.MSMConfig.default()
+            for k, v in cfgkw.items():
+                setattr(cfg, k, v)
+            cfg.is_async = is_async
+            if on_device:
+                d_out = torch.zeros(3 * L, dtype=torch.int32, device=dev)
+                M.msm(cname, d_sc.data_ptr(), d_b.data_ptr(), cfg, results=d_out.data_ptr(), msm_size=n, g2=g2)
+                torch.cuda.synchronize()
+                outs.append(d_out.cpu().numpy().view(np.uint32).reshape(1, -1))
+            else:
+                out = np.zeros((1, 3 * L), dtype=np.uint32)
+                M.msm(cname, d_sc.data_ptr(), d_b.data_ptr(), cfg, results=out, msm_size=n, g2=g2)
+                outs.append(out)
+        aff = [refc.to_affine(o) for o in outs]
+        assert np.array_equal(aff[0], aff[1]), (cname, g2, cfgkw, "host combine differs from k_final")
+        assert np.array_equal(aff[0], aff[2]), (cname, g2, cfgkw, "synchronous device-resident result")
+        return aff[0]
+
+    exp = refc.to_affine(refc.msm(sc, bases))
+    assert np.array_equal(both(bases), exp)
+    cfgp = hip.MSMConfig.default()
+    cfgp.precompute_factor = 4
+    table = M.precompute_bases(cname, bases, cfgp, g2=g2)
+    assert np.array_equal(both(table, precompute_factor=4), exp)
+    if not g2:
+        ext = lib.create_config_extension()
+        lib.config_extension_set_int(ext, b"hip_msm_windows", 19)
+        try:
+            assert np.array_equal(both(bases, ext=ext), exp)
+        finally:
+            lib.destroy_config_extension(ext)
+
+
 def test_idle_workspace_decays(hip):
     """the temporaries of a large call stayed cached until an allocation failed or the caller asked. Arenas idle
     for ICICLE_HIP_WORKSPACE_DECAY_S seconds (default 30) are now given back by the next call that leases a temporary."""

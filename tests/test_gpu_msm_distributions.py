@@ -118,7 +118,7 @@ def test_bn254_auto_mixed_width_plans_vs_reference(hip, refpool, logn):
     M.msm("bn254", sc.data_ptr(), bases.data_ptr(), cfg, results=out, msm_size=n)
     # the same MSM with the result left on the device (k_final instead of the host-side window combine)
     cfg_d = hip.MSMConfig.default()
-    cfg_d.are_results_on_device = True
+    cfg_d.are_results_on_device, cfg_d.is_async = True, True  # (a synchronous call would combine on the host as well)
     d_out = torch.zeros(24, dtype=torch.int32, device=dev)
     M.msm("bn254", sc.data_ptr(), bases.data_ptr(), cfg_d, results=d_out.data_ptr(), msm_size=n)
     torch.cuda.synchronize()

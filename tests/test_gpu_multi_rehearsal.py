@@ -538,3 +538,61 @@ def test_resident_copies_versioned_by_the_callers_generation(hip, slots):
     finally:
         lib.icicle_hip_msm_release_resident_bases(None)
         lib.destroy_config_extension(ext)
+
+
+def test_operand_copies_when_peer_access_is_refused(hip, slots):
+    """the copy route the in-process multi-GPU paths take when hipDeviceEnablePeerAccess is refused (or
+    ICICLE_HIP_NO_PEER_ACCESS=1): device-resident operands and results of the slots other than the caller's go through
+    hipMemcpyPeerAsync -- which the HIP runtime stages through host memory between non-peer devices -- instead of direct
+    hipMemcpyDefault copies (common.h PeerRoute). Rehearsed on 4 slots: MSM (E1 and E2), base residency, batched NTT row
+    shards; results must equal the reference and the counter must show that the route was taken."""
+    from icicle_amd import msm as M
+    from icicle_amd import ntt as N
+    from icicle_amd._lib import lib, check, multi_stats
+    from icicle_amd.runtime import DeviceVec
+
+    C, rng, bases, sc = _inputs("bn254", 5003, 4242)
+    n = len(sc)
+    refc = ref.RefCurve("bn254")
+    sc2 = np.vstack([sc, to_words(rand_scalars(rng, n, C.r), 8)])
+    exp = refc.to_affine(refc.msm(sc2, bases, batch=2, shared=True))
+    slots(4)
+    check(lib.icicle_hip_test_set_no_peer_access(True))
+    d_sc, d_b = DeviceVec.from_host(sc2), DeviceVec.from_host(bases)
+    try:
+        for exchange in (False, True):
+            ext = _ext(hip_num_devices=4, hip_msm_exchange_buckets=exchange)
+            try:
+                multi_stats(reset=True)
+                cfg = hip.MSMConfig.default()
+                cfg.ext, cfg.batch_size = ext, 2
+                got = M.msm("bn254", d_sc, d_b, cfg, msm_size=n)
+                assert np.array_equal(refc.to_affine(got), exp), exchange
+                st = multi_stats()
+                assert st["threaded_calls"] == 1 and st["peer_staged_copies"] >= 3 * (2 + 1), st  # three remote slots: two scalar rows + the bases each
+            finally:
+                lib.destroy_config_extension(ext)
+        # batched NTT row shards, device-resident rows in and out
+        F = pyref.BABYBEAR
+        logn, rows = 12, 16
+        x = rng.integers(0, F.p, size=rows << logn, dtype=np.uint32)
+        N.init_domain("babybear", N.get_root_of_unity("babybear", 1 << logn))
+        rf = ref.RefNttField("babybear")
+        rf.init_domain(rf.get_root_of_unity(1 << logn))
+        ext = _ext(hip_num_devices=4)
+        d_x, d_y = DeviceVec.from_host(x), DeviceVec(x.nbytes)
+        try:
+            multi_stats(reset=True)
+            ncfg = hip.NTTConfigU32.default()
+            ncfg.batch_size, ncfg.ext = rows, ext
+            N.ntt("babybear", d_x, N.FORWARD, ncfg, out=d_y, size=1 << logn)
+            assert np.array_equal(d_y.to_host(), rf.ntt(x, 1 << logn, 0, batch=rows))
+            assert multi_stats()["peer_staged_copies"] >= 6  # three remote slots, rows in and rows out
+        finally:
+            lib.destroy_config_extension(ext)
+            d_x.free(), d_y.free()
+            N.release_domain("babybear")
+            rf.release_domain()
+    finally:
+        check(lib.icicle_hip_test_set_no_peer_access(False))
+        d_sc.free(), d_b.free()

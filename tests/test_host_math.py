@@ -119,6 +119,10 @@ def test_ec_ops(lib, ci, c):
         assert run(5, [base[2]], [k])[0] == pyref.ec_mul(c, 1 << k, base[2])
     got, raw = run(5, [pyref.INF], [9])
     assert got == pyref.INF and raw[1] != 0
+    for k in [0, 1, 2, 3, 17, 84, 300]:  # msm_precompute_bases' chain: lazily reduced doubling from Z = 1 (bounds asserted by the tracker)
+        for b in (base[2], base[5]):
+            assert run(6, [b], [k])[0] == pyref.ec_mul(c, 1 << k, b)
+    assert run(6, [pyref.INF], [9])[0] == pyref.INF
 
 
 @pytest.mark.parametrize("ci,c", [(2, pyref.BN254_G2), (3, pyref.BLS12_381_G2), (6, pyref.BLS12_377_G2)])
@@ -179,6 +183,8 @@ def test_g2_ec_ops(lib, ci, c):
         assert run(4, [base[2]], [k])[0] == pyref.g2_mul(c, 1 << k, base[2])
     for k in [0, 1, 2, 7, 64, 300]:
         assert run(5, [base[2]], [k])[0] == pyref.g2_mul(c, 1 << k, base[2])
+    for k in [0, 1, 17, 84]:  # (over Fq2 the precompute chain is dbl_jac itself)
+        assert run(6, [base[2]], [k])[0] == pyref.g2_mul(c, 1 << k, base[2])
     got, raw = run(5, [pyref.INF2], [9])
     assert got == pyref.INF2 and raw[1] != (0, 0)
 

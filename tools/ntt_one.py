@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One BabyBear NTT case on the GPU (profiling helper): tools/ntt_one.py LOGN BATCH [reps]   (NTT_ONE_COLUMNS=1: columns_batch,
-NTT_ONE_ORDERING=<0..5>)"""
+"""One NTT case on the GPU (profiling helper): tools/ntt_one.py LOGN BATCH [reps]   (NTT_ONE_COLUMNS=1: columns_batch,
+NTT_ONE_ORDERING=<0..5>, NTT_ONE_FIELD=babybear|koalabear, NTT_ONE_ROUNDTRIP=1: forward + inverse per repetition)"""
 import os
 import sys
 
@@ -16,14 +16,20 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 runtime.set_device(0)
 dev = torch.device("cuda", 0)
 n = 1 << logn
-N.init_domain("babybear", N.get_root_of_unity("babybear", n))
-x = torch.randint(0, 0x78000001, (batch, n), dtype=torch.int32, device=dev)
+field = os.environ.get("NTT_ONE_FIELD", "babybear")
+P = {"babybear": 0x78000001, "koalabear": 0x7F000001}[field]
+N.init_domain(field, N.get_root_of_unity(field, n))
+x = torch.randint(0, P, (batch, n), dtype=torch.int32, device=dev)
 y = torch.empty_like(x)
 cfg = NTTConfigU32.default()
 cfg.batch_size = batch
 cfg.is_async = True
 cfg.columns_batch = os.environ.get("NTT_ONE_COLUMNS", "0") == "1"
 cfg.ordering = int(os.environ.get("NTT_ONE_ORDERING", "0"))
+roundtrip = os.environ.get("NTT_ONE_ROUNDTRIP", "0") == "1"
+z = torch.empty_like(x) if roundtrip else None
 for _ in range(reps):
-    N.ntt("babybear", x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n)
+    N.ntt(field, x.data_ptr(), N.FORWARD, cfg, out=y.data_ptr(), size=n)
+    if roundtrip:
+        N.ntt(field, y.data_ptr(), N.INVERSE, cfg, out=z.data_ptr(), size=n)
 torch.cuda.synchronize()
