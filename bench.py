@@ -805,17 +805,21 @@ def main():
             cn = min(n, 1 << clog)
             hb = np.ascontiguousarray(bases[:cn].cpu().numpy().view(np.uint32))
             hs = np.ascontiguousarray(scalars[:cn].cpu().numpy().view(np.uint32))
+            # the reference's worker count: its default is one per hardware thread, which is NOT its best on a many-core host -- every
+            # worker owns and merges a full bucket set (profiles/r06_ref_scaling.txt: BN254 2^24 on this class of box, 32 workers
+            # 6.6 s, 256 workers 8.5 s). The baseline is timed at the better setting; `cores` says which.
+            ref_threads = 32 if big_host else 0
             t0 = time.perf_counter()
-            exp = refc.msm(hs, hb)
+            exp = refc.msm(hs, hb, n_threads=ref_threads)
             tc = time.perf_counter() - t0
             # parity on the very inputs the CPU was timed on (the full bench inputs when cn == n)
             got = res.cpu().numpy().view(np.uint32).reshape(1, -1) if cn == n else M.msm("bn254", hs, hb)
             parity = bool(np.array_equal(refc.to_affine(got), refc.to_affine(exp)))
             full = cn == n and args.size_log2 == 26
             out["cpu_baseline"] = {
-                "value": (cn / float(1 << 26)) / tc, "unit": "MSM/s", "cores": cores, "kind": "reference",
+                "value": (cn / float(1 << 26)) / tc, "unit": "MSM/s", "cores": ref_threads or cores, "host_threads": cores, "kind": "reference",
                 "sample": (f"the bench workload itself: one BN254 MSM of 2^{args.size_log2} terms took {tc:.2f} s on the reference CPU backend "
-                           f"(oracle/_ref, Taskflow shim, {cores} threads)" if cn == n else
+                           f"(oracle/_ref, Taskflow shim, {ref_threads or cores} worker threads of {cores}: MSMConfig.ext n_threads, the fastest setting measured)" if cn == n else
                            f"one BN254 MSM of 2^{clog} terms (a prefix of the bench inputs) took {tc:.2f} s on the reference CPU backend; value = "
                            f"that rate in 2^26-term MSMs/s assuming linear scaling (Pippenger is sub-linear per point, so this UNDERSTATES the CPU)"),
                 "timed_on_full_workload": full, "parity_with_gpu_on_sample": parity,

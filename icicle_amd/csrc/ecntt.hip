@@ -17,6 +17,7 @@
 // compare to_affine() limbs, as for the MSM.
 #include "ntt_big_common.hpp"
 #include "ec.hpp"
+#include "glv.hpp"
 #include "ntt_plan.h"
 #include <algorithm>
 
@@ -69,26 +70,59 @@ namespace icicle_hip {
         e = (i == 0) ? p : ((i == 1) ? E::dbl(p) : ADD(e, p)); // 0, p, 2p, 3p, ...
       }
       __syncthreads();
+      auto quad_dbl4 = [&](Proj& r) {
+        typename E::Jac j = E::to_jac(r);
+#ifdef ECNTT_NOQUAD
+        for (int q = 0; q < 4; q++)
+          j = E::dbl_jac(j);
+#else
+        for (int q = 0; q < 4; q++)
+          j = E::dbl_jac_quad(j, role);
+#endif
+        r = E::from_jac(j);
+      };
       Proj r = E::proj_identity();
       bool started = false;
+#ifndef ECNTT_NO_GLV // (-DECNTT_NO_GLV: the plain 63-window chain of rounds 3-5, for A/B builds with tools/ab_lib.sh)
+      {
+        // Round 6: k P = k1 P + k2 phi(P), phi(x, y) = (beta x, y), |k1|, |k2| < 2^129 (glv.hpp) -- ONE joint chain of 33 windows
+        // (128 + 4 doublings) with up to two additions each instead of 63 windows (252 doublings) with one: the multiples of
+        // phi(P) are the same table entries with X scaled by beta, a negative half negates the entry's Y. The chain is the latency
+        // of a stage and, from 2^16 points up, its throughput: 252 x 3 + 78 x 5 dependent product latencies become 132 x 3 + 81 x 5.
+        uint32_t k1[5], k2[5];
+        bool n1, n2;
+        glv_decompose<C>(k, k1, n1, k2, n2);
+        const typename F::fe beta = F::from_const(C::GLV_BETA);
+        for (int d = 32; d >= 0; d--) {
+          const uint32_t d1 = (k1[d >> 3] >> ((d & 7) * 4)) & 15u, d2 = (k2[d >> 3] >> ((d & 7) * 4)) & 15u;
+          if (started) quad_dbl4(r);
+          if (d1) {
+            Proj t = tab[d1];
+            if (n1) t.y = F::template neg<4>(F::below4(t.y));
+            r = started ? ADD(r, t) : t;
+            started = true;
+          }
+          if (d2) {
+            Proj t = tab[d2];
+            t.x = F::mul(t.x, beta);
+            if (n2) t.y = F::template neg<4>(F::below4(t.y));
+            r = started ? ADD(r, t) : t;
+            started = true;
+          }
+        }
+      }
+#else
       for (int d = 63; d >= 0; d--) {
         const uint32_t dig = (k[d >> 3] >> ((d & 7) * 4)) & 15u;
         if (started) {
-          typename E::Jac j = E::to_jac(r);
-#ifdef ECNTT_NOQUAD
-          for (int q = 0; q < 4; q++)
-            j = E::dbl_jac(j);
-#else
-          for (int q = 0; q < 4; q++)
-            j = E::dbl_jac_quad(j, role);
-#endif
-          r = E::from_jac(j);
+          quad_dbl4(r);
           if (dig) r = ADD(r, tab[dig]);
         } else if (dig) {
           r = tab[dig];
           started = true;
         }
       }
+#endif
       return r;
     }
     // scalar given as packed Montgomery words (twiddle / coset tables) -> canonical words

@@ -941,7 +941,7 @@ namespace icicle_hip {
     // m_wide / m_lo: rows per lane of a wide / narrow window's chunks (a chunk = 64 m buckets). Round 5 gave both kinds the same m, so
     // a narrow window had half the chunks: 10 x 128 + 2 x 256 = 1792 waves at 2^26 on 1024 SIMDs that hold two of them each -- three
     // quarters of the SIMDs ran two waves back to back, the rest one. With m_lo = m_wide / 2 every window has the same number of
-    // chunks (3072 waves of two sizes, dealt out as SIMDs free up).
+    // chunks (3072 waves of two sizes, dealt out as SIMDs free up). Built, parity-green, measured 3 % slower on the tail: off by default (reduce_group).
     // nb_stride: buckets between the slots of consecutive windows. The first nlo_w windows of the launch are the NARROW
     // windows of a mixed-width plan: they use the first nb_wide / 2 buckets of their slot = nseg_lo chunks; the others use
     // nb_wide buckets, chunks [seg_lo, seg_lo + nsegr). One launch for both kinds: a window set of ~1800 waves fits the chip
@@ -1815,7 +1815,9 @@ namespace icicle_hip {
         const int split = std::min(std::max(pl.n_lo, w0), w0 + nw);
         const uint32_t nlo_w = (uint32_t)(split - w0);
         // narrow windows: half the rows per lane, so that they have as many chunks as the wide ones (see k_reduce_wave)
-        static const bool balance = !(getenv("ICICLE_HIP_MSM_REDUCE_BALANCE") && atoi(getenv("ICICLE_HIP_MSM_REDUCE_BALANCE")) == 0);
+        // Measured and left OFF (profiles/r06_msm_reduce_balance_ab.txt, same box, BN254 2^26): tail 4.72 / 4.75 ms without, 4.90 / 4.86 ms
+        // with -- the extra 1280 waves bring 19 scan additions each, more than the evened-out SIMD load gives back. ICICLE_HIP_MSM_REDUCE_BALANCE=1: on.
+        static const bool balance = getenv("ICICLE_HIP_MSM_REDUCE_BALANCE") && atoi(getenv("ICICLE_HIP_MSM_REDUCE_BALANCE")) != 0;
         const uint32_t mrow_lo = (balance && nlo_w > 0 && mrow >= 2 && !hook) ? mrow / 2 : mrow;
         const uint32_t nseg_lo = std::max<uint32_t>(1, (nb / 2) / (64 * mrow_lo));
         const uint32_t log_chunk_lo = mrow_lo == mrow ? log_chunk : log_chunk - 1;

@@ -518,7 +518,12 @@ namespace icicle_hip {
               x[m] = S::mul(x[m], coset_out ? cfac[m] : nl.ninv_mont);
           }
           if (OUTREV) {
-            uint32_t* q = pout + K0rev * L * eso;
+            // (lane-native column groups: launch row cs of the block holds logical column K0 + cs * tcl, and the column enters the bit
+            //  reversal -- the three-round store below has had this since round 5, this single-round store did not: 2^9-point
+            //  transforms (5 + 4 stages) of 2 or 4 interleaved transforms with kNR / kRR were wrong until the reference's own
+            //  randomised test drew one in round 6, tests/test_gpu_ntt_refspace.py)
+            const uint64_t k0r = LN ? bitrev64(K0 + (uint64_t)((nl.row0 + rloc) % cgrp) * nl.tcl, nl.logn - SS) : K0rev;
+            uint32_t* q = pout + k0r * L * eso;
             if (live) {
 #pragma unroll
               for (int m = 0; m < (1 << NQ0); m++)

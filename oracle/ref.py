@@ -183,6 +183,8 @@ class RefCurve:
         n = scalars.size // 8 // batch
         cfg = MSMConfig(None, precompute_factor, c, bitsize, batch, shared, False, scalars_mont, False, points_mont,
                         False, False, None)
+        if not n_threads:  # (a session-wide default worker count, e.g. tests/conftest.py on many-core hosts)
+            n_threads = int(os.environ.get("ICICLE_REF_MSM_THREADS", "0") or 0)
         ext = None
         if n_threads:
             dev = _load("device")

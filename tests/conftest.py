@@ -9,6 +9,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the reference CPU MSM is fastest with ~32 workers and costs a tenth of the core-seconds of its default (one per hardware thread):
+# tests/refpool.py, profiles/r06_ref_scaling.txt. oracle/ref.py reads this for calls that do not say otherwise.
+if (os.cpu_count() or 1) >= 64:
+    os.environ.setdefault("ICICLE_REF_MSM_THREADS", "32")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "refjob(*keys, order=0): the test joins background reference-CPU jobs of tests/refpool.py; it runs at the end of the session, lower order first")
@@ -82,7 +88,6 @@ def refpool(request):
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
         pool.start()
-        pool.pin_foreground()
         pool.setup_s = time.time() - t0
     request.config._refpool = pool
     yield pool

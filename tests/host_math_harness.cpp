@@ -7,6 +7,7 @@
 #include "../icicle_amd/csrc/ec.hpp"
 #include "../icicle_amd/csrc/smallfield.hpp"
 #include "../icicle_amd/csrc/goldfield.hpp"
+#include "../icicle_amd/csrc/glv.hpp"
 
 using namespace icicle_hip;
 
@@ -130,6 +131,21 @@ namespace {
     }
   }
 } // namespace
+
+// GLV decomposition (glv.hpp): out = |k1| (5 words), neg1, |k2| (5 words), neg2
+extern "C" int host_glv_decompose(int curve, const uint32_t* k, uint32_t* out)
+{
+  bool n1 = false, n2 = false;
+  switch (curve) {
+  case 0: glv_decompose<bn254_g1>(k, out, n1, out + 6, n2); break;
+  case 1: glv_decompose<bls12_381_g1>(k, out, n1, out + 6, n2); break;
+  case 4: glv_decompose<bls12_377_g1>(k, out, n1, out + 6, n2); break;
+  case 5: glv_decompose<grumpkin_g1>(k, out, n1, out + 6, n2); break;
+  default: return -1;
+  }
+  out[5] = n1, out[11] = n2;
+  return 0;
+}
 
 extern "C" int host_field_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out)
 {

@@ -13,11 +13,14 @@ Lanes:
   * NTT jobs run in worker PROCESSES (tests/ref_ntt_worker.py): the reference keeps ONE twiddle domain per field and
     process, and the foreground tests of the same session init / release it at other sizes. Inputs and outputs travel
     as .npy files in a scratch directory (page cache), jobs of one lane run in submission order.
-Host cores are PARTITIONED between the lanes and the foreground (the first measurement ran every lane on all 256 threads of the
-box: the foreground's subprocess tests took 15 x longer and the suite gained nothing): each lane pins itself -- and thereby
-the worker threads the reference spawns, which inherit the mask -- to its share, and the pytest process keeps the rest. The
-reference CPU MSM scales poorly beyond a few dozen threads anyway (256 threads are 8 x faster than 8), so the shares cost
-the background legs little. Below 32 cores nothing is pinned.
+Host cores: the reference CPU MSM does NOT scale with its worker count -- every worker owns a full set of buckets that has to be
+cleared and merged (cpu_msm.hpp:78-100, 365-417). Measured on the 256-thread GPU box (profiles/r06_ref_scaling.txt, BN254 2^24):
+8 workers 13.7 s, 16: 8.0 s, 32: 6.6 s, 64: 7.8 s, 256 (the default): 8.5 s -- thirty-two workers are the fastest AND cost a tenth
+of the core-seconds of the default. So every MSM job runs on its own thread with MSMConfig.ext "n_threads" = 16 (32 for the 2^28
+job), all of them at once; the NTT workers (no such knob: ntt_cpu.h uses hardware_concurrency) are pinned to 32 cores each, and
+the foreground's own reference calls default to 32 workers (oracle/ref.py, ICICLE_REF_MSM_THREADS). The first attempt of round 6
+ran every lane on all 256 threads (the foreground's subprocess tests took 15 x longer), the second gave each lane a fixed share
+of the cores with 256 workers each (the 2^26 references took 200 s instead of 33): profiles/r06_notes.md section 1.
 Nothing here is imported by the product.
 """
 import json
@@ -34,37 +37,30 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# share of the host cores per lane (fractions of os.cpu_count(); the foreground keeps the first quarter)
-LANE_SHARE = {"fg": (0.0, 0.25), "msm_big": (0.25, 0.60), "msm": (0.60, 0.80), "ntt_a": (0.80, 0.90), "ntt_b": (0.90, 1.0)}
-
-
-_ALL_CORES = None  # the cores this process could use before anything was pinned
+# cores of the NTT worker processes (fractions of the cores available to this process); everything else is not pinned
+LANE_SHARE = {"ntt_a": (0.75, 0.875), "ntt_b": (0.875, 1.0)}
+MSM_THREADS = {"msm_big": 32}  # MSMConfig.ext "n_threads" per lane; others: 16
+_ALL_CORES = None
 
 
 def lane_cores(lane):
-    """cores of `lane` (None: no pinning on this host)"""
+    """cores an NTT worker lane is pinned to (None: no pinning on this host / for this lane)"""
     global _ALL_CORES
-    if (os.cpu_count() or 1) < 32 or not hasattr(os, "sched_setaffinity"):
+    if lane not in LANE_SHARE or (os.cpu_count() or 1) < 64 or not hasattr(os, "sched_setaffinity"):
         return None
     if _ALL_CORES is None:
         try:
             _ALL_CORES = sorted(os.sched_getaffinity(0))
         except Exception:
             return None
-    lo, hi = LANE_SHARE.get(lane, LANE_SHARE["msm"])
+    lo, hi = LANE_SHARE[lane]
     n = len(_ALL_CORES)
     return _ALL_CORES[int(lo * n):max(int(lo * n) + 1, int(hi * n))] or None
 
 
-def pin_to_lane(lane):
-    """pin the CALLING thread (pid 0 = this thread on Linux) to the lane's cores; threads it spawns inherit the mask"""
-    cores = lane_cores(lane)
-    if cores:
-        try:
-            os.sched_setaffinity(0, cores)
-        except OSError:
-            pass
-    return cores
+def msm_threads(lane):
+    """worker count of the reference MSM for a job of `lane` (0 = the reference's default: small hosts)"""
+    return MSM_THREADS.get(lane, 16) if (os.cpu_count() or 1) >= 64 else 0
 
 
 class RefPool:
@@ -72,12 +68,6 @@ class RefPool:
         self._futures = {}
         self._lanes = {}
         self._dir = None
-        self._fg_before = None
-        try:
-            self._fg_before = os.sched_getaffinity(0)
-            lane_cores("fg")  # records the cores available to this process before anything is pinned (main thread, unpinned)
-        except Exception:
-            pass
         self._ntt = {}  # lane -> {"jobs": [...], "proc": Popen}
         self._started = {}
         self.timings = {}  # key -> seconds the reference call took (MSM lanes), for the session summary
@@ -86,16 +76,17 @@ class RefPool:
 
     # ---------------------------------------------------------------- MSM: in-process threads
     def _lane(self, name):
-        if name not in self._lanes:
-            self._lanes[name] = ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"ref-{name}")
+        if name not in self._lanes:  # (every MSM job has a thread of its own: the worker count bounds what it takes)
+            self._lanes[name] = ThreadPoolExecutor(max_workers=16, thread_name_prefix=f"ref-{name}")
         return self._lanes[name]
 
     def submit_msm(self, key, curve, scalars: np.ndarray, bases: np.ndarray, lane="msm", **kw):
         """reference msm() on host arrays (kept alive by the closure); result(key) -> projective_t[batch]"""
         from oracle import ref
 
+        kw.setdefault("n_threads", msm_threads(lane))
+
         def run():
-            pin_to_lane(lane)
             t0 = time.time()
             out = ref.RefCurve(curve).msm(scalars, bases, **kw)
             self.timings[key] = time.time() - t0
@@ -128,10 +119,6 @@ class RefPool:
                 "coset_gen": coset_gen, "chain": chain or []}
         self._ntt.setdefault(lane, {"jobs": []})["jobs"].append(spec)
         self._futures[key] = ("ntt", lane, 1 + len(spec["chain"]))
-
-    def pin_foreground(self):
-        """the pytest process (and the subprocesses its tests spawn) keep the foreground share of the cores"""
-        pin_to_lane("fg")
 
     def start(self):
         """spawn the worker processes (after every submit_ntt of the session)"""
@@ -194,8 +181,3 @@ class RefPool:
         if self._dir:
             shutil.rmtree(self._dir, ignore_errors=True)
             self._dir = None
-        if self._fg_before:
-            try:
-                os.sched_setaffinity(0, self._fg_before)
-            except OSError:
-                pass

@@ -1,0 +1,64 @@
+"""GPU parity over the WHOLE configuration space the reference's own NTT test draws from at random.
+
+icicle/tests/test_mod_arithmetic_api.h:614-695 (TYPED_TEST ModArithTest.ntt, run for scalar_t and extension_t) seeds itself from
+the clock and draws ONE configuration per run: logn in 0..17, a domain of 2^(logn + 2), batch 1 / 2 / 4, columns_batch, in place or
+not, direction, ordering kNN / kNR / kRN / kRR and a coset generator omega(logn + stride), stride 0 / 1 / 2. tests/
+test_gpu_reference_suite.py runs that very binary on this backend -- so every CI run tested one random point, and in round 6 a run
+drew (extension field, N = 512, kRR, domain 2^11) and failed. This module walks the space exhaustively up to 2^12 points for both
+31-bit fields, base and extension, byte-comparing with the reference CPU backend (memcmp rule of the reference test, line 694), so a
+configuration that breaks is found by construction and not by the luck of a seed."""
+import numpy as np
+import pytest
+
+from oracle import pyref, ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fname", ["babybear", "koalabear"])
+@pytest.mark.parametrize("extension", [False, True])
+def test_every_configuration_the_reference_test_can_draw(hip, fname, extension):
+    from icicle_amd import ntt as N
+    from icicle_amd.runtime import DeviceVec
+
+    F = pyref.NTT_FIELDS[fname]
+    rf = ref.RefNttField(fname)
+    lanes = 4 if extension else 1
+    rng = np.random.default_rng(20260 + lanes)
+    bad, ran = [], 0
+    for logn in range(0, 13):
+        n = 1 << logn
+        dom = logn + 2
+        root = N.get_root_of_unity(fname, 1 << dom)
+        N.init_domain(fname, root)
+        rf.init_domain(root)
+        try:
+            for batch in (1, 2, 4):
+                x = rng.integers(0, F.p, size=n * batch * lanes, dtype=np.uint32)
+                for columns in (False, True):
+                    for direction in (0, 1):
+                        for ordering in (0, 1, 2, 3):
+                            for stride in (0, 1, 2):
+                                coset = 1 if stride == 0 else pyref.omega(F, logn + stride)
+                                cfg = hip.NTTConfigU32.default()
+                                cfg.batch_size, cfg.columns_batch, cfg.ordering, cfg.coset_gen = batch, columns, ordering, coset
+                                got = N.ntt(fname, x, direction, cfg, extension=extension)
+                                exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset, extension=extension)
+                                ran += 1
+                                if not np.array_equal(got, exp):
+                                    bad.append((logn, batch, columns, direction, ordering, stride, "host"))
+                                # device-resident and IN PLACE (the reference test's `inplace` draw) on a rotating subset
+                                if (ran % 5) == 0:
+                                    d = DeviceVec.from_host(x)
+                                    try:
+                                        cfg2 = hip.NTTConfigU32.default()
+                                        cfg2.batch_size, cfg2.columns_batch, cfg2.ordering, cfg2.coset_gen = batch, columns, ordering, coset
+                                        N.ntt(fname, d, direction, cfg2, out=d, size=n, extension=extension)
+                                        if not np.array_equal(d.to_host(), exp):
+                                            bad.append((logn, batch, columns, direction, ordering, stride, "device, in place"))
+                                    finally:
+                                        d.free()
+        finally:
+            N.release_domain(fname)
+            rf.release_domain()
+    assert not bad, f"{fname}{' extension' if extension else ''}: {len(bad)} of {ran} configurations differ from the reference; first (logn, batch, columns_batch, dir, ordering, coset stride): {bad[:24]}"

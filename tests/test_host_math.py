@@ -22,7 +22,7 @@ NL = {0: 8, 1: 8, 2: 12, 3: 8, 4: 12, 5: 8, 6: 8, 7: 2}
 @pytest.fixture(scope="module")
 def lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.hpp", "fq2.hpp", "ec.hpp", "smallfield.hpp", "goldfield.hpp", "field_consts.h")]
+    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.hpp", "fq2.hpp", "ec.hpp", "smallfield.hpp", "goldfield.hpp", "field_consts.h", "glv.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-DBIGFIELD_BOUNDS", "-fPIC", "-shared", SRC, "-o", SO])
     return ctypes.CDLL(SO)
@@ -187,6 +187,47 @@ def test_g2_ec_ops(lib, ci, c):
         assert run(6, [base[2]], [k])[0] == pyref.g2_mul(c, 1 << k, base[2])
     got, raw = run(5, [pyref.INF2], [9])
     assert got == pyref.INF2 and raw[1] != (0, 0)
+
+
+def _consts(cname):
+    """GLV constants of struct <cname>_g1 in the generated header"""
+    import re
+
+    text = open(os.path.join(HERE, "..", "icicle_amd", "csrc", "field_consts.h")).read()
+    body = text[text.index(f"struct {cname}_g1 {{"):]
+    body = body[:body.index("\n};")]
+
+    def arr(name):
+        m = re.search(name + r"\[\d+\] = \{([^}]*)\}", body)
+        return [int(v.rstrip("u"), 16) for v in m.group(1).split(",")]
+
+    return arr
+
+
+@pytest.mark.parametrize("ci,c", [(0, pyref.BN254), (1, pyref.BLS12_381), (4, pyref.BLS12_377), (5, pyref.GRUMPKIN)])
+def test_glv_decomposition(lib, ci, c):
+    """glv.hpp (the ECNTT butterflies' scalar split): k = k1 + k2 lambda mod r with both halves below 2^129, for edge values and
+    random scalars; lambda acts as phi(x, y) = (beta x, y) on the generator (the constants of tools/gen_consts.py pair up)."""
+    arr = _consts(c.name)
+    lam = sum(v << (32 * i) for i, v in enumerate(arr("GLV_LAMBDA")))
+    r, q = c.r, c.q
+    assert (lam * lam + lam + 1) % r == 0
+    nl = len(arr("GLV_BETA"))
+    beta_m = sum(v << (29 * i) for i, v in enumerate(arr("GLV_BETA")))
+    beta = beta_m * pow(1 << (29 * nl), -1, q) % q
+    assert pow(beta, 3, q) == 1 and beta != 1
+    assert pyref.ec_mul(c, lam, (c.gx, c.gy)) == (beta * c.gx % q, c.gy)
+    rnd = random.Random(77 + ci)
+    ks = [0, 1, 2, 3, r - 1, r - 2, lam, lam - 1, lam + 1, r // 2, r // 3, (1 << 128) - 1, 1 << 128, (1 << 253) % r] + [rnd.randrange(r) for _ in range(3000)]
+    out = (ctypes.c_uint32 * 12)()
+    worst = 0
+    for k in ks:
+        assert lib.host_glv_decompose(ci, w(k, 8), out) == 0
+        k1 = sum(int(out[i]) << (32 * i) for i in range(5)) * (-1 if out[5] else 1)
+        k2 = sum(int(out[6 + i]) << (32 * i) for i in range(5)) * (-1 if out[11] else 1)
+        assert (k1 + k2 * lam - k) % r == 0, (c.name, k)
+        worst = max(worst, abs(k1).bit_length(), abs(k2).bit_length())
+    assert worst <= 129, worst
 
 
 @pytest.mark.parametrize("fi,f", [(0, pyref.BABYBEAR), (1, pyref.KOALABEAR)])

@@ -197,6 +197,77 @@ def gen_curve_g2(name, fq, fr):
     return "\n".join(s)
 
 
+def ec_add_aff(P, Q, p):
+    """affine addition on y^2 = x^3 + b (None = identity); generator-time only"""
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    if P[0] == Q[0]:
+        if (P[1] + Q[1]) % p == 0:
+            return None
+        l = 3 * P[0] * P[0] * pow(2 * P[1], -1, p) % p
+    else:
+        l = (Q[1] - P[1]) * pow(Q[0] - P[0], -1, p) % p
+    x = (l * l - P[0] - Q[0]) % p
+    return x, (l * (P[0] - x) - P[1]) % p
+
+
+def ec_mul_aff(k, P, p):
+    R = None
+    while k:
+        if k & 1:
+            R = ec_add_aff(R, P, p)
+        P = ec_add_aff(P, P, p)
+        k >>= 1
+    return R
+
+
+def glv_constants(p, r, gx, gy):
+    """The GLV endomorphism of a j = 0 curve: phi(x, y) = (beta x, y) = lambda (x, y) on the r-torsion (beta^3 = 1 in Fq,
+    lambda^2 + lambda + 1 = 0 mod r), a reduced basis (a1, b1), (a2, b2) of the lattice {(a, b): a + b lambda = 0 mod r} from the
+    extended Euclidean algorithm on (r, lambda) (Guide to ECC, alg. 3.74), and the two rounding multipliers scaled by 2^256.
+    k = k1 + k2 lambda with c_i = sign(G_i) ((k |G_i|) >> 256), k1 = k - c1 a1 - c2 a2, k2 = -c1 b1 - c2 b2, |k_i| < 2^129."""
+    import math
+
+    def roots(m):
+        for g in range(2, 200):
+            w = pow(g, (m - 1) // 3, m)
+            if w != 1:
+                return w, w * w % m
+        raise AssertionError
+
+    pair = None
+    for beta in roots(p):
+        for lam in roots(r):
+            if ec_mul_aff(lam, (gx, gy), p) == (beta * gx % p, gy):
+                pair = (beta, lam)
+    assert pair
+    beta, lam = pair
+    rs = [(r, 1, 0), (lam, 0, 1)]
+    while rs[-1][0] != 0:
+        q = rs[-2][0] // rs[-1][0]
+        rs.append((rs[-2][0] - q * rs[-1][0], rs[-2][1] - q * rs[-1][1], rs[-2][2] - q * rs[-1][2]))
+    sq = math.isqrt(r)
+    l = max(i for i, x in enumerate(rs) if x[0] >= sq)
+    a1, b1 = rs[l + 1][0], -rs[l + 1][2]
+    c1, c2 = (rs[l][0], -rs[l][2]), (rs[l + 2][0], -rs[l + 2][2])
+    a2, b2 = c1 if c1[0] ** 2 + c1[1] ** 2 <= c2[0] ** 2 + c2[1] ** 2 else c2
+    det = a1 * b2 - a2 * b1
+    assert abs(det) == r and (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0
+    sgn = 1 if det > 0 else -1
+    g1 = (b2 * sgn << 256) // r if b2 * sgn >= 0 else -((-b2 * sgn << 256) // r)
+    g2 = (-b1 * sgn << 256) // r if -b1 * sgn >= 0 else -((b1 * sgn << 256) // r)
+    assert max(abs(x).bit_length() for x in (a1, b1, a2, b2)) <= 128 and max(abs(g1).bit_length(), abs(g2).bit_length()) <= 131
+    return beta, lam, (a1, b1, a2, b2), (g1, g2)
+
+
+def words(x, n):
+    """n little-endian 32-bit words of x mod 2^(32 n) (two's complement for negative x)"""
+    x %= 1 << (32 * n)
+    return "{" + ", ".join(f"0x{(x >> (32 * i)) & 0xFFFFFFFF:08x}u" for i in range(n)) + "}"
+
+
 def gen_curve(name, fq, fr, b, gx, gy):
     p, _ = BIG[fq]
     nl = (p.bit_length() + 6 + RB - 1) // RB
@@ -210,6 +281,14 @@ def gen_curve(name, fq, fr, b, gx, gy):
     s.append(f"  static constexpr uint32_t B3[{nl}] = {arr(limbs(3 * b % p * R % p, nl))}; // 3*b, Montgomery")
     s.append(f"  static constexpr uint32_t GX[{nl}] = {arr(limbs(gx * R % p, nl))}; // generator, Montgomery")
     s.append(f"  static constexpr uint32_t GY[{nl}] = {arr(limbs(gy * R % p, nl))};")
+    # GLV endomorphism (glv.hpp): every curve here has j = 0
+    r, _ = BIG[fr]
+    beta, lam, (a1, b1, a2, b2), (g1, g2) = glv_constants(p, r, gx, gy)
+    s.append(f"  static constexpr uint32_t GLV_BETA[{nl}] = {arr(limbs(beta * R % p, nl))}; // phi(x, y) = (beta x, y) = lambda (x, y); Montgomery")
+    s.append(f"  static constexpr uint32_t GLV_LAMBDA[8] = {words(lam, 8)}; // lambda^2 + lambda + 1 = 0 mod r (tests)")
+    s.append(f"  static constexpr uint32_t GLV_A1[5] = {words(a1, 5)}, GLV_B1[5] = {words(b1, 5)}, GLV_A2[5] = {words(a2, 5)}, GLV_B2[5] = {words(b2, 5)}; // lattice basis, two's complement mod 2^160")
+    s.append(f"  static constexpr uint32_t GLV_G1[5] = {words(abs(g1), 5)}, GLV_G2[5] = {words(abs(g2), 5)}; // |round-down(2^256 b2 / det)|, |... -b1 / det|")
+    s.append(f"  static constexpr bool GLV_G1_NEG = {'true' if g1 < 0 else 'false'}, GLV_G2_NEG = {'true' if g2 < 0 else 'false'};")
     s.append("};")
     return "\n".join(s)
 
