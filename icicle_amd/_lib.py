@@ -310,7 +310,8 @@ lib.icicle_hip_test_inject_failure.argtypes = [ctypes.c_int, ctypes.c_int]
 
 def multi_stats(reset=False):
     """dict of the multi-device / pipelined-path counters (icicle_hip_multi_stats)"""
-    out = (ctypes.c_uint64 * 7)()
-    check(lib.icicle_hip_multi_stats2(out, 7, reset), "multi_stats")
-    return dict(zip(("staged_base_bytes", "staged_scalar_bytes", "exchanged_bucket_bytes", "resident_base_hits", "threaded_calls", "exchange_messages", "peer_staged_copies"),
+    out = (ctypes.c_uint64 * 8)()
+    check(lib.icicle_hip_multi_stats2(out, 8, reset), "multi_stats")
+    return dict(zip(("staged_base_bytes", "staged_scalar_bytes", "exchanged_bucket_bytes", "resident_base_hits", "threaded_calls", "exchange_messages", "peer_staged_copies",
+                     "plan_fallbacks"),
                     [int(v) for v in out]))

@@ -137,6 +137,7 @@ namespace icicle_hip {
   Arena* arena_acquire(size_t bytes, hipStream_t st); // nullptr on allocation failure
   void arena_release(Arena* a, hipStream_t st);
   void arena_trim(int device); // frees all idle arenas of a device (icicle_hip_release_workspace, release_domain)
+  void arena_decay(int device); // frees the arenas of a device that have been idle for ICICLE_HIP_WORKSPACE_DECAY_S seconds
   size_t arena_cached_bytes(int device);
 
   // One temporary = one arena lease (released, i.e. made reusable in stream order, on destruction).
@@ -225,6 +226,7 @@ namespace icicle_hip {
   struct MultiStats {
     std::atomic<uint64_t> staged_base_bytes{0}, staged_scalar_bytes{0}, exchanged_bucket_bytes{0}, resident_base_hits{0}, threaded_calls{0}, exchange_messages{0};
     std::atomic<uint64_t> peer_staged_copies{0}; // cross-device copies that took the no-peer-access route (hipMemcpyPeerAsync)
+    std::atomic<uint64_t> plan_fallbacks{0};     // MSMs re-run on the uniform window plan after the mixed-width one did not get its memory
   };
   MultiStats& multi_stats();
   // ---- copies between the caller's device and a worker's device (in-process multi-GPU paths) ----------------------------------
@@ -283,6 +285,7 @@ namespace icicle_hip {
   // freed through icicle_free / the plugin (table_forget_range); a host table is recognised by 32 bytes of its second entry.
   void table_register(const void* table, size_t bytes, size_t entry_bytes, int pf, int c);
   int table_lookup_c(const void* bases, size_t entry_bytes, int pf); // 0: unknown table
+  void table_forget_overlap(const void* dst, size_t size); // a runtime-API write of [dst, dst + size): tables recorded there are stale
   void table_forget_range(const void* ptr); // every table that starts inside the device allocation `ptr` belongs to
 
   // ---- host-thread rendezvous of the multi-device entry points (msm_multi.hpp, ntt_split.hpp) ----

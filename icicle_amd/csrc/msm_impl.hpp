@@ -1429,7 +1429,25 @@ namespace icicle_hip {
 
   // ------------------------------------------------------------------------------------------
   template <class C>
+  static icicle_error_t msm_run_single_planned(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v, MsmBucketHook<C>* hook, int plan_override);
+  // The auto-selected mixed-width plan (2^23 terms and up) holds ~2.15 x the buckets, counters and lists of the uniform plan -- several
+  // GB more for G2 at 2^26. A call that does not get that memory is run again on the uniform plan, which fit before round 5.
+  template <class C>
   static icicle_error_t msm_run_single(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v, MsmBucketHook<C>* hook = nullptr)
+  {
+    // (icicle_hip_test_inject_failure(0, 9): the first attempt "runs out of memory" once -- the rehearsal of this path)
+    icicle_error_t rc = (!hook && test_failure_armed(0, 9)) ? ICICLE_ALLOCATION_FAILED : msm_run_single_planned<C>(scalars_v, bases_v, n, cfg, results_v, hook, 0);
+    if (rc == ICICLE_ALLOCATION_FAILED && !hook && cfg && make_plan(std::max(n, 1), C::fr::NBITS, *cfg, 0).n_lo > 0) {
+      multi_stats().plan_fallbacks++;
+      (void)hipGetLastError();
+      if (cfg->stream) (void)hipStreamSynchronize((hipStream_t)cfg->stream);
+      (void)icicle_hip_release_workspace();
+      rc = msm_run_single_planned<C>(scalars_v, bases_v, n, cfg, results_v, hook, -1);
+    }
+    return rc;
+  }
+  template <class C>
+  static icicle_error_t msm_run_single_planned(const void* scalars_v, const void* bases_v, int n, const icicle_msm_config_t* cfg, void* results_v, MsmBucketHook<C>* hook, int plan_override)
   {
     using E = EC<C>;
     using FR = FieldOps<typename C::fr>;
@@ -1439,8 +1457,8 @@ namespace icicle_hip {
     if (n > 0 && (!scalars_v || !bases_v)) return ICICLE_INVALID_POINTER;
     ICICLE_TRY(bind_current_device());
     hipStream_t st = (hipStream_t)cfg->stream;
-    int force_windows = hook ? -1 : 0; // (a bucket exchange adds bucket arrays of several calls element-wise: uniform widths)
-    if (!hook && cfg->ext) force_windows = std::max(0, reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_msm_windows", 0));
+    int force_windows = hook ? -1 : plan_override; // (a bucket exchange adds bucket arrays of several calls element-wise: uniform widths)
+    if (!hook && plan_override == 0 && cfg->ext) force_windows = std::max(0, reinterpret_cast<const ConfigExt*>(cfg->ext)->get_int("hip_msm_windows", 0));
     {
       static const int env_w = getenv("ICICLE_HIP_MSM_WINDOWS") ? atoi(getenv("ICICLE_HIP_MSM_WINDOWS")) : 0; // A/B: -1 = uniform only
       if (force_windows == 0 && env_w != 0) force_windows = env_w;

@@ -113,34 +113,43 @@ namespace icicle_hip {
   }
   // Decay of the cached workspace (8-12 GiB stayed cached after a 2^26 MSM until an allocation failed
   // or the caller asked): an arena nobody has leased for ICICLE_HIP_WORKSPACE_DECAY_S seconds (default 30, 0 = keep forever)
-  // and whose last user has finished is given back the next time any entry point leases or releases a temporary -- a
-  // loop of calls keeps its arenas, a process that moved on to other work gets the memory back without asking.
+  // and whose last user has finished is given back the next time any entry point leases or releases a temporary, allocates
+  // (icicle_malloc*) or asks for the free memory (icicle_get_available_memory) -- a loop of calls keeps its arenas, a process
+  // that moved on to other work gets the memory back without asking.
   static double now_seconds()
   {
     using namespace std::chrono;
     return duration<double>(steady_clock::now().time_since_epoch()).count();
   }
-  static void arena_decay_locked(int dev)
+  // collects the arenas of `dev` that are due under g_arena_mtx, frees them AFTER dropping it: hipFree synchronises the device and
+  // must not block other threads' leases meanwhile
+  void arena_decay(int dev)
   {
     static const double decay = getenv("ICICLE_HIP_WORKSPACE_DECAY_S") ? atof(getenv("ICICLE_HIP_WORKSPACE_DECAY_S")) : 30.0;
     if (decay <= 0) return;
-    const double t = now_seconds();
-    for (Arena* a : arenas()) {
-      if (a->busy || a->device != dev || !a->base || t - a->released_at < decay) continue;
-      if (a->last_use && hipEventQuery(a->last_use) != hipSuccess) {
-        (void)hipGetLastError();
-        continue;
+    std::vector<void*> due;
+    {
+      std::lock_guard<std::mutex> g(g_arena_mtx);
+      const double t = now_seconds();
+      for (Arena* a : arenas()) {
+        if (a->busy || a->device != dev || !a->base || t - a->released_at < decay) continue;
+        if (a->last_use && hipEventQuery(a->last_use) != hipSuccess) {
+          (void)hipGetLastError();
+          continue;
+        }
+        due.push_back(a->base);
+        a->base = nullptr;
+        a->cap = 0;
       }
-      (void)hipFree(a->base);
-      a->base = nullptr;
-      a->cap = 0;
     }
+    for (void* p : due)
+      (void)hipFree(p);
   }
   Arena* arena_acquire(size_t bytes, hipStream_t st)
   {
     const int dev = current_device_id();
+    arena_decay(dev);
     std::lock_guard<std::mutex> g(g_arena_mtx);
-    arena_decay_locked(dev);
     Arena* best = nullptr;
     Arena* empty = nullptr;
     for (Arena* a : arenas()) {
@@ -188,11 +197,15 @@ namespace icicle_hip {
   }
   void arena_release(Arena* a, hipStream_t st)
   {
-    std::lock_guard<std::mutex> g(g_arena_mtx);
-    (void)hipEventRecord(a->last_use, st);
-    a->last_stream = st;
-    a->busy = false;
-    a->released_at = now_seconds();
+    const int dev = a->device;
+    {
+      std::lock_guard<std::mutex> g(g_arena_mtx);
+      (void)hipEventRecord(a->last_use, st);
+      a->last_stream = st;
+      a->busy = false;
+      a->released_at = now_seconds();
+    }
+    arena_decay(dev); // (OTHER arenas that have been idle long enough: a process that finished its big call and goes on with small ones gets the memory back)
   }
   void arena_trim(int device)
   {
@@ -472,6 +485,23 @@ namespace icicle_hip {
     }
     return t.c;
   }
+  // a write of [dst, dst + size) through the runtime API (icicle_copy*, icicle_memset*): whatever table was recorded there is gone
+  // (a stale entry would hand msm() the OLD table's window size for new contents). Writes by the caller's own kernels
+  // or another allocator's reuse of the memory are not visible here: tables in memory this runtime does not own should pass config.c.
+  void table_forget_overlap(const void* dst, size_t size)
+  {
+    if (!dst || !size) return;
+    std::lock_guard<std::mutex> g(g_table_mtx);
+    if (g_tables.empty()) return;
+    const uintptr_t a = (uintptr_t)dst;
+    auto it = g_tables.upper_bound(a);
+    if (it != g_tables.begin()) {
+      auto pv = std::prev(it);
+      if (pv->first + pv->second.bytes > a) g_tables.erase(pv);
+    }
+    for (it = g_tables.lower_bound(a); it != g_tables.end() && it->first < a + size;)
+      it = g_tables.erase(it);
+  }
   void table_forget_range(const void* ptr)
   {
     if (!ptr) return;
@@ -683,7 +713,7 @@ icicle_error_t icicle_hip_set_collectives_library(const char* path)
 }
 icicle_error_t icicle_hip_test_inject_failure(int slot, int stage)
 {
-  if (stage < 0 || stage > 3) return ICICLE_INVALID_ARGUMENT;
+  if (stage < 0 || (stage > 3 && stage != 9)) return ICICLE_INVALID_ARGUMENT; // (9: the msm() window-plan fallback, msm_impl.hpp)
   g_fail_slot.store(slot);
   g_fail_stage.store(stage);
   return ICICLE_SUCCESS;
@@ -695,9 +725,9 @@ icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset)
 {
   MultiStats& m = multi_stats();
   if (out) {
-    const uint64_t v[7] = {m.staged_base_bytes.load(), m.staged_scalar_bytes.load(), m.exchanged_bucket_bytes.load(),
-                           m.resident_base_hits.load(), m.threaded_calls.load(), m.exchange_messages.load(), m.peer_staged_copies.load()};
-    for (int i = 0; i < n && i < 7; i++)
+    const uint64_t v[8] = {m.staged_base_bytes.load(), m.staged_scalar_bytes.load(), m.exchanged_bucket_bytes.load(), m.resident_base_hits.load(),
+                           m.threaded_calls.load(), m.exchange_messages.load(), m.peer_staged_copies.load(), m.plan_fallbacks.load()};
+    for (int i = 0; i < n && i < 8; i++)
       out[i] = v[i];
   }
   if (reset) {
@@ -708,6 +738,7 @@ icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset)
     m.threaded_calls = 0;
     m.exchange_messages = 0;
     m.peer_staged_copies = 0;
+    m.plan_fallbacks = 0;
   }
   return ICICLE_SUCCESS;
 }
@@ -798,6 +829,7 @@ icicle_error_t icicle_malloc(void** ptr, size_t size)
 {
   if (!ptr) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(bind_current_device());
+  arena_decay(current_device_id());
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && size > total_b) return ICICLE_OUT_OF_MEMORY;
   HIP_TRY(device_alloc(ptr, size ? size : 1), ICICLE_ALLOCATION_FAILED);
@@ -858,6 +890,7 @@ icicle_error_t icicle_get_available_memory(size_t* total, size_t* free)
   if (!total || !free) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(bind_current_device());
   reap_deferred(false);
+  arena_decay(current_device_id());
   HIP_TRY(hipMemGetInfo(free, total), ICICLE_INVALID_DEVICE);
   return ICICLE_SUCCESS;
 }
@@ -866,6 +899,7 @@ icicle_error_t icicle_memset(void* ptr, int value, size_t size)
 {
   if (icicle_is_active_device_memory(ptr) != ICICLE_SUCCESS) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(bind_current_device());
+  table_forget_overlap(ptr, size);
   HIP_TRY(hipMemset(ptr, value, size), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
@@ -874,6 +908,7 @@ icicle_error_t icicle_memset_async(void* ptr, int value, size_t size, icicleStre
 {
   if (icicle_is_active_device_memory(ptr) != ICICLE_SUCCESS) return ICICLE_INVALID_POINTER;
   ICICLE_TRY(bind_current_device());
+  table_forget_overlap(ptr, size);
   HIP_TRY(hipMemsetAsync(ptr, value, size, (hipStream_t)stream), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
@@ -897,6 +932,7 @@ icicle_error_t icicle_copy(void* dst, const void* src, size_t size)
     return ICICLE_SUCCESS;
   }
   ICICLE_TRY(bind_current_device());
+  table_forget_overlap(dst, size);
   HIP_TRY(hipMemcpy(dst, src, size, kind), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
@@ -910,6 +946,7 @@ icicle_error_t icicle_copy_async(void* dst, const void* src, size_t size, icicle
     return ICICLE_SUCCESS;
   }
   ICICLE_TRY(bind_current_device());
+  table_forget_overlap(dst, size);
   HIP_TRY(hipMemcpyAsync(dst, src, size, kind, (hipStream_t)stream), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
@@ -929,12 +966,14 @@ icicle_error_t icicle_copy_to_host_async(void* dst, const void* src, size_t size
 icicle_error_t icicle_copy_to_device(void* dst, const void* src, size_t size)
 {
   ICICLE_TRY(bind_current_device());
+  table_forget_overlap(dst, size);
   HIP_TRY(hipMemcpy(dst, src, size, hipMemcpyHostToDevice), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }
 icicle_error_t icicle_copy_to_device_async(void* dst, const void* src, size_t size, icicleStreamHandle stream)
 {
   ICICLE_TRY(bind_current_device());
+  table_forget_overlap(dst, size);
   HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, (hipStream_t)stream), ICICLE_COPY_FAILED);
   return ICICLE_SUCCESS;
 }

@@ -365,8 +365,10 @@ icicle_error_t icicle_hip_workspace_bytes(size_t* bytes);
 icicle_error_t icicle_hip_msm_release_resident_bases(const void* bases);
 /* Counters of what the multi-device / pipelined paths moved since the last reset: { base bytes staged to a device, scalar
  * bytes staged, bytes sent by the bucket exchange / the split transform's all-to-all, resident-base hits (shards NOT staged
- * again), calls that ran one host thread per device slot, point-to-point messages sent }. icicle_hip_multi_stats2 writes the
- * first min(n, 6) of them; icicle_hip_multi_stats writes exactly the first FIVE (out[5], the contract since round 3). */
+ * again), calls that ran one host thread per device slot, point-to-point messages sent, cross-device copies that took the
+ * no-peer-access route, MSMs re-run on the uniform window plan after the mixed-width plan did not get its memory }.
+ * icicle_hip_multi_stats2 writes the first min(n, 8) of them; icicle_hip_multi_stats writes exactly the first FIVE (out[5], the
+ * contract since round 3). */
 icicle_error_t icicle_hip_multi_stats(uint64_t* out5, bool reset);
 icicle_error_t icicle_hip_multi_stats2(uint64_t* out, int n, bool reset);
 /* What the collectives library (RCCL, or the one set with icicle_hip_set_collectives_library) reported for the most recently created
@@ -383,7 +385,8 @@ icicle_error_t icicle_hip_set_collectives_library(const char* path);
 /* Rehearsal hooks for the multi-device code on a box with fewer GPUs than device slots (tests only): K virtual device slots
  * mapped round-robin onto the physical GPUs, and a one-shot failure of device slot `slot` at stage 1 (worker set-up), 2 (right
  * before the bucket-exchange gate / the split transform's second exchange) or 3 (right before the result-gather gate); stage 0
- * disarms. */
+ * disarms. (slot 0, stage 9): the next single-device msm() "fails to allocate" its first plan once -- the rehearsal of the fallback
+ * from the auto-selected mixed-width window plan to the uniform one. */
 icicle_error_t icicle_hip_test_set_virtual_devices(int slots);
 /* Rehearsal of the case "hipDeviceEnablePeerAccess is refused" (also ICICLE_HIP_NO_PEER_ACCESS=1): the in-process multi-GPU paths then move
  * device-resident operands and results with hipMemcpyPeerAsync (staged through host memory by the HIP runtime when the two devices

@@ -257,6 +257,37 @@ def test_msm_precompute_non_shared_batch(hip, cname):
     assert np.array_equal(refc.to_affine(got1), refc.to_affine(refc.msm(np.ascontiguousarray(sc[:100]), np.ascontiguousarray(bases[:100]))))
 
 
+def test_table_overwritten_through_the_runtime_api_is_not_looked_up_with_its_old_window_size(hip):
+    """msm() with precompute_factor > 1 and c = 0 takes the window size of a table this process wrote from the table
+    registry. A device buffer that held a table built with c = 5 and is then overwritten (icicle_copy_to_device) with a table built
+    with the default c must not be run with c = 5: writes through the runtime API drop the entries they overlap."""
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib, check
+    from icicle_amd.runtime import DeviceVec
+
+    C = pyref.BN254
+    refc = ref.RefCurve("bn254")
+    rng = np.random.default_rng(515)
+    n, pf = 700, 2
+    bases = points_to_array(C, cached_points(C, n))
+    sc = to_words(rand_scalars(rng, n, C.r), 8)
+    exp = refc.to_affine(refc.msm(sc, bases))
+    cfg5 = hip.MSMConfig.default()
+    cfg5.precompute_factor, cfg5.c = pf, 5
+    d_tab = DeviceVec(bases.nbytes * pf)
+    d_in = DeviceVec.from_host(bases)
+    try:
+        M.precompute_bases("bn254", d_in, cfg5, output=d_tab, nof_bases=n)  # registered: this range holds a c = 5 table
+        cfg0 = hip.MSMConfig.default()
+        cfg0.precompute_factor = pf
+        host_tab = M.precompute_bases("bn254", bases, cfg0)  # a table with the default window size, built on the host side
+        check(lib.icicle_copy_to_device(d_tab.ptr, host_tab.ctypes.data, host_tab.nbytes))
+        got = M.msm("bn254", sc, d_tab, cfg0, msm_size=n)  # c = 0: must be derived from msm_size, not read from the stale entry
+        assert np.array_equal(refc.to_affine(got), exp)
+    finally:
+        d_tab.free(), d_in.free()
+
+
 def test_msm_precompute_refuses_a_total_count_that_overruns_the_device_buffers(hip):
     """msm_precompute_bases takes nof_bases as the bases of ONE MSM (both wrappers' convention); a caller
     that hands the TOTAL with per-MSM bases would be read / written batch_size times past its buffers. With device buffers
@@ -628,6 +659,16 @@ N.init_domain("babybear", N.get_root_of_unity("babybear", 16)); N.ntt("babybear"
 check(lib.icicle_hip_workspace_bytes(ctypes.byref(c))); small = c.value
 print("DECAY", big, small)
 assert big > (32 << 20) and small < big // 4, (big, small)
+# ... and without any further msm() / ntt() at all (ADVICE r05: a process that moves on to non-icicle work): asking for the free
+# memory, or a plain icicle_malloc, gives idle arenas back as well
+M.msm("bn254", sc, bases)
+check(lib.icicle_hip_workspace_bytes(ctypes.byref(c))); big2 = c.value
+time.sleep(1.6)
+tot, free = ctypes.c_size_t(), ctypes.c_size_t()
+check(lib.icicle_get_available_memory(ctypes.byref(tot), ctypes.byref(free)))
+check(lib.icicle_hip_workspace_bytes(ctypes.byref(c))); after = c.value
+print("DECAY2", big2, after)
+assert big2 > (32 << 20) and after < big2 // 4, (big2, after)
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ICICLE_HIP_WORKSPACE_DECAY_S="1", PYTHONPATH=root)

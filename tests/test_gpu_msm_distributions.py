@@ -131,6 +131,33 @@ def test_bn254_auto_mixed_width_plans_vs_reference(hip, refpool, logn):
     assert refc.projective_eq(out[0], exp[0])
 
 
+def test_mixed_width_plan_falls_back_to_the_uniform_plan_when_memory_is_short(hip):
+    """the auto-selected mixed-width plan needs ~2.15 x the bucket memory of the uniform one; a call that does not get it
+    runs again on the uniform plan instead of returning ALLOCATION_FAILED. Rehearsed with the one-shot failure hook (slot 0, stage 9)
+    at 2^23 terms, where the plan is a mixed-width one: same group element as the un-armed call, and the counter shows the re-run."""
+    import torch
+    from icicle_amd import msm as M
+    from icicle_amd._lib import lib, check, multi_stats
+
+    refc = ref.RefCurve("bn254")
+    dev = torch.device("cuda", 0)
+    logn = 23
+    sc, bases = make_inputs("uniform", logn, dev, seed=600 + logn)  # (the inputs of the auto-plan test: that result is compared with the reference)
+    plan = (ctypes.c_int * 8)()
+    cfg = hip.MSMConfig.default()
+    assert lib.icicle_hip_msm_plan_info(1 << logn, 254, ctypes.byref(cfg), 0, plan) == 0 and plan[2] > 0
+    out0, out1 = np.zeros((1, 24), dtype=np.uint32), np.zeros((1, 24), dtype=np.uint32)
+    M.msm("bn254", sc.data_ptr(), bases.data_ptr(), cfg, results=out0, msm_size=1 << logn)
+    multi_stats(reset=True)
+    check(lib.icicle_hip_test_inject_failure(0, 9))
+    try:
+        M.msm("bn254", sc.data_ptr(), bases.data_ptr(), hip.MSMConfig.default(), results=out1, msm_size=1 << logn)
+    finally:
+        lib.icicle_hip_test_inject_failure(-1, 0)
+    assert multi_stats()["plan_fallbacks"] == 1
+    assert refc.is_on_curve(out1[0]) and np.array_equal(refc.to_affine(out0), refc.to_affine(out1))
+
+
 def _job_forced22(pool, hip, dev):
     sc, bases = make_inputs("skewed", 22, dev, seed=2222)
     pool.submit_msm("bn254_forced_22_skewed", "bn254", _host(sc), _host(bases))
