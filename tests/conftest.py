@@ -27,6 +27,9 @@ def pytest_collection_modifyitems(config, items):
     late = [it for it in items if it.get_closest_marker("refjob")]
     if late:
         rest = [it for it in items if not it.get_closest_marker("refjob")]
+        # the subprocess tests of bench.py (two ranks + gloo + their own reference legs) are the most sensitive to the first minutes,
+        # when every background job is in its parallel phase: they go behind the other foreground tests
+        rest.sort(key=lambda it: 1 if it.module.__name__.endswith("test_bench_cli") else 0)
         late.sort(key=lambda it: it.get_closest_marker("refjob").kwargs.get("order", 0))
         items[:] = rest + late
     config._refjob_items = late

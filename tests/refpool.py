@@ -16,8 +16,8 @@ Lanes:
 Host cores: the reference CPU MSM does NOT scale with its worker count -- every worker owns a full set of buckets that has to be
 cleared and merged (cpu_msm.hpp:78-100, 365-417). Measured on the 256-thread GPU box (profiles/r06_ref_scaling.txt, BN254 2^24):
 8 workers 13.7 s, 16: 8.0 s, 32: 6.6 s, 64: 7.8 s, 256 (the default): 8.5 s -- thirty-two workers are the fastest AND cost a tenth
-of the core-seconds of the default. So every MSM job runs on its own thread with MSMConfig.ext "n_threads" = 16 (32 for the 2^28
-job), all of them at once; the NTT workers (no such knob: ntt_cpu.h uses hardware_concurrency) are pinned to 32 cores each, and
+of the core-seconds of the default; at 2^26 more workers still help (33 s on 256, 213 s on 16), at 2.5 x the core-seconds. So every
+MSM job runs on its own thread with MSMConfig.ext "n_threads" sized by its term count (8 .. 48, msm_threads()), all of them at once; the NTT workers (no such knob: ntt_cpu.h uses hardware_concurrency) are pinned to 32 cores each, and
 the foreground's own reference calls default to 32 workers (oracle/ref.py, ICICLE_REF_MSM_THREADS). The first attempt of round 6
 ran every lane on all 256 threads (the foreground's subprocess tests took 15 x longer), the second gave each lane a fixed share
 of the cores with 256 workers each (the 2^26 references took 200 s instead of 33): profiles/r06_notes.md section 1.
@@ -39,7 +39,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # cores of the NTT worker processes (fractions of the cores available to this process); everything else is not pinned
 LANE_SHARE = {"ntt_a": (0.75, 0.875), "ntt_b": (0.875, 1.0)}
-MSM_THREADS = {"msm_big": 32}  # MSMConfig.ext "n_threads" per lane; others: 16
 _ALL_CORES = None
 
 
@@ -58,9 +57,13 @@ def lane_cores(lane):
     return _ALL_CORES[int(lo * n):max(int(lo * n) + 1, int(hi * n))] or None
 
 
-def msm_threads(lane):
-    """worker count of the reference MSM for a job of `lane` (0 = the reference's default: small hosts)"""
-    return MSM_THREADS.get(lane, 16) if (os.cpu_count() or 1) >= 64 else 0
+def msm_threads(n_terms):
+    """worker count of the reference MSM for a job of `n_terms` terms per MSM (0 = the reference's default: small hosts). At 2^24 the
+    reference is fastest with 32 workers, at 2^26 it still gains from more (33 s on 256, 213 s on 16): the big jobs get 40-48, so that
+    all jobs together leave the foreground a few dozen cores."""
+    if (os.cpu_count() or 1) < 64:
+        return 0
+    return 48 if n_terms >= (1 << 27) else 40 if n_terms >= (1 << 26) else 24 if n_terms >= (1 << 25) else 16 if n_terms >= (1 << 24) else 8
 
 
 class RefPool:
@@ -84,7 +87,7 @@ class RefPool:
         """reference msm() on host arrays (kept alive by the closure); result(key) -> projective_t[batch]"""
         from oracle import ref
 
-        kw.setdefault("n_threads", msm_threads(lane))
+        kw.setdefault("n_threads", msm_threads(scalars.size // 8 // max(1, kw.get("batch", 1))))
 
         def run():
             t0 = time.time()

@@ -27,8 +27,8 @@ def _check(hip, cname, scalars, bases, refc, **kw):
     cfg.are_scalars_montgomery_form = kw.get("scalars_mont", False)
     got = M.msm(cname, scalars, bases, cfg)
     sc_ref = scalars
-    exp = refc.msm(sc_ref, bases, batch=batch, shared=cfg.are_points_shared_in_batch, bitsize=cfg.bitsize,
-                   scalars_mont=cfg.are_scalars_montgomery_form)
+    exp = kw["expected"]() if "expected" in kw else refc.msm(sc_ref, bases, batch=batch, shared=cfg.are_points_shared_in_batch, bitsize=cfg.bitsize,
+                                                               scalars_mont=cfg.are_scalars_montgomery_form)
     ga, ea = refc.to_affine(got), refc.to_affine(exp)
     assert np.array_equal(ga, ea), f"affine mismatch {cname} {kw}"
     for b in range(batch):
@@ -489,25 +489,43 @@ def test_concurrent_host_threads(hip):
         assert np.array_equal(out_ntt[i], serial_ntt[i])
 
 
-@pytest.mark.parametrize("cname", CURVES)
-def test_msm_large_batch_fused_digit_histogram(hip, cname):
-    """batch >= 512 with enough scalar chunks takes the fused k_digits_count path (digits + pass-A histogram in one
-    kernel; otherwise only reached by the 2^26 run): 600 MSMs of 2^10 terms, shared and per-MSM bases, every result
-    against the reference CPU backend (the perf matrix benchmarks this shape: 1024 x 2^12)."""
-    C = pyref.CURVES[cname]
-    refc = ref.RefCurve(cname)
-    rng = np.random.default_rng(37)
-    n, batch = 1 << 10, 600
+def _large_batch_inputs(cname):
+    """600 MSMs of 2^10 terms on shared bases, 520 of them on per-MSM bases (host arrays; the bases come from the GPU generator)"""
     from icicle_amd import msm as M
 
+    rng = np.random.default_rng(37)
+    n, batch, nb2 = 1 << 10, 600, 520
     bases = M.generate_affine_points(cname, n, k0=4242)
     words = rng.integers(0, 1 << 32, size=(n * batch, 8), dtype=np.uint64).astype(np.uint32)
     words[:, 7] &= 0x0FFFFFFF  # < r for both curves
     words[::97] = 0
-    _check(hip, cname, words, bases, refc, batch=batch, shared=True)
-    nb2 = 520
     bases2 = M.generate_affine_points(cname, n * nb2, k0=99)
-    _check(hip, cname, np.ascontiguousarray(words[: n * nb2]), bases2, refc, batch=nb2, shared=False)
+    return n, batch, nb2, bases, words, bases2
+
+
+def _job_large_batch(cname):
+    def start(pool, hip, dev):  # the two reference batch MSMs (~15-40 s of host time per curve): background jobs of tests/refpool.py
+        n, batch, nb2, bases, words, bases2 = _large_batch_inputs(cname)
+        pool.submit_msm(f"large_batch_{cname}_shared", cname, words, bases, lane="msm_small", batch=batch, shared=True)
+        pool.submit_msm(f"large_batch_{cname}_per_msm", cname, np.ascontiguousarray(words[: n * nb2]), bases2, lane="msm_small", batch=nb2, shared=False)
+    return start
+
+
+for _c in CURVES:
+    REF_JOBS[f"large_batch_{_c}_shared"] = (8, _job_large_batch(_c))
+    REF_JOBS[f"large_batch_{_c}_per_msm"] = (8, REF_JOBS[f"large_batch_{_c}_shared"][1])
+
+
+@pytest.mark.refjob(*[f"large_batch_{c}_{k}" for c in CURVES for k in ("shared", "per_msm")], order=8)
+@pytest.mark.parametrize("cname", CURVES)
+def test_msm_large_batch_fused_digit_histogram(hip, refpool, cname):
+    """batch >= 512 with enough scalar chunks takes the fused k_digits_count path (digits + pass-A histogram in one
+    kernel; otherwise only reached by the 2^26 run): 600 MSMs of 2^10 terms, shared and per-MSM bases, every result
+    against the reference CPU backend (the perf matrix benchmarks this shape: 1024 x 2^12)."""
+    refc = ref.RefCurve(cname)
+    n, batch, nb2, bases, words, bases2 = _large_batch_inputs(cname)
+    _check(hip, cname, words, bases, refc, batch=batch, shared=True, expected=lambda: refpool.result(f"large_batch_{cname}_shared"))
+    _check(hip, cname, np.ascontiguousarray(words[: n * nb2]), bases2, refc, batch=nb2, shared=False, expected=lambda: refpool.result(f"large_batch_{cname}_per_msm"))
 
 
 @pytest.mark.parametrize("curve_id", [0, 1])
