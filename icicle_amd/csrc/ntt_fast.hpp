@@ -67,7 +67,11 @@ namespace icicle_hip {
   // per SIMD (2 blocks of 8 waves per CU) and fit 128 VGPRs; the three-round, coset and bit-reversed-output
   // variants (separate instantiations, so that they do not cost the plain path registers) get 2 (the kNR store needs
   // ~170-185 VGPRs: held to 128 it spilled 236-332 bytes per thread through rounds 1-3, tools/kernel_regs.py)
-  constexpr int ntt_fast_min_waves(int nr, bool extra) { return (nr <= 2 && !extra) ? 4 : 2; }
+  // Round 6: the plain three-round ROW pass (the 512-row last pass of a 2^27-point transform) took 148 VGPRs under a budget of two waves
+  // per SIMD = ONE 512-thread block per CU; held to four waves it compiles to 112 VGPRs without scratch and two blocks fit (the
+  // three-round column pass always did: 120). The coset / bit-reversed-input / bit-reversed-output three-round variants spill at 128
+  // (92 - 132 B, tools/kernel_regs.py) and keep two.
+  constexpr int ntt_fast_min_waves(int nr, bool extra, bool plain_row = false) { return ((nr <= 2 || plain_row) && !extra) ? 4 : 2; }
 
   // 4x4 transpose across the four 16-lane rows of a wave: lanes {l, l+16, l+32, l+48} form a group, in: the lane of
   // row r holds v[c] = M[r][c]; out: v[c] = M[c][r]. gfx950's v_permlane16_swap (odd rows of the first operand <->
@@ -112,7 +116,7 @@ namespace icicle_hip {
   // passes, RN == 1: the DIT column code with direct loads and the factor w_M^(j_{q+1} (column + A_q row)) behind it.
   // The last pass applies 1/N (or g^-k / N) instead. Forward cosets and kRR keep the pre-pass.
   template <class PR, int NQ0, int NR, bool DIF, bool INV, bool COSET, bool OUTREV, bool V4 = false, bool BIG = false, bool LN = false, int RN = 0>
-  __global__ __launch_bounds__(BIG ? 1024 : 512, BIG ? 1 : ntt_fast_min_waves(NR, (COSET && (DIF || LN || RN != 0)) || OUTREV)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
+  __global__ __launch_bounds__(BIG ? 1024 : 512, BIG ? 1 : ntt_fast_min_waves(NR, (COSET && (DIF || LN || RN != 0)) || OUTREV, DIF && !COSET && RN == 0 && !LN)) void k_ntt_fast(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ ctab, PassDesc pd, NttLaunch nl, uint32_t rows_per_block)
   {
     using S = SmallField<PR>;
     constexpr int SS = NQ0 + 4 * (NR - 1);

@@ -8,11 +8,15 @@ the session, and the test body only waits for the future where its assertion nee
 dropped: the same reference call on the same bytes, just earlier and beside the GPU work.
 
 Lanes:
-  * MSM jobs run on two in-process threads (ctypes releases the GIL; the reference's cpu_msm keeps no state between calls):
-    one lane for the five-minute BLS12-381 2^28 job, one for all BN254 jobs in submission order;
-  * NTT jobs run in worker PROCESSES (tests/ref_ntt_worker.py): the reference keeps ONE twiddle domain per field and
-    process, and the foreground tests of the same session init / release it at other sizes. Inputs and outputs travel
-    as .npy files in a scratch directory (page cache), jobs of one lane run in submission order.
+  * every MSM job runs in a worker PROCESS of its own (tests/ref_msm_worker.py), started the moment it is submitted. Threads of the
+    pytest process were tried first (ctypes releases the GIL): eight concurrent jobs then shared ONE address space, and the reference
+    clears and merges gigabytes of per-worker bucket arrays -- every page fault of every job queued on the same mm lock. The box sat
+    at 10 busy cores of 256 while a 2^26 job took 220 s (33 s alone) and a batch of 600 small MSMs 400 s (15 s alone), whatever the
+    worker count (gpurun_out/r06e, profiles/r06_notes.md section 1);
+  * NTT jobs run in worker processes too (tests/ref_ntt_worker.py), one per lane, jobs of a lane in submission order: the
+    reference keeps ONE twiddle domain per field and process, and the foreground tests of the same session init / release it at
+    other sizes.
+  Inputs and outputs travel as .npy files in a scratch directory (a tmpfs on the GPU boxes), mapped by the workers.
 Host cores: the reference CPU MSM does NOT scale with its worker count -- every worker owns a full set of buckets that has to be
 cleared and merged (cpu_msm.hpp:78-100, 365-417). Measured on the 256-thread GPU box (profiles/r06_ref_scaling.txt, BN254 2^24):
 8 workers 13.7 s, 16: 8.0 s, 32: 6.6 s, 64: 7.8 s, 256 (the default): 8.5 s -- thirty-two workers are the fastest AND cost a tenth
@@ -69,35 +73,31 @@ def msm_threads(n_terms):
 class RefPool:
     def __init__(self):
         self._futures = {}
-        self._lanes = {}
         self._dir = None
+        self._msm = {}  # key -> Popen
         self._ntt = {}  # lane -> {"jobs": [...], "proc": Popen}
         self._started = {}
         self.timings = {}  # key -> seconds the reference call took (MSM lanes), for the session summary
         self.finished_at = {}  # key -> seconds after the pool was created (MSM lanes: when the call returned; NTT: when joined)
         self._t0 = time.time()
 
-    # ---------------------------------------------------------------- MSM: in-process threads
-    def _lane(self, name):
-        if name not in self._lanes:  # (every MSM job has a thread of its own: the worker count bounds what it takes)
-            self._lanes[name] = ThreadPoolExecutor(max_workers=16, thread_name_prefix=f"ref-{name}")
-        return self._lanes[name]
-
+    # ---------------------------------------------------------------- MSM: one worker process per job
     def submit_msm(self, key, curve, scalars: np.ndarray, bases: np.ndarray, lane="msm", **kw):
-        """reference msm() on host arrays (kept alive by the closure); result(key) -> projective_t[batch]"""
-        from oracle import ref
-
-        kw.setdefault("n_threads", msm_threads(scalars.size // 8 // max(1, kw.get("batch", 1))))
-
-        def run():
-            t0 = time.time()
-            out = ref.RefCurve(curve).msm(scalars, bases, **kw)
-            self.timings[key] = time.time() - t0
-            self.finished_at[key] = time.time() - self._t0
-            return out
-
+        """reference msm() on host arrays in a process of its own (tests/ref_msm_worker.py), started at once; result(key) ->
+        projective_t[batch]. The arrays travel as .npy files in the scratch directory (a tmpfs on the GPU boxes) and are mapped,
+        not copied, by the worker."""
         assert key not in self._futures, key
-        self._futures[key] = self._lane(lane).submit(run)
+        d = self.scratch()
+        np.save(os.path.join(d, f"in_{key}_scalars.npy"), np.ascontiguousarray(scalars))
+        np.save(os.path.join(d, f"in_{key}_bases.npy"), np.ascontiguousarray(bases))
+        kw.setdefault("n_threads", msm_threads(scalars.size // 8 // max(1, kw.get("batch", 1))))
+        with open(os.path.join(d, f"msm_{key}.json"), "w") as f:
+            json.dump({"key": key, "curve": curve, "kw": kw}, f)
+        log = open(os.path.join(d, f"msm_{key}.log"), "w")
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ref_msm_worker.py"), d, key], stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+        self._msm[key] = proc
+        self._futures[key] = ("msm", key, 1)
 
     # ---------------------------------------------------------------- NTT: worker processes
     def scratch(self):
@@ -145,42 +145,44 @@ class RefPool:
 
     def result(self, key, timeout=1500):
         f = self._futures[key]
-        if isinstance(f, Future):
-            return f.result(timeout=timeout)
-        _, lane, nout = f
-        d, st = self.scratch(), self._ntt[lane]
-        assert lane in self._started, f"lane {lane} was never started"
+        kind, lane, nout = f
+        d = self.scratch()
+        proc = self._msm[key] if kind == "msm" else self._ntt[lane]["proc"]
+        logf = os.path.join(d, f"msm_{key}.log" if kind == "msm" else f"lane_{lane}.log")
+        assert kind == "msm" or lane in self._started, f"lane {lane} was never started"
         done = os.path.join(d, f"done_{key}")
         t0 = time.time()
         while not os.path.exists(done):
-            rc = st["proc"].poll()
+            rc = proc.poll()
             if rc is not None and not os.path.exists(done):
-                raise RuntimeError(f"reference NTT worker (lane {lane}) exited with {rc} before job {key}:\n" + open(os.path.join(d, f"lane_{lane}.log")).read()[-2000:])
+                raise RuntimeError(f"reference worker for job {key} exited with {rc}:\n" + open(logf).read()[-2000:])
             if time.time() - t0 > timeout:
-                raise TimeoutError(f"reference NTT job {key} not done after {timeout} s")
+                raise TimeoutError(f"reference job {key} not done after {timeout} s")
             time.sleep(0.05)
-        outs = [np.load(os.path.join(d, f"out_{key}_{i}.npy"), mmap_mode="r") for i in range(nout)]
         try:
-            self.timings[key] = float(open(done).read() or 0)
-        except ValueError:
+            parts = open(done).read().split()
+            self.timings[key] = float(parts[0])
+            if len(parts) > 1:
+                self.finished_at[key] = float(parts[1]) - self._t0
+        except (ValueError, IndexError):
             pass
+        if kind == "msm":
+            return np.load(os.path.join(d, f"out_{key}.npy"))
+        outs = [np.load(os.path.join(d, f"out_{key}_{i}.npy"), mmap_mode="r") for i in range(nout)]
         return outs if nout > 1 else outs[0]
 
     def drop(self, key):
         """free the files of a finished NTT job"""
         if self._dir:
             for f in os.listdir(self._dir):
-                if f.startswith((f"in_{key}.", f"out_{key}_")):
+                if f.startswith((f"in_{key}.", f"in_{key}_", f"out_{key}_", f"out_{key}.")):
                     os.unlink(os.path.join(self._dir, f))
 
     def close(self):
-        for st in self._ntt.values():
-            p = st.get("proc")
+        for p in [st.get("proc") for st in self._ntt.values()] + list(self._msm.values()):
             if p is not None and p.poll() is None:
                 p.kill()
                 p.wait()
-        for ex in self._lanes.values():
-            ex.shutdown(wait=False, cancel_futures=True)
         if self._dir:
             shutil.rmtree(self._dir, ignore_errors=True)
             self._dir = None
