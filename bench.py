@@ -124,6 +124,25 @@ class GlooViaHost:
         self._d.all_gather_object(out, obj)
 
 
+def effective_host_cores():
+    """CPU time the process can really get: the cgroup quota if there is one (the GPU boxes of this build show 256 hardware threads and
+    grant 16 cores: cat /sys/fs/cgroup/cpu.max -> 1600000 100000), else the visible cores."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def visible_gpus():
     try:
         return torch.cuda.device_count()
@@ -798,17 +817,20 @@ def main():
         try:
             from oracle import ref
 
-            cores = os.cpu_count()
-            big_host = cores >= 64
+            threads_visible = os.cpu_count()
+            cores = effective_host_cores()  # what the cgroup grants: the honest "cores" of this baseline
+            big_host = cores >= 16
+            # the Taskflow stand-in's pool is bounded by twice that (the reference asks for one thread per VISIBLE hardware thread)
+            os.environ.setdefault("ICICLE_TASKFLOW_SHIM_MAX_THREADS", str(2 * cores))
             refc = ref.RefCurve("bn254")
             clog = args.cpu_msm_log2 or (args.size_log2 if big_host else min(20, args.size_log2))
             cn = min(n, 1 << clog)
             hb = np.ascontiguousarray(bases[:cn].cpu().numpy().view(np.uint32))
             hs = np.ascontiguousarray(scalars[:cn].cpu().numpy().view(np.uint32))
-            # the reference's worker count: its default is one per hardware thread, which is NOT its best on a many-core host -- every
-            # worker owns and merges a full bucket set (profiles/r06_ref_scaling.txt: BN254 2^24 on this class of box, 32 workers
-            # 6.6 s, 256 workers 8.5 s). The baseline is timed at the better setting; `cores` says which.
-            ref_threads = 32 if big_host else 0
+            # the reference's worker count: its default is one per visible hardware thread, which is NOT its best -- every worker owns and
+            # merges a full bucket set, and the GPU boxes grant 16 cores of CPU time for their 256 visible threads (profiles/
+            # r06_ref_scaling.txt: BN254 2^24, 32 workers 6.6 s, 256 workers 8.5 s). Timed at the better setting: 2 workers per granted core.
+            ref_threads = 2 * cores if cores < threads_visible else 0
             t0 = time.perf_counter()
             exp = refc.msm(hs, hb, n_threads=ref_threads)
             tc = time.perf_counter() - t0
@@ -817,9 +839,9 @@ def main():
             parity = bool(np.array_equal(refc.to_affine(got), refc.to_affine(exp)))
             full = cn == n and args.size_log2 == 26
             out["cpu_baseline"] = {
-                "value": (cn / float(1 << 26)) / tc, "unit": "MSM/s", "cores": ref_threads or cores, "host_threads": cores, "kind": "reference",
+                "value": (cn / float(1 << 26)) / tc, "unit": "MSM/s", "cores": cores, "worker_threads": ref_threads or threads_visible, "host_threads_visible": threads_visible, "kind": "reference",
                 "sample": (f"the bench workload itself: one BN254 MSM of 2^{args.size_log2} terms took {tc:.2f} s on the reference CPU backend "
-                           f"(oracle/_ref, Taskflow shim, {ref_threads or cores} worker threads of {cores}: MSMConfig.ext n_threads, the fastest setting measured)" if cn == n else
+                           f"(oracle/_ref, Taskflow shim, {ref_threads or threads_visible} worker threads on the {cores} cores of CPU time the host grants; {threads_visible} hardware threads are visible)" if cn == n else
                            f"one BN254 MSM of 2^{clog} terms (a prefix of the bench inputs) took {tc:.2f} s on the reference CPU backend; value = "
                            f"that rate in 2^26-term MSMs/s assuming linear scaling (Pippenger is sub-linear per point, so this UNDERSTATES the CPU)"),
                 "timed_on_full_workload": full, "parity_with_gpu_on_sample": parity,

@@ -6,6 +6,7 @@
 // any schedule yields identical results.
 #pragma once
 #include <atomic>
+#include <cstdlib>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -24,10 +25,27 @@ namespace tf {
     std::vector<std::function<void()>> m_tasks;
   };
 
+  // ICICLE_TASKFLOW_SHIM_MAX_THREADS=<n>: upper bound on the threads of one run(). The reference asks for hardware_concurrency()
+  // workers; a container whose cgroup grants 16 cores of CPU time while 256 are visible (the GPU boxes of this build) then runs 256
+  // threads on 16 cores' worth of quota. tests/conftest.py and bench.py set the bound to what the cgroup grants. Scheduling only:
+  // tasks touch disjoint data, any thread count gives identical results.
+  inline unsigned shim_max_threads()
+  {
+    static const unsigned cap = [] {
+      const char* e = std::getenv("ICICLE_TASKFLOW_SHIM_MAX_THREADS");
+      const long v = e ? std::atol(e) : 0;
+      return v > 0 ? (unsigned)v : 0u;
+    }();
+    return cap;
+  }
+
   class Executor
   {
   public:
-    explicit Executor(unsigned n = std::thread::hardware_concurrency()) : m_n(n ? n : 1) {}
+    explicit Executor(unsigned n = std::thread::hardware_concurrency()) : m_n(n ? n : 1)
+    {
+      if (shim_max_threads() && m_n > shim_max_threads()) m_n = shim_max_threads();
+    }
 
     struct Done {
       void wait() {}

@@ -9,10 +9,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# the reference CPU MSM is fastest with ~32 workers and costs a tenth of the core-seconds of its default (one per hardware thread):
-# tests/refpool.py, profiles/r06_ref_scaling.txt. oracle/ref.py reads this for calls that do not say otherwise.
-if (os.cpu_count() or 1) >= 64:
-    os.environ.setdefault("ICICLE_REF_MSM_THREADS", "32")
+# What the host really grants (the cgroup quota, not the visible hardware threads: tests/refpool.py effective_cores) bounds the threads
+# of every reference call of this session: the MSM's worker count (oracle/ref.py, ICICLE_REF_MSM_THREADS) and the Taskflow stand-in's
+# pool (oracle/shim/taskflow, ICICLE_TASKFLOW_SHIM_MAX_THREADS). 256 threads on 16 cores of quota only burn the quota faster.
+try:
+    from tests.refpool import effective_cores as _effective_cores
+
+    if _effective_cores() < (os.cpu_count() or 1):
+        os.environ.setdefault("ICICLE_REF_MSM_THREADS", str(_effective_cores()))
+        os.environ.setdefault("ICICLE_TASKFLOW_SHIM_MAX_THREADS", str(2 * _effective_cores()))
+except Exception:
+    pass
 
 
 def pytest_configure(config):

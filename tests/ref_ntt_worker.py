@@ -17,12 +17,6 @@ if ROOT not in sys.path:
 
 def main():
     d, lane = sys.argv[1], sys.argv[2]
-    cores = os.environ.get("ICICLE_REFPOOL_CORES")
-    if cores and hasattr(os, "sched_setaffinity"):  # this lane's share of the host cores (tests/refpool.py); the reference's threads inherit it
-        try:
-            os.sched_setaffinity(0, [int(c) for c in cores.split(",")])
-        except OSError:
-            pass
     from oracle import ref
 
     jobs = json.load(open(os.path.join(d, f"lane_{lane}.json")))

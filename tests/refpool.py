@@ -17,14 +17,13 @@ Lanes:
     reference keeps ONE twiddle domain per field and process, and the foreground tests of the same session init / release it at
     other sizes.
   Inputs and outputs travel as .npy files in a scratch directory (a tmpfs on the GPU boxes), mapped by the workers.
-Host cores: the reference CPU MSM does NOT scale with its worker count -- every worker owns a full set of buckets that has to be
-cleared and merged (cpu_msm.hpp:78-100, 365-417). Measured on the 256-thread GPU box (profiles/r06_ref_scaling.txt, BN254 2^24):
-8 workers 13.7 s, 16: 8.0 s, 32: 6.6 s, 64: 7.8 s, 256 (the default): 8.5 s -- thirty-two workers are the fastest AND cost a tenth
-of the core-seconds of the default; at 2^26 more workers still help (33 s on 256, 213 s on 16), at 2.5 x the core-seconds. So every
-MSM job runs on its own thread with MSMConfig.ext "n_threads" sized by its term count (8 .. 48, msm_threads()), all of them at once; the NTT workers (no such knob: ntt_cpu.h uses hardware_concurrency) are pinned to 32 cores each, and
-the foreground's own reference calls default to 32 workers (oracle/ref.py, ICICLE_REF_MSM_THREADS). The first attempt of round 6
-ran every lane on all 256 threads (the foreground's subprocess tests took 15 x longer), the second gave each lane a fixed share
-of the cores with 256 workers each (the 2^26 references took 200 s instead of 33): profiles/r06_notes.md section 1.
+Host cores: the GPU boxes of this build show 256 hardware threads but their cgroup grants 16 cores of CPU time (cpu.max = 1600000
+100000, tools/cpu_probe.sh: 256 busy processes reach a parallelism of 15.7). Every reference leg of rounds 1-5 ran its 256 threads on
+that quota, and the whole suite is bound by it: ~13 000 core-seconds of reference work / 16 = ~800 s whatever the schedule (measured:
+threads of one process 721-782 s, fixed core shares > 681 s, one process per job 810 s -- profiles/r06_notes.md section 1). What the
+pool can do is (i) keep the GPU work off the critical path and (ii) spend fewer core-seconds: the reference MSM is most frugal with
+few workers (msm_threads), the NTT workers and the foreground's reference calls are capped at what the cgroup grants
+(ICICLE_TASKFLOW_SHIM_MAX_THREADS in oracle/shim/taskflow, ICICLE_REF_MSM_THREADS in oracle/ref.py).
 Nothing here is imported by the product.
 """
 import json
@@ -41,33 +40,39 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# cores of the NTT worker processes (fractions of the cores available to this process); everything else is not pinned
-LANE_SHARE = {"ntt_a": (0.75, 0.875), "ntt_b": (0.875, 1.0)}
-_ALL_CORES = None
-
-
-def lane_cores(lane):
-    """cores an NTT worker lane is pinned to (None: no pinning on this host / for this lane)"""
-    global _ALL_CORES
-    if lane not in LANE_SHARE or (os.cpu_count() or 1) < 64 or not hasattr(os, "sched_setaffinity"):
-        return None
-    if _ALL_CORES is None:
+def effective_cores():
+    """CPU time this process can really get: the cgroup quota (cpu.max) if there is one, else the visible cores. The GPU boxes of this
+    build show 256 hardware threads and grant 16 cores of quota (cat /sys/fs/cgroup/cpu.max -> 1600000 100000; tools/cpu_probe.sh)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
         try:
-            _ALL_CORES = sorted(os.sched_getaffinity(0))
-        except Exception:
-            return None
-    lo, hi = LANE_SHARE[lane]
-    n = len(_ALL_CORES)
-    return _ALL_CORES[int(lo * n):max(int(lo * n) + 1, int(hi * n))] or None
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def msm_threads(n_terms):
-    """worker count of the reference MSM for a job of `n_terms` terms per MSM (0 = the reference's default: small hosts). At 2^24 the
-    reference is fastest with 32 workers, at 2^26 it still gains from more (33 s on 256, 213 s on 16): the big jobs get 40-48, so that
-    all jobs together leave the foreground a few dozen cores."""
-    if (os.cpu_count() or 1) < 64:
-        return 0
-    return 48 if n_terms >= (1 << 27) else 40 if n_terms >= (1 << 26) else 24 if n_terms >= (1 << 25) else 16 if n_terms >= (1 << 24) else 8
+    """worker count of the reference MSM for a job of `n_terms` terms per MSM. All jobs run at once and share the cores the cgroup
+    grants, so what matters is core-seconds per job, and the reference is most frugal with FEW workers (every worker owns, clears and
+    merges a full bucket set, cpu_msm.hpp:78-100): profiles/r06_ref_scaling.txt, BN254 2^24: 8 workers 110 core-s, 16: 129, 256: 135
+    at the quota. The one job that is the critical path on its own (2^28) gets as many workers as there are cores."""
+    e = effective_cores()
+    if e <= 8:
+        return 0  # small hosts: the reference's default
+    return e if n_terms >= (1 << 27) else max(4, e // 2) if n_terms >= (1 << 25) else max(2, e // 4)
+
+
+def ntt_worker_threads():
+    """thread cap of an NTT worker process (ICICLE_TASKFLOW_SHIM_MAX_THREADS: the reference asks for hardware_concurrency() threads)"""
+    return max(2, effective_cores() // 2)
 
 
 class RefPool:
@@ -133,9 +138,7 @@ class RefPool:
                 json.dump(st["jobs"], f)
             log = open(os.path.join(d, f"lane_{lane}.log"), "w")
             env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-            cores = lane_cores(lane)
-            if cores:
-                env["ICICLE_REFPOOL_CORES"] = ",".join(str(c) for c in cores)
+            env["ICICLE_TASKFLOW_SHIM_MAX_THREADS"] = str(ntt_worker_threads())
             st["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ref_ntt_worker.py"), d, lane], stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
             self._started[lane] = True
 

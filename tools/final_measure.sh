@@ -15,7 +15,7 @@ python bench.py 2>"$O/bench.err" | grep '^{"metric"' > "$O/bench.json"; echo "be
 python tools/bench_brief.py plain < "$O/bench.json"
 cd /tmp
 rm -rf "$O/prof"
-rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench -- python "$R/bench.py" --no-cpu-baseline > "$O/bench_prof.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench -- python "$R/bench.py" --no-cpu-baseline --no-shard-extras > "$O/bench_prof.log" 2>&1
 grep '^{"metric"' "$O/bench_prof.log" > "$O/bench_prof.json"
 DB=$(find "$O/prof" -name '*.db' | head -1)
 [ -n "$DB" ] && python "$R/tools/rocpd_stats.py" "$DB" > "$O/kernel_stats.txt"

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   O=$R/gpurun_out/pmc_$C
   rm -rf $O; mkdir -p $O
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O -o t -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/log.txt 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O -o t -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-shard-extras > $O/log.txt 2>&1
   F=$(find $O -name "*counter_collection.csv" | head -1)
   python - "$F" "$C" <<'PY'
 import csv, sys, collections
