@@ -652,6 +652,42 @@ def test_window_combine_on_the_gpu_equals_the_host_side_combine(hip, cname, g2):
             lib.destroy_config_extension(ext)
 
 
+@pytest.mark.parametrize("cname,g2", [(c, False) for c in CURVES] + [("bn254", True), ("bls12_381", True), ("bls12_377", True)])
+def test_every_size_and_precompute_factor_the_reference_tests_can_draw(hip, cname, g2):
+    """icicle/tests/test_curve_api.cpp draws ONE point of a small space per run (clock seed): MSM_test N = 2^12 - rand(0..60), batch 1
+    (:36-79); MSM_PRE_COMPUTE_test the same N with batch 3 on shared bases and precompute_factor = rand(1..8) (:125-170); bases from
+    projective_t::rand_host_many (100 points repeated). Here: every N for the plain MSM, every precompute_factor on eight of the sizes
+    (both ends, the size classes around a multiple of 64 / 100) for the table path -- against the reference CPU backend."""
+    from icicle_amd import msm as M
+
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname, g2=g2)
+    rng = np.random.default_rng(4096)
+    nmax = 1 << 12
+    bases_all = refc.generate_affine_points(nmax)
+    sc_all = to_words(rand_scalars(rng, 3 * nmax, C.r), 8)
+    bad = []
+    for r in range(0, 61):
+        n = nmax - r
+        got = M.msm(cname, np.ascontiguousarray(sc_all[:n]), np.ascontiguousarray(bases_all[:n]), g2=g2)
+        exp = refc.msm(np.ascontiguousarray(sc_all[:n]), np.ascontiguousarray(bases_all[:n]))
+        if not (np.array_equal(refc.to_affine(got), refc.to_affine(exp)) and refc.is_on_curve(got[0])):
+            bad.append(("msm", n))
+    for r in (0, 1, 4, 32, 33, 59, 60, 17):
+        n = nmax - r
+        b = np.ascontiguousarray(bases_all[:n])
+        sc = np.ascontiguousarray(sc_all[: 3 * n])
+        exp = refc.to_affine(refc.msm(sc, b, batch=3, shared=True))
+        for pf in range(1, 9):
+            cfg = hip.MSMConfig.default()
+            cfg.batch_size, cfg.are_points_shared_in_batch, cfg.precompute_factor = 3, True, pf
+            table = M.precompute_bases(cname, b, cfg, g2=g2)
+            got = M.msm(cname, sc, table, cfg, g2=g2)
+            if not np.array_equal(refc.to_affine(got), exp):
+                bad.append(("precompute", n, pf))
+    assert not bad, bad[:20]
+
+
 def test_idle_workspace_decays(hip):
     """the temporaries of a large call stayed cached until an allocation failed or the caller asked. Arenas idle
     for ICICLE_HIP_WORKSPACE_DECAY_S seconds (default 30) are now given back by the next call that leases a temporary."""

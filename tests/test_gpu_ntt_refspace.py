@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("extension", [False, True])
 def test_every_configuration_the_reference_test_can_draw(hip, fname, extension):
     from icicle_amd import ntt as N
+    from icicle_amd._lib import lib, check
     from icicle_amd.runtime import DeviceVec
 
     F = pyref.NTT_FIELDS[fname]
@@ -35,30 +36,116 @@ def test_every_configuration_the_reference_test_can_draw(hip, fname, extension):
         try:
             for batch in (1, 2, 4):
                 x = rng.integers(0, F.p, size=n * batch * lanes, dtype=np.uint32)
-                for columns in (False, True):
-                    for direction in (0, 1):
-                        for ordering in (0, 1, 2, 3):
-                            for stride in (0, 1, 2):
-                                coset = 1 if stride == 0 else pyref.omega(F, logn + stride)
-                                cfg = hip.NTTConfigU32.default()
-                                cfg.batch_size, cfg.columns_batch, cfg.ordering, cfg.coset_gen = batch, columns, ordering, coset
-                                got = N.ntt(fname, x, direction, cfg, extension=extension)
-                                exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset, extension=extension)
-                                ran += 1
-                                if not np.array_equal(got, exp):
-                                    bad.append((logn, batch, columns, direction, ordering, stride, "host"))
-                                # device-resident and IN PLACE (the reference test's `inplace` draw) on a rotating subset
-                                if (ran % 5) == 0:
-                                    d = DeviceVec.from_host(x)
-                                    try:
+                d = DeviceVec(x.nbytes)  # (one allocation per shape: hipMalloc / hipFree per configuration were most of this test's time)
+                try:
+                    for columns in (False, True):
+                        for direction in (0, 1):
+                            for ordering in (0, 1, 2, 3):
+                                for stride in (0, 1, 2):
+                                    coset = 1 if stride == 0 else pyref.omega(F, logn + stride)
+                                    cfg = hip.NTTConfigU32.default()
+                                    cfg.batch_size, cfg.columns_batch, cfg.ordering, cfg.coset_gen = batch, columns, ordering, coset
+                                    got = N.ntt(fname, x, direction, cfg, extension=extension)
+                                    exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset, extension=extension)
+                                    ran += 1
+                                    if not np.array_equal(got, exp):
+                                        bad.append((logn, batch, columns, direction, ordering, stride, "host"))
+                                    # device-resident and IN PLACE (the reference test's `inplace` draw) on a rotating subset
+                                    if (ran % 5) == 0:
+                                        check(lib.icicle_copy_to_device(d.ptr, x.ctypes.data, x.nbytes))
                                         cfg2 = hip.NTTConfigU32.default()
                                         cfg2.batch_size, cfg2.columns_batch, cfg2.ordering, cfg2.coset_gen = batch, columns, ordering, coset
                                         N.ntt(fname, d, direction, cfg2, out=d, size=n, extension=extension)
                                         if not np.array_equal(d.to_host(), exp):
                                             bad.append((logn, batch, columns, direction, ordering, stride, "device, in place"))
-                                    finally:
-                                        d.free()
+                finally:
+                    d.free()
         finally:
             N.release_domain(fname)
             rf.release_domain()
     assert not bad, f"{fname}{' extension' if extension else ''}: {len(bad)} of {ran} configurations differ from the reference; first (logn, batch, columns_batch, dir, ordering, coset stride): {bad[:24]}"
+
+
+def _rand_words(rng, p: int, count: int, words: int) -> np.ndarray:
+    """count canonical elements of a `words` x 32-bit field as a flat uint32 array"""
+    raw = rng.integers(0, 1 << 32, size=(count, words + 1), dtype=np.uint64)
+    out = np.empty((count, words), dtype=np.uint32)
+    for i in range(count):
+        v = sum(int(raw[i, j]) << (32 * j) for j in range(words + 1)) % p
+        for j in range(words):
+            out[i, j] = (v >> (32 * j)) & 0xFFFFFFFF
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("fname", ["bn254", "bls12_381", "bls12_377", "stark252"])
+def test_every_configuration_over_the_256_bit_fields(hip, fname):
+    """the same space for the scalar-field NTT (`ModArithTest.ntt` is instantiated for the curves' scalar fields and stark252 too; another
+    kernel family: ntt_big.hip), up to 2^12 points"""
+    from icicle_amd import ntt as N
+
+    F = pyref.NTT_FIELDS[fname]
+    rf = ref.RefScalarNttField(fname)
+    rng = np.random.default_rng(7070)
+    bad, ran = [], 0
+    for logn in range(0, 13):
+        n = 1 << logn
+        root = N.get_root_of_unity(fname, 1 << (logn + 2))
+        N.init_domain(fname, root)
+        rf.init_domain(root)
+        try:
+            for batch in (1, 2, 4):
+                x = _rand_words(rng, F.p, n * batch, 8)
+                for columns in (False, True):
+                    for direction in (0, 1):
+                        for ordering in (0, 1, 2, 3):
+                            for stride in (0, 1, 2):
+                                coset = 1 if stride == 0 else pyref.omega(F, logn + stride)
+                                cfg = hip.NTTConfigU256.default()
+                                cfg.batch_size, cfg.columns_batch, cfg.ordering = batch, columns, ordering
+                                cfg.set_coset_gen(coset)
+                                got = N.ntt(fname, x, direction, cfg)
+                                exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset)
+                                ran += 1
+                                if not np.array_equal(got, exp):
+                                    bad.append((logn, batch, columns, direction, ordering, stride))
+        finally:
+            N.release_domain(fname)
+            rf.release_domain()
+    assert not bad, f"{fname}: {len(bad)} of {ran} configurations differ from the reference; first (logn, batch, columns_batch, dir, ordering, coset stride): {bad[:24]}"
+
+
+@pytest.mark.parametrize("extension", [False, True])
+def test_every_configuration_over_goldilocks(hip, extension):
+    """... and for the 64-bit field and its quadratic extension (goldilocks, up to 2^13 points)"""
+    from icicle_amd import ntt as N
+
+    F = pyref.GOLDILOCKS
+    rf = ref.RefGoldField()
+    lanes = 2 if extension else 1
+    rng = np.random.default_rng(6464 + lanes)
+    bad, ran = [], 0
+    for logn in range(0, 14):
+        n = 1 << logn
+        root = N.get_root_of_unity("goldilocks", 1 << (logn + 2))
+        N.init_domain("goldilocks", root)
+        rf.init_domain(root)
+        try:
+            for batch in (1, 2, 4):
+                x = _rand_words(rng, F.p, n * batch * lanes, 2)
+                for columns in (False, True):
+                    for direction in (0, 1):
+                        for ordering in (0, 1, 2, 3):
+                            for stride in (0, 1, 2):
+                                coset = 1 if stride == 0 else pyref.omega(F, logn + stride)
+                                cfg = hip.NTTConfigU64.default()
+                                cfg.batch_size, cfg.columns_batch, cfg.ordering = batch, columns, ordering
+                                cfg.set_coset_gen(coset)
+                                got = N.ntt("goldilocks", x, direction, cfg, extension=extension)
+                                exp = rf.ntt(x, n, direction, batch=batch, columns_batch=columns, ordering=ordering, coset_gen=coset, extension=extension)
+                                ran += 1
+                                if not np.array_equal(got, exp):
+                                    bad.append((logn, batch, columns, direction, ordering, stride))
+        finally:
+            N.release_domain("goldilocks")
+            rf.release_domain()
+    assert not bad, f"goldilocks{' extension' if extension else ''}: {len(bad)} of {ran} configurations differ from the reference; first: {bad[:24]}"
