@@ -126,6 +126,9 @@ namespace icicle_hip {
     constexpr uint32_t NG16 = L / E;              // threads per tile column
     constexpr int QT = NR >= 2 ? NQ0 + 4 * (NR - 2) : 0; // first stage of the top round
     constexpr int KB_BITS = SS - NQ0;
+    // (Round 6, measured and removed: generating the 16 inter-pass factors of the plain three-round COLUMN pass at the store -- one running
+    //  product instead of 16 registers -- to pay for the cross-row prefetch the two-round passes have. At 128 VGPRs the kernel spilled 84 B
+    //  and 2^26 x 16 went from 6.72 to 7.91 ms, 2^25 x 32 from 6.09 to 6.50: profiles/r06_notes.md section 4b.)
     extern __shared__ uint32_t lds[];
     static_assert(!LN || (!V4 && !BIG), "lane-native tiles: 4-byte lanes, 512-thread blocks");
     static_assert(RN == 0 || (!DIF && !INV && !OUTREV && !V4 && !BIG), "bit-reversed input: DIT column-type passes (the direction is a run-time flag there)");
