@@ -56,6 +56,26 @@ namespace icicle_hip {
     // the chip has lanes, so spending four lanes on one chain is free. `tab` = 16 entries of LDS owned by the quad (a
     // private array indexed by the digit would live in scratch memory). Every lane of the WAVE must call this together
     // (the table is published with a barrier); lanes with go == false compute on the identity and the result is unused.
+    // dbl_jac_quad (ec.hpp) with the range management of dbl_jac_lazy: inside a run of doublings only D is brought back below 4 p
+    // (X < 9.2 p, Y < 17.8 p, Z < 2.8 p is a fixed point of the step), two conditional subtractions per step instead of eight. In quad
+    // form every lane executes the linear steps redundantly, so they were ~45 % of a doubling's instructions. The caller reduces Y once
+    // per window. The same operand flow, one lane's arithmetic, runs under the host bound tracker: tests/host_math_harness.cpp op 7.
+    static __device__ __forceinline__ typename E::Jac dbl_jac_quad_lazy(const typename E::Jac& p, uint32_t role)
+    {
+      using fe = typename F::fe;
+      const fe l1 = F::mul(E::lane_select(role == 0, p.x, p.y), E::lane_select(role == 0, p.x, E::lane_select(role == 1, p.y, p.z)));
+      const fe A = E::template quad_bcast<0>(l1), B = E::template quad_bcast<1>(l1), YZ = E::template quad_bcast<2>(l1);
+      const fe Ev = F::add(F::dbl(A), A);
+      const fe l2 = F::sqr(E::lane_select(role == 0, Ev, E::lane_select(role == 1, B, F::add(p.x, B))));
+      const fe Fv = E::template quad_bcast<0>(l2), CC = E::template quad_bcast<1>(l2), t = E::template quad_bcast<2>(l2);
+      const fe D = F::below4(F::dbl(F::template sub<4>(t, F::add(A, CC))));
+      typename E::Jac r;
+      r.x = F::template sub<8>(Fv, F::dbl(D));
+      const fe m = F::mul(Ev, F::template sub<16>(D, r.x));
+      r.y = F::template sub<16>(m, F::dbl(F::dbl(F::dbl(CC))));
+      r.z = F::dbl(YZ);
+      return r;
+    }
     static __device__ Proj mul_words_quad(const Proj& p, const uint32_t* k, uint32_t role, Proj* tab)
     {
       // the additions are quad-cooperative as well (five product latencies instead of fourteen): -DECNTT_NOQUADADD = A/B
@@ -75,9 +95,14 @@ namespace icicle_hip {
 #ifdef ECNTT_NOQUAD
         for (int q = 0; q < 4; q++)
           j = E::dbl_jac(j);
-#else
+#elif defined(ECNTT_NO_LAZY_DBL) // (A/B: the fully reduced quad doubling of rounds 3-5)
         for (int q = 0; q < 4; q++)
           j = E::dbl_jac_quad(j, role);
+#else
+        for (int q = 0; q < 4; q++)
+          j = dbl_jac_quad_lazy(j, role);
+        F::template cond_sub<16>(j.y); // back to Y < 4 p, the bound the complete addition (and the butterfly's negation) is laid out for
+        j.y = F::below4(j.y);
 #endif
         r = E::from_jac(j);
       };

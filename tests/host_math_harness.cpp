@@ -127,6 +127,55 @@ namespace {
       E::store_proj_canonical(out, E::from_jac(j));
       return 0;
     }
+    case 7: { // the ECNTT butterflies' scalar multiplication (ecntt.hip mul_words_quad, one lane's arithmetic): aux[0..7] * pts[0] by the GLV
+              // split, 33 joint four-bit windows, four lazily reduced doublings per window with Y brought back below 4p for the complete addition
+      if constexpr (C::EXT_DEGREE == 1) {
+        using Proj = typename E::Proj;
+        const Proj p = E::words_are_zero(pts) ? E::proj_identity() : E::to_proj(load(pts));
+        Proj tab[16];
+        Proj e = E::proj_identity();
+        for (int i = 0; i < 16; i++) {
+          tab[i] = e;
+          e = (i == 0) ? p : ((i == 1) ? E::dbl(p) : E::add(e, p));
+        }
+        uint32_t k1[5], k2[5];
+        bool n1, n2;
+        glv_decompose<C>(aux, k1, n1, k2, n2);
+        const typename F::fe beta = F::from_const(C::GLV_BETA);
+        Proj r = E::proj_identity();
+        bool started = false;
+        for (int d = 32; d >= 0; d--) {
+          const uint32_t d1 = (k1[d >> 3] >> ((d & 7) * 4)) & 15u, d2 = (k2[d >> 3] >> ((d & 7) * 4)) & 15u;
+          if (started) {
+            typename E::Jac j = E::to_jac(r);
+            for (int q = 0; q < 4; q++)
+              j = E::dbl_jac_lazy(j);
+            F::template cond_sub<16>(j.y);
+            j.y = F::below4(j.y);
+            r = E::from_jac(j);
+          }
+          if (d1) {
+            Proj t = tab[d1];
+            if (n1) t.y = F::template neg<4>(F::below4(t.y));
+            r = started ? E::add(r, t) : t;
+            started = true;
+          }
+          if (d2) {
+            Proj t = tab[d2];
+            t.x = F::mul(t.x, beta);
+            if (n2) t.y = F::template neg<4>(F::below4(t.y));
+            r = started ? E::add(r, t) : t;
+            started = true;
+          }
+        }
+        // (the butterfly then forms u + v and u - v: the negation of the result must be in bounds as well)
+        Proj nr = r;
+        nr.y = F::template neg<4>(r.y);
+        E::store_proj_canonical(out, E::add(E::add(r, nr), r));
+        return 0;
+      }
+      return -1;
+    }
     default: return -1;
     }
   }

@@ -119,6 +119,12 @@ def test_ec_ops(lib, ci, c):
         assert run(5, [base[2]], [k])[0] == pyref.ec_mul(c, 1 << k, base[2])
     got, raw = run(5, [pyref.INF], [9])
     assert got == pyref.INF and raw[1] != 0
+    if ci in (0, 1, 4):  # the ECNTT butterflies' scalar multiplication: GLV split + joint windows + lazily reduced doublings (one lane's arithmetic of ecntt.hip)
+        rnd2 = random.Random(900 + ci)
+        ks = [0, 1, 2, 15, 16, 17, c.r - 1, c.r - 2, c.r // 2, (1 << 128) - 1, 1 << 128, (1 << 200) + 12345] + [rnd2.randrange(c.r) for _ in range(25)]
+        for k in ks:
+            assert run(7, [base[4]], [(k >> (32 * i)) & 0xFFFFFFFF for i in range(8)])[0] == pyref.ec_mul(c, k, base[4]), (c.name, hex(k))
+        assert run(7, [pyref.INF], [5, 0, 0, 0, 0, 0, 0, 0])[0] == pyref.INF
     for k in [0, 1, 2, 3, 17, 84, 300]:  # msm_precompute_bases' chain: lazily reduced doubling from Z = 1 (bounds asserted by the tracker)
         for b in (base[2], base[5]):
             assert run(6, [b], [k])[0] == pyref.ec_mul(c, 1 << k, b)
