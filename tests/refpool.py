@@ -18,12 +18,12 @@ Lanes:
     other sizes.
   Inputs and outputs travel as .npy files in a scratch directory (a tmpfs on the GPU boxes), mapped by the workers.
 Host cores: the GPU boxes of this build show 256 hardware threads but their cgroup grants 16 cores of CPU time (cpu.max = 1600000
-100000, tools/cpu_probe.sh: 256 busy processes reach a parallelism of 15.7). Every reference leg of rounds 1-5 ran its 256 threads on
-that quota, and the whole suite is bound by it: ~13 000 core-seconds of reference work / 16 = ~800 s whatever the schedule (measured:
-threads of one process 721-782 s, fixed core shares > 681 s, one process per job 810 s -- profiles/r06_notes.md section 1). What the
-pool can do is (i) keep the GPU work off the critical path and (ii) spend fewer core-seconds: the reference MSM is most frugal with
-few workers (msm_threads), the NTT workers and the foreground's reference calls are capped at what the cgroup grants
-(ICICLE_TASKFLOW_SHIM_MAX_THREADS in oracle/shim/taskflow, ICICLE_REF_MSM_THREADS in oracle/ref.py).
+100000, tools/cpu_probe.sh: 256 busy processes reach a parallelism of 15.7). Every reference leg of rounds 1-5 ran 256 threads on that
+quota and burnt most of it on itself (every MSM worker owns, clears and merges a full bucket set; the NTT asks for
+hardware_concurrency() threads per call). Five schedules that left the thread counts alone cost 721-829 s (profiles/r06_notes.md
+section 1); with every reference call sized to the quota -- few workers per MSM job (msm_threads), the NTT workers' and the
+foreground's calls capped (ICICLE_TASKFLOW_SHIM_MAX_THREADS in oracle/shim/taskflow, ICICLE_REF_MSM_THREADS in oracle/ref.py) -- the
+same compares cost 478 s.
 Nothing here is imported by the product.
 """
 import json
