@@ -18,6 +18,7 @@
 #include "ntt_big_common.hpp"
 #include "ec.hpp"
 #include "glv.hpp"
+#include "ec_dbl_quad.hpp"
 #include "ntt_plan.h"
 #include <algorithm>
 
@@ -76,6 +77,29 @@ namespace icicle_hip {
       r.z = F::dbl(YZ);
       return r;
     }
+    // The two coordinate changes around a window's doublings, (X : Y : Z) -> (X Z, Y Z^2, Z) and back (X Z : Y : Z^3), are three products
+    // each; spread over the quad they are two dependent products per lane instead of three (ec.hpp to_jac / from_jac, same values).
+    static __device__ __forceinline__ typename E::Jac to_jac_quad(const Proj& p, uint32_t role)
+    {
+      using fe = typename F::fe;
+      const fe l1 = F::mul(E::lane_select(role == 0, p.x, p.z), p.z); // role 0: X Z ; others: Z^2
+      typename E::Jac r;
+      r.x = E::template quad_bcast<0>(l1);
+      r.y = F::mul(p.y, E::template quad_bcast<1>(l1));
+      r.z = p.z;
+      return r;
+    }
+    static __device__ __forceinline__ Proj from_jac_quad(const typename E::Jac& j, uint32_t role)
+    {
+      using fe = typename F::fe;
+      if (F::is_zero(j.z)) return E::proj_identity(); // (uniform over the quad: every lane holds the same point)
+      const fe l1 = F::mul(E::lane_select(role == 0, j.x, j.z), j.z); // role 0: X Z ; others: Z^2
+      Proj r;
+      r.x = E::template quad_bcast<0>(l1);
+      r.y = j.y;
+      r.z = F::mul(E::template quad_bcast<1>(l1), j.z);
+      return r;
+    }
     static __device__ Proj mul_words_quad(const Proj& p, const uint32_t* k, uint32_t role, Proj* tab)
     {
       // the additions are quad-cooperative as well (five product latencies instead of fourteen): -DECNTT_NOQUADADD = A/B
@@ -91,7 +115,19 @@ namespace icicle_hip {
       }
       __syncthreads();
       auto quad_dbl4 = [&](Proj& r) {
+#if !defined(ECNTT_JAC_DBL) && !defined(ECNTT_NOQUAD) && !defined(ECNTT_NO_LAZY_DBL) // (-DECNTT_JAC_DBL: the Jacobian chain below, for A/B builds)
+        if constexpr (C::B3_SMALL != 0) {
+          // complete projective doublings in two product levels each, no coordinate change around the window (ec_dbl_quad.hpp)
+          for (int q = 0; q < 4; q++)
+            r = EcDblSmallB<C>::dbl_quad(r, role);
+          return;
+        }
+#endif
+#if defined(ECNTT_NOQUAD) || defined(ECNTT_NO_LAZY_DBL)
         typename E::Jac j = E::to_jac(r);
+#else
+        typename E::Jac j = to_jac_quad(r, role);
+#endif
 #ifdef ECNTT_NOQUAD
         for (int q = 0; q < 4; q++)
           j = E::dbl_jac(j);
@@ -103,6 +139,8 @@ namespace icicle_hip {
           j = dbl_jac_quad_lazy(j, role);
         F::template cond_sub<16>(j.y); // back to Y < 4 p, the bound the complete addition (and the butterfly's negation) is laid out for
         j.y = F::below4(j.y);
+        r = from_jac_quad(j, role);
+        return;
 #endif
         r = E::from_jac(j);
       };

@@ -8,6 +8,7 @@
 #include "../icicle_amd/csrc/smallfield.hpp"
 #include "../icicle_amd/csrc/goldfield.hpp"
 #include "../icicle_amd/csrc/glv.hpp"
+#include "../icicle_amd/csrc/ec_dbl_quad.hpp"
 
 using namespace icicle_hip;
 
@@ -147,12 +148,17 @@ namespace {
         for (int d = 32; d >= 0; d--) {
           const uint32_t d1 = (k1[d >> 3] >> ((d & 7) * 4)) & 15u, d2 = (k2[d >> 3] >> ((d & 7) * 4)) & 15u;
           if (started) {
-            typename E::Jac j = E::to_jac(r);
-            for (int q = 0; q < 4; q++)
-              j = E::dbl_jac_lazy(j);
-            F::template cond_sub<16>(j.y);
-            j.y = F::below4(j.y);
-            r = E::from_jac(j);
+            if constexpr (C::B3_SMALL != 0) {
+              for (int q = 0; q < 4; q++)
+                r = EcDblSmallB<C>::dbl(r); // ec_dbl_quad.hpp: the quad form's operand flow on one lane
+            } else {
+              typename E::Jac j = E::to_jac(r);
+              for (int q = 0; q < 4; q++)
+                j = E::dbl_jac_lazy(j);
+              F::template cond_sub<16>(j.y);
+              j.y = F::below4(j.y);
+              r = E::from_jac(j);
+            }
           }
           if (d1) {
             Proj t = tab[d1];

@@ -22,7 +22,7 @@ NL = {0: 8, 1: 8, 2: 12, 3: 8, 4: 12, 5: 8, 6: 8, 7: 2}
 @pytest.fixture(scope="module")
 def lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.hpp", "fq2.hpp", "ec.hpp", "smallfield.hpp", "goldfield.hpp", "field_consts.h", "glv.hpp")]
+    deps = [SRC] + [os.path.join(HERE, "..", "icicle_amd", "csrc", f) for f in ("bigfield.hpp", "fq2.hpp", "ec.hpp", "smallfield.hpp", "goldfield.hpp", "field_consts.h", "glv.hpp", "ec_dbl_quad.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-DBIGFIELD_BOUNDS", "-fPIC", "-shared", SRC, "-o", SO])
     return ctypes.CDLL(SO)

@@ -279,6 +279,7 @@ def gen_curve(name, fq, fr, b, gx, gy):
     s.append(f"  using fr = {fr}_params;")
     s.append("  static constexpr int EXT_DEGREE = 1;")
     s.append(f"  static constexpr uint32_t B3[{nl}] = {arr(limbs(3 * b % p * R % p, nl))}; // 3*b, Montgomery")
+    s.append(f"  static constexpr uint32_t B3_SMALL = {3 * b if 0 < 3 * b < 64 else 0}; // 3*b as a plain integer when it is small (0: it is not), ec_dbl_quad.hpp")
     s.append(f"  static constexpr uint32_t GX[{nl}] = {arr(limbs(gx * R % p, nl))}; // generator, Montgomery")
     s.append(f"  static constexpr uint32_t GY[{nl}] = {arr(limbs(gy * R % p, nl))};")
     # GLV endomorphism (glv.hpp): every curve here has j = 0
