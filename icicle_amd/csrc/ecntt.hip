@@ -108,10 +108,23 @@ namespace icicle_hip {
 #else
       auto ADD = [&](const Proj& a, const Proj& b) { return E::add_quad(a, b, role); };
 #endif
-      Proj e = E::proj_identity();
-      for (int i = 0; i < 16; i++) {
-        if (role == 0) tab[i] = e;
-        e = (i == 0) ? p : ((i == 1) ? E::dbl(p) : ADD(e, p)); // 0, p, 2p, 3p, ...
+#if !defined(ECNTT_NO_GLV) && !defined(ECNTT_JAC_DBL) && !defined(ECNTT_NOQUAD) && !defined(ECNTT_NO_LAZY_DBL) && !defined(ECNTT_WIN4)
+      constexpr bool WIN5 = C::B3_SMALL != 0; // signed five-bit windows over the multiples 1..16 (below); -DECNTT_WIN4 = A/B
+#else
+      constexpr bool WIN5 = false;
+#endif
+      if constexpr (WIN5) {
+        Proj e = p;
+        for (int i = 0; i < 16; i++) { // tab[i] = (i + 1) p
+          if (role == 0) tab[i] = e;
+          if (i < 15) e = (i == 0) ? EcDblSmallB<C>::dbl_quad(p, role) : ADD(e, p);
+        }
+      } else {
+        Proj e = E::proj_identity();
+        for (int i = 0; i < 16; i++) {
+          if (role == 0) tab[i] = e;
+          e = (i == 0) ? p : ((i == 1) ? E::dbl(p) : ADD(e, p)); // 0, p, 2p, 3p, ...
+        }
       }
       __syncthreads();
       auto quad_dbl4 = [&](Proj& r) {
@@ -156,6 +169,37 @@ namespace icicle_hip {
         bool n1, n2;
         glv_decompose<C>(k, k1, n1, k2, n2);
         const typename F::fe beta = F::from_const(C::GLV_BETA);
+        if constexpr (WIN5) {
+          // 27 signed five-bit windows (glv.hpp glv_recode5; the top one is 0 or 1 and costs nothing while the chain has not started):
+          // 130 doublings and <= 54 additions where four-bit windows take 132 and <= 66 -- the table is the same 16 entries, now the
+          // multiples 1..16, and a negative digit negates the entry's Y like a negative half does.
+          if constexpr (C::B3_SMALL != 0) {
+            uint32_t pk1[7], pk2[7];
+            glv_recode5(k1, pk1);
+            glv_recode5(k2, pk2);
+            for (int d = 26; d >= 0; d--) {
+              const uint32_t b1 = (pk1[d >> 2] >> ((d & 3) * 8)) & 0xFFu, b2 = (pk2[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+              if (started) {
+                for (int q = 0; q < 5; q++)
+                  r = EcDblSmallB<C>::dbl_quad(r, role);
+              }
+              if (b1 & 31u) {
+                Proj t = tab[(b1 & 31u) - 1];
+                if (n1 != ((b1 & 0x80u) != 0)) t.y = F::template neg<4>(F::below4(t.y));
+                r = started ? ADD(r, t) : t;
+                started = true;
+              }
+              if (b2 & 31u) {
+                Proj t = tab[(b2 & 31u) - 1];
+                t.x = F::mul(t.x, beta);
+                if (n2 != ((b2 & 0x80u) != 0)) t.y = F::template neg<4>(F::below4(t.y));
+                r = started ? ADD(r, t) : t;
+                started = true;
+              }
+            }
+          }
+          return r;
+        }
         for (int d = 32; d >= 0; d--) {
           const uint32_t d1 = (k1[d >> 3] >> ((d & 7) * 4)) & 15u, d2 = (k2[d >> 3] >> ((d & 7) * 4)) & 15u;
           if (started) quad_dbl4(r);

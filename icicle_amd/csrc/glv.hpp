@@ -134,4 +134,26 @@ namespace icicle_hip {
     if (neg2) glv_neg(k2);
   }
 
+  // |k| < 2^130 (5 words) -> 27 signed five-bit digits, least significant first: k = sum_i d_i 32^i, d_i in [-15, 16]. One digit per
+  // byte of pk[0..6]: bits 0..4 = |d_i| (0..16), bit 7 = sign. A window value above 16 becomes value - 32 with a carry into the next
+  // window, so a table of the multiples 1..16 serves (with one conditional negation) where unsigned five-bit windows would need 31.
+  GLV_HD void glv_recode5(const uint32_t* k, uint32_t* pk)
+  {
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+      pk[i] = 0;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 27; i++) {
+      const int b = 5 * i, w = b >> 5, sh = b & 31;
+      uint32_t v = k[w] >> sh;
+      if (sh > 27 && w + 1 < 5) v |= k[w + 1] << (32 - sh);
+      v = (v & 31u) + carry;
+      const bool negd = v > 16u;
+      carry = negd ? 1u : 0u;
+      const uint32_t mag = negd ? 32u - v : v;
+      pk[i >> 2] |= (mag | (negd ? 0x80u : 0u)) << ((i & 3) * 8);
+    }
+  }
+
 } // namespace icicle_hip

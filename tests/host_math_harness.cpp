@@ -134,17 +134,50 @@ namespace {
         using Proj = typename E::Proj;
         const Proj p = E::words_are_zero(pts) ? E::proj_identity() : E::to_proj(load(pts));
         Proj tab[16];
-        Proj e = E::proj_identity();
-        for (int i = 0; i < 16; i++) {
-          tab[i] = e;
-          e = (i == 0) ? p : ((i == 1) ? E::dbl(p) : E::add(e, p));
-        }
         uint32_t k1[5], k2[5];
         bool n1, n2;
         glv_decompose<C>(aux, k1, n1, k2, n2);
         const typename F::fe beta = F::from_const(C::GLV_BETA);
         Proj r = E::proj_identity();
         bool started = false;
+        if constexpr (C::B3_SMALL != 0) { // signed five-bit windows over the multiples 1..16, projective doublings (the device's WIN5 path)
+          Proj e = p;
+          for (int i = 0; i < 16; i++) {
+            tab[i] = e;
+            if (i < 15) e = (i == 0) ? EcDblSmallB<C>::dbl(p) : E::add(e, p);
+          }
+          uint32_t pk1[7], pk2[7];
+          glv_recode5(k1, pk1);
+          glv_recode5(k2, pk2);
+          for (int d = 26; d >= 0; d--) {
+            const uint32_t b1 = (pk1[d >> 2] >> ((d & 3) * 8)) & 0xFFu, b2 = (pk2[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+            if (started)
+              for (int q = 0; q < 5; q++)
+                r = EcDblSmallB<C>::dbl(r);
+            if (b1 & 31u) {
+              Proj t = tab[(b1 & 31u) - 1];
+              if (n1 != ((b1 & 0x80u) != 0)) t.y = F::template neg<4>(F::below4(t.y));
+              r = started ? E::add(r, t) : t;
+              started = true;
+            }
+            if (b2 & 31u) {
+              Proj t = tab[(b2 & 31u) - 1];
+              t.x = F::mul(t.x, beta);
+              if (n2 != ((b2 & 0x80u) != 0)) t.y = F::template neg<4>(F::below4(t.y));
+              r = started ? E::add(r, t) : t;
+              started = true;
+            }
+          }
+          Proj nr = r;
+          nr.y = F::template neg<4>(r.y);
+          E::store_proj_canonical(out, E::add(E::add(r, nr), r));
+          return 0;
+        }
+        Proj e = E::proj_identity();
+        for (int i = 0; i < 16; i++) {
+          tab[i] = e;
+          e = (i == 0) ? p : ((i == 1) ? E::dbl(p) : E::add(e, p));
+        }
         for (int d = 32; d >= 0; d--) {
           const uint32_t d1 = (k1[d >> 3] >> ((d & 7) * 4)) & 15u, d2 = (k2[d >> 3] >> ((d & 7) * 4)) & 15u;
           if (started) {
@@ -199,6 +232,19 @@ extern "C" int host_glv_decompose(int curve, const uint32_t* k, uint32_t* out)
   default: return -1;
   }
   out[5] = n1, out[11] = n2;
+  return 0;
+}
+
+// signed five-bit recoding (glv.hpp glv_recode5): k (5 words) -> 27 digits as int32
+extern "C" int host_glv_recode5(const uint32_t* k, int32_t* digits)
+{
+  uint32_t pk[7];
+  glv_recode5(k, pk);
+  for (int i = 0; i < 27; i++) {
+    const uint32_t b = (pk[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+    digits[i] = (b & 0x80u) ? -(int32_t)(b & 31u) : (int32_t)(b & 31u);
+    if (b & 0x60u) return -1; // no other bits
+  }
   return 0;
 }
 

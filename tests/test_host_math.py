@@ -236,6 +236,20 @@ def test_glv_decomposition(lib, ci, c):
     assert worst <= 129, worst
 
 
+def test_glv_signed_five_bit_recoding(lib):
+    """glv.hpp glv_recode5 (the ECNTT chain's windows): 27 digits in [-15, 16] that sum back to k, for every k < 2^130 tried -- the
+    all-ones and carry-chain patterns first"""
+    rnd = random.Random(55)
+    ks = [0, 1, 16, 17, 31, 32, (1 << 130) - 1, (1 << 129) - 1, 1 << 129, (1 << 129) + 1, int("10001" * 26, 2), int("10000" * 26, 2), int("01111" * 26, 2)]
+    ks += [rnd.randrange(1 << rnd.randrange(1, 131)) for _ in range(4000)]
+    dig = (ctypes.c_int32 * 27)()
+    for k in ks:
+        assert lib.host_glv_recode5(w(k, 5), dig) == 0
+        ds = list(dig)
+        assert all(-15 <= d <= 16 for d in ds), (hex(k), ds)
+        assert sum(d << (5 * i) for i, d in enumerate(ds)) == k, hex(k)
+
+
 @pytest.mark.parametrize("fi,f", [(0, pyref.BABYBEAR), (1, pyref.KOALABEAR)])
 def test_small_field(lib, fi, f):
     rnd = random.Random(fi)
