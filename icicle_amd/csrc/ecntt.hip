@@ -6,12 +6,13 @@
 // feature applies: orderings, coset generator, batch / columns_batch, 1/N on the inverse. It uses the
 // twiddle domain of the scalar-field NTT (<curve>_ntt_init_domain).
 //
-// A butterfly here is one 254-bit scalar multiplication (4-bit windows: 252 Jacobian doublings + <= 77 complete
-// additions, ~0.8 M instructions) plus two point additions; memory traffic is irrelevant by five orders of
+// A butterfly here is one 254-bit scalar multiplication (rounds 3-5: 4-bit windows, 252 Jacobian doublings + <= 77 complete
+// additions, ~0.8 M instructions; round 6: GLV split, 27 signed 5-bit joint windows, 130 complete projective doublings + <= 69
+// additions -- mul_words_quad below) plus two point additions; memory traffic is irrelevant by five orders of
 // magnitude, and a stage of an ECNTT of practical size has far fewer butterflies than the chip has lanes: the
 // time of a stage is the LATENCY of one scalar multiplication. So the structure is radix-2 DIT with one launch per
 // stage, points in HBM in the kernels' internal form (Montgomery limbs, 3 x 9 or 3 x 14 words), and FOUR lanes (a DPP
-// quad) per butterfly sharing the doubling chain (three dependent products per doubling instead of seven); the
+// quad) per butterfly sharing the doubling chain (two dependent products per doubling, ec_dbl_quad.hpp); the
 // reorderings / coset / 1/N factors are folded into the load and store kernels. The projective representative of a result differs from
 // the reference's (it depends on the order of additions); the group element is the same -- tests
 // compare to_affine() limbs, as for the MSM.
@@ -47,17 +48,19 @@ namespace icicle_hip {
       }
       return r;
     }
-    // The butterflies' k * p: fixed 4-bit windows, most significant first (the reference's own scalar multiplication is
-    // windowed too, include/icicle/curves/projective.h:192-224) -- per window four doublings on the Jacobian chain of
-    // ec.hpp (2M + 5S each instead of 6M + 2S + 1 for the complete doubling; Z = 0 stays Z = 0 and comes back as the
-    // identity) and at most one COMPLETE addition of a table entry, so no input is exceptional: 252 doublings +
-    // <= 63 + 14 additions instead of 255 + ~127 of the bit-serial form.
-    // The four lanes of a DPP quad hold the same operands and share every doubling (dbl_jac_quad: three dependent products
-    // per step instead of seven) -- a butterfly is a pure latency chain and an ECNTT stage has far fewer butterflies than
+    // The butterflies' k * p: fixed windows, most significant first (the reference's own scalar multiplication is windowed
+    // too, include/icicle/curves/projective.h:192-224), a run of doublings and COMPLETE additions of table entries per window, so
+    // no input is exceptional. Three generations live here, the older ones behind A/B macros (tools/ab_lib.sh):
+    //   rounds 3-5 (-DECNTT_NO_GLV): 63 four-bit windows, 252 Jacobian doublings (2M + 5S, three product levels per quad) + <= 77 additions;
+    //   round 6a (-DECNTT_JAC_DBL / -DECNTT_WIN4): the GLV split, 33 joint four-bit windows, 132 doublings + <= 80 additions;
+    //   round 6b (default, curves with small 3 b): GLV, 27 joint signed five-bit windows, 130 complete projective doublings in two
+    //   product levels each (ec_dbl_quad.hpp) + <= 69 additions.
+    // The four lanes of a DPP quad hold the same operands and share every doubling and addition -- a butterfly is a latency chain
+    // and an ECNTT stage of practical size has fewer butterflies than
     // the chip has lanes, so spending four lanes on one chain is free. `tab` = 16 entries of LDS owned by the quad (a
     // private array indexed by the digit would live in scratch memory). Every lane of the WAVE must call this together
     // (the table is published with a barrier); lanes with go == false compute on the identity and the result is unused.
-    // dbl_jac_quad (ec.hpp) with the range management of dbl_jac_lazy: inside a run of doublings only D is brought back below 4 p
+    // (round 6a) dbl_jac_quad (ec.hpp) with the range management of dbl_jac_lazy: inside a run of doublings only D is brought back below 4 p
     // (X < 9.2 p, Y < 17.8 p, Z < 2.8 p is a fixed point of the step), two conditional subtractions per step instead of eight. In quad
     // form every lane executes the linear steps redundantly, so they were ~45 % of a doubling's instructions. The caller reduces Y once
     // per window. The same operand flow, one lane's arithmetic, runs under the host bound tracker: tests/host_math_harness.cpp op 7.
