@@ -22,7 +22,7 @@ line at N > 1 carries that figure as well, as the object "strong", so one invoca
 Extra objects: "roofline" (dominant kernel = MSM bucket accumulation, duration from hipEvents on the
 launch stream, algorithmic bytes per SURVEY.md 8(d); its ALU and gather roofs are measured in the same
 run), "cpu_baseline" (the reference CPU backend from oracle/_ref timed on this box's host cores -- on
-the full workload when the host has >= 64 cores), "ntt" (secondary metric with its own
+the full workload when the host grants >= 16 cores of CPU time), "ntt" (secondary metric with its own
 roofline/cpu_baseline).  --size-log2 / --ntt-log2 shrink the workload for quick checks; the
 JSON then names the reduced workload (never reported as the headline config).
 """
@@ -54,8 +54,8 @@ def parse():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--msm-c", type=int, default=0, help="force the MSM window size (0 = backend default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-msm-log2", type=int, default=0, help="CPU baseline MSM size; 0 = the full workload when the host has >= 64 cores, else 2^20")
-    ap.add_argument("--cpu-ntt-log2", type=int, default=0, help="CPU baseline NTT size; 0 = the full size when the host has >= 64 cores, else 2^20")
+    ap.add_argument("--cpu-msm-log2", type=int, default=0, help="CPU baseline MSM size; 0 = the full workload when the host grants >= 16 cores, else 2^20")
+    ap.add_argument("--cpu-ntt-log2", type=int, default=0, help="CPU baseline NTT size; 0 = the full size when the host grants >= 16 cores, else 2^20")
     ap.add_argument("--no-inproc", action="store_true", help="N > 1: skip the single-process hip_num_devices=N measurement")
     ap.add_argument("--no-shard-extras", action="store_true", help="N = 1: skip the config3_shard / config4_shard objects (per-GPU shares of BASELINE configs[3] and [4])")
     ap.add_argument("--inproc-only", action="store_true", help=argparse.SUPPRESS)  # internal: the launcher's second leg
@@ -811,8 +811,9 @@ def main():
             out["config4_shard"] = {"error": repr(e)}
 
     # ---------------- CPU baseline: the reference CPU backend on this box's host cores ----------------
-    # On a host with >= 64 cores (the GPU boxes have 256) the baseline is timed on the REAL workload: the full 2^26 MSM
-    # (about half a minute) and full-size NTT rows; on small hosts a 2^20 sample is timed and the JSON says so.
+    # On a host that grants >= 16 cores of CPU time (the GPU boxes: 256 visible threads, a cgroup quota of 16 cores) the baseline is timed
+    # on the REAL workload: the full 2^26 MSM (about half a minute) and full-size NTT rows; on small hosts a 2^20 sample is timed and the
+    # JSON says so.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import ref
