@@ -86,4 +86,50 @@ namespace icicle_hip {
 #endif
   };
 
+#if defined(__HIPCC__)
+  // ---- complete addition over a quad in FOUR product rounds -------------------------------------------------------------------
+  // ec.hpp add_quad follows add_body's three levels (6, 2, 6 products) literally: five rounds, two of them half empty. The fourteen
+  // products pack into 4 + 4 + 4 + 2 when a product starts as soon as its operands exist:
+  //   A: X1X2 | Y1Y2 | Z1Z2 | (X1+Y1)(X2+Y2)                 -> t0, t1, t2, t3, 3 t0
+  //   B: (Y1+Z1)(Y2+Z2) | (X1+Z1)(X2+Z2) | 3b t2 | (3 t0) t3   -> t4, t5, z3 = t1 + 3b t2, t1m = t1 - 3b t2
+  //   C: 3b t5 | t3 t1m | t1m z3 | z3 t4                       -> y3
+  //   D: t4 y3 (even lanes) | y3 (3 t0) (odd lanes)
+  // Same operand pairs, bounds and values as add_body (Renes-Costello-Batina Algorithm 7, a = 0; the reference's operator+,
+  // projective.h:101-143); four products per lane and addition instead of five.
+  template <class C>
+  struct EcQuadAdd {
+    using E = EC<C>;
+    using F = typename E::F;
+    using fe = typename F::fe;
+    using Proj = typename E::Proj;
+    static __device__ __forceinline__ fe sel4(uint32_t role, const fe& a0, const fe& a1, const fe& a2, const fe& a3)
+    {
+      return E::lane_select(role == 0, a0, E::lane_select(role == 1, a1, E::lane_select(role == 2, a2, a3)));
+    }
+    static __device__ __forceinline__ Proj add(const Proj& p, const Proj& q, uint32_t role)
+    {
+      const bool even = (role & 1u) == 0;
+      const fe b3 = E::b3();
+      const fe a = F::mul(sel4(role, p.x, p.y, p.z, F::add(p.x, p.y)), sel4(role, q.x, q.y, q.z, F::add(q.x, q.y)));
+      const fe t0 = E::template quad_bcast<0>(a), t1 = E::template quad_bcast<1>(a), t2 = E::template quad_bcast<2>(a);
+      const fe t3 = F::template sub<4>(E::template quad_bcast<3>(a), F::add(t0, t1)); // X1Y2 + X2Y1
+      const fe t0_3 = F::add(F::dbl(t0), t0);                                          // 3 X1X2
+      const fe b = F::mul(sel4(role, F::add(p.y, p.z), F::add(p.x, p.z), b3, t0_3), sel4(role, F::add(q.y, q.z), F::add(q.x, q.z), t2, t3));
+      const fe t4 = F::template sub<4>(E::template quad_bcast<0>(b), F::add(t1, t2)); // Y1Z2 + Y2Z1
+      const fe t5 = F::template sub<4>(E::template quad_bcast<1>(b), F::add(t0, t2)); // X1Z2 + X2Z1
+      const fe bt2 = E::template quad_bcast<2>(b), t03t3 = E::template quad_bcast<3>(b);
+      const fe z3 = F::add(t1, bt2);
+      const fe t1m = F::template sub<2>(t1, bt2);
+      const fe c = F::mul(sel4(role, b3, t3, t1m, z3), sel4(role, t5, t1m, z3, t4));
+      const fe y3 = E::template quad_bcast<0>(c);
+      const fe d = F::mul(y3, E::lane_select(even, t4, t0_3));
+      Proj r;
+      r.x = F::template sub<2>(E::template quad_bcast<1>(c), E::template quad_bcast<0>(d));
+      r.y = F::add(E::template quad_bcast<2>(c), E::template quad_bcast<1>(d));
+      r.z = F::add(E::template quad_bcast<3>(c), t03t3);
+      return r;
+    }
+  };
+#endif
+
 } // namespace icicle_hip

@@ -23,6 +23,13 @@
 #include "ntt_plan.h"
 #include <algorithm>
 
+// the quad addition of every kernel here: four product rounds (ec_dbl_quad.hpp EcQuadAdd); -DECNTT_ADD5 = ec.hpp add_quad's five, for A/B builds
+#ifdef ECNTT_ADD5
+  #define QADD(a, b, role) E::add_quad(a, b, role)
+#else
+  #define QADD(a, b, role) EcQuadAdd<C>::add(a, b, role)
+#endif
+
 namespace icicle_hip {
 
   template <class C>
@@ -109,7 +116,7 @@ namespace icicle_hip {
 #ifdef ECNTT_NOQUADADD
       auto ADD = [&](const Proj& a, const Proj& b) { return E::add(a, b); };
 #else
-      auto ADD = [&](const Proj& a, const Proj& b) { return E::add_quad(a, b, role); };
+      auto ADD = [&](const Proj& a, const Proj& b) { return QADD(a, b, role); };
 #endif
 #if !defined(ECNTT_NO_GLV) && !defined(ECNTT_JAC_DBL) && !defined(ECNTT_NOQUAD) && !defined(ECNTT_NO_LAZY_DBL) && !defined(ECNTT_WIN4)
       constexpr bool WIN5 = C::B3_SMALL != 0; // signed five-bit windows over the multiples 1..16 (below); -DECNTT_WIN4 = A/B
@@ -375,7 +382,7 @@ namespace icicle_hip {
       base[i + half] = E::add(u, T::neg(v));
     }
 #else
-    const typename E::Proj s0 = E::add_quad(u, v, role), s1 = E::add_quad(u, T::neg(v), role);
+    const typename E::Proj s0 = QADD(u, v, role), s1 = QADD(u, T::neg(v), role);
     if (live && role == 0) {
       base[i] = s0;
       base[i + half] = s1;
@@ -453,10 +460,10 @@ namespace icicle_hip {
     const typename E::Proj* tg = terms + (grp * (R - 1)) * hr + u; // term (j, u) at tg[(j - 1) * hr]
     typename E::Proj ev = work[base], od = tg[(size_t)(hr - 1) * hr]; // A_0 ; T_{R/2}
     for (uint32_t j = 1; j < hr; j++)
-      ev = E::add_quad(ev, tg[(size_t)(j - 1) * hr], role);
+      ev = QADD(ev, tg[(size_t)(j - 1) * hr], role);
     for (uint32_t j = hr + 1; j < R; j++)
-      od = E::add_quad(od, tg[(size_t)(j - 1) * hr], role);
-    const typename E::Proj y0 = E::add_quad(ev, od, role), y1 = E::add_quad(ev, T::neg(od), role);
+      od = QADD(od, tg[(size_t)(j - 1) * hr], role);
+    const typename E::Proj y0 = QADD(ev, od, role), y1 = QADD(ev, T::neg(od), role);
     if (live && role == 0) {
       next[base + (uint64_t)u * L] = y0;
       next[base + (uint64_t)(u + hr) * L] = y1;
