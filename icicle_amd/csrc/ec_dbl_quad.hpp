@@ -19,6 +19,14 @@
 
 namespace icicle_hip {
 
+  // true for the G1 curves whose 3 b is 3, 9 or 12 (the G2 parameter sets have no B3_SMALL at all)
+  template <class C, class = void>
+  struct has_small_b3 : std::false_type {
+  };
+  template <class C>
+  struct has_small_b3<C, std::void_t<decltype(C::B3_SMALL)>> : std::bool_constant<C::EXT_DEGREE == 1 && C::B3_SMALL != 0> {
+  };
+
   template <class C>
   struct EcDblSmallB {
     static_assert(C::EXT_DEGREE == 1 && (C::B3_SMALL == 3 || C::B3_SMALL == 9 || C::B3_SMALL == 12), "3 b must be 3, 9 or 12");

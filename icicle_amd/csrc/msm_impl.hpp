@@ -26,6 +26,7 @@
 #pragma once
 #include "common.h"
 #include "ec.hpp"
+#include "ec_dbl_quad.hpp"
 #include "msm_plan.h"
 #include <algorithm>
 #include <tuple>
@@ -1103,13 +1104,18 @@ namespace icicle_hip {
     typename E::Proj v = E::proj_identity();
     if (w < nwb) {
       v = winsum[w];
-      if (wfirst + w > 0) { // Jacobian doubling chain (ec.hpp), 2M + 5S per step
-        typename E::Jac j = E::to_jac(v);
+      if (wfirst + w > 0) {
         const int wg = wfirst + w; // bit offset of the window = sum of the widths below it
         const int nd = wg < ww.n_lo ? wg * (c - 1) : ww.n_lo * (c - 1) + (wg - ww.n_lo) * c;
-        for (int i = 0; i < nd; i++) // the same trip count in all four lanes of a quad
-          j = E::dbl_jac_quad(j, role);
-        v = E::from_jac(j);
+        if constexpr (has_small_b3<C>::value) { // complete projective doublings, two product levels per step (ec_dbl_quad.hpp; round 6)
+          for (int i = 0; i < nd; i++)          // the same trip count in all four lanes of a quad
+            v = EcDblSmallB<C>::dbl_quad(v, role);
+        } else { // Jacobian doubling chain (ec.hpp), 2M + 5S in three levels per step
+          typename E::Jac j = E::to_jac(v);
+          for (int i = 0; i < nd; i++)
+            j = E::dbl_jac_quad(j, role);
+          v = E::from_jac(j);
+        }
       }
     }
     if (role == 0) sh[w] = v;
@@ -1140,11 +1146,17 @@ namespace icicle_hip {
     const typename E::Proj* ws = winsum + (size_t)(act ? b : 0) * wpf;
     typename E::Proj acc = ws[wpf - 1];
     for (int w = wpf - 2; w >= 0; w--) { // acc = 2^width(w) * acc + S_w (the same trip counts in every lane)
-      typename E::Jac j = E::to_jac(acc);
       const int nd = ww.width(w);
-      for (int i = 0; i < nd; i++)
-        j = E::dbl_jac_quad(j, role);
-      acc = E::add_quad(E::from_jac(j), ws[w], role);
+      if constexpr (has_small_b3<C>::value) {
+        for (int i = 0; i < nd; i++)
+          acc = EcDblSmallB<C>::dbl_quad(acc, role);
+        acc = EcQuadAdd<C>::add(acc, ws[w], role);
+      } else {
+        typename E::Jac j = E::to_jac(acc);
+        for (int i = 0; i < nd; i++)
+          j = E::dbl_jac_quad(j, role);
+        acc = E::add_quad(E::from_jac(j), ws[w], role);
+      }
     }
     if (act && role == 0) E::store_proj_canonical(result + (size_t)b * 3 * E::N32, acc);
   }
