@@ -6,6 +6,10 @@
 // bucket method pays per point and window, and 2 n half-length scalars cost what n full-length ones do).
 // The reference multiplies with a plain windowed double-and-add (icicle/include/icicle/curves/projective.h:192-224); any method
 // that returns the same group element is a drop-in.
+// Precondition: P in the subgroup of prime order r (phi = lambda only there; BLS12-381 / BLS12-377 have cofactors of ~2^126). The ECNTT
+// itself has that precondition: outside the subgroup w^a (w^b P) != w^(a + b mod r) P and the reference's own transform is neither
+// invertible nor equal to its definition (tests/test_ecntt_domain_of_definition.py pins that with the reference), so the split
+// narrows nothing.
 //
 // Constants (tools/gen_consts.py glv_constants -> field_consts.h): a reduced basis (a1, b1), (a2, b2) of the lattice
 // {(a, b) : a + b lambda = 0 mod r} and G_i = 2^256 b2 / det, 2^256 (-b1) / det rounded towards zero. With
