@@ -203,7 +203,7 @@ API_SYMBOLS = (
     + [f"{pre}{f}_matrix_transpose" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + BIG_VEC_FIELDS + [GOLD]]
     + [f"{pre}{f}_extension_matrix_transpose" for pre in ("", "icicle_hip_") for f in NTT_FIELDS + [GOLD]]
     + ["icicle_hip_msm_plan", "icicle_hip_msm_plan_info", "icicle_hip_version", "icicle_hip_kernel_timing", "icicle_hip_enable_kernel_timing", "icicle_hip_set_device",
-       "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_ubench_ntt_pass", "icicle_hip_selftest_inplace_products", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
+       "icicle_hip_ubench_mixed_add", "icicle_hip_ubench_gather", "icicle_hip_ubench_ntt_pass", "icicle_hip_selftest_inplace_products", "icicle_hip_selftest_quad_group_ops", "icicle_hip_release_workspace", "icicle_hip_workspace_bytes",
        "icicle_hip_msm_release_resident_bases", "icicle_hip_multi_stats", "icicle_hip_multi_stats2", "icicle_hip_collectives_info", "icicle_hip_test_set_virtual_devices", "icicle_hip_test_set_no_peer_access",
        "icicle_hip_set_collectives_library", "icicle_hip_test_inject_failure",
        "icicle_hip_create_config_extension", "icicle_hip_destroy_config_extension", "icicle_hip_config_extension_set_int",
@@ -300,6 +300,7 @@ lib.icicle_hip_ubench_ntt_pass.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c
 lib.icicle_hip_ubench_gather.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double)]
 lib.icicle_hip_workspace_bytes.argtypes = [ctypes.POINTER(ctypes.c_size_t)]
 lib.icicle_hip_selftest_inplace_products.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+lib.icicle_hip_selftest_quad_group_ops.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
 lib.icicle_hip_msm_release_resident_bases.argtypes = [ctypes.c_void_p]
 lib.icicle_hip_multi_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_bool]
 lib.icicle_hip_multi_stats2.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_bool]

@@ -11,6 +11,7 @@
 // None touches user data. tools/ubench/msm_ubench.hip holds the wider design-decision sweeps.
 #include "common.h"
 #include "ec.hpp"
+#include "ec_dbl_quad.hpp"
 #include "ntt_fast.hpp"
 
 namespace icicle_hip {
@@ -244,6 +245,62 @@ namespace icicle_hip {
     return ICICLE_SUCCESS;
   }
 
+  // ---- self-test of the quad-cooperative group operations (ec.hpp add_quad, ec_dbl_quad.hpp EcQuadAdd / EcDblSmallB) -----------
+  // The ECNTT's butterflies and the MSM's window combine spread the complete addition and doubling over the four lanes of a DPP
+  // quad. Here every quad takes a pair (P, Q) = (a G, +- b G), a, b in 0..6 (0 = the identity) -- so P = Q, P = -Q, O + P, P + O and
+  // O + O all occur -- and compares each quad form with the one-lane complete formulas (add_body / dbl_body, themselves checked against
+  // Python integers on the host) AS GROUP ELEMENTS: cross-multiplied coordinates, both or neither at infinity.
+  template <class C>
+  __global__ __launch_bounds__(64) void k_selftest_quad_ops(uint32_t* __restrict__ mismatches)
+  {
+    using E = EC<C>;
+    using F = typename E::F;
+    using Proj = typename E::Proj;
+    const uint32_t role = threadIdx.x & 3u;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const uint32_t a = t % 7u, b = (t / 7u) % 7u, neg = (t / 49u) & 1u;
+    const Proj g = E::to_proj(E::generator());
+    const Proj p = E::mul_small(g, a);
+    Proj q = E::mul_small(g, b);
+    if (neg) q.y = F::template neg<4>(q.y);
+    auto same_point = [&](const Proj& u, const Proj& v) {
+      const bool zu = F::is_zero(u.z), zv = F::is_zero(v.z);
+      if (zu || zv) return zu == zv && !F::is_zero(u.y) && !F::is_zero(v.y); // (0 : y != 0 : 0), never (0, 0, 0)
+      return F::eq(F::mul(u.x, v.z), F::mul(v.x, u.z)) && F::eq(F::mul(u.y, v.z), F::mul(v.y, u.z));
+    };
+    uint32_t bad = 0;
+    const Proj s = E::add(p, q);
+    bad += !same_point(E::add_quad(p, q, role), s);
+    bad += !same_point(EcQuadAdd<C>::add(p, q, role), s);
+    Proj d5 = p, h5 = p;
+    for (int i = 0; i < 5; i++) {
+      d5 = EcDblSmallB<C>::dbl_quad(d5, role);
+      h5 = E::dbl(h5);
+    }
+    bad += !same_point(EcDblSmallB<C>::dbl_quad(q, role), E::dbl(q));
+    bad += !same_point(d5, h5);
+    bad += !same_point(d5, E::mul_small(p, 32));
+    // a doubling and an addition fed by quad results (the bounds the chain runs with)
+    bad += !same_point(EcQuadAdd<C>::add(EcDblSmallB<C>::dbl_quad(s, role), EcQuadAdd<C>::add(p, q, role), role), E::add(E::dbl(s), s));
+    if (bad && role == 0) atomicAdd(mismatches, bad);
+    if (role != 0 && bad) atomicAdd(mismatches + 1, bad); // (every lane of a quad must hold the result: lanes 1..3 counted apart)
+  }
+
+  template <class C>
+  static icicle_error_t selftest_quad_ops_run(int* mismatches)
+  {
+    ICICLE_TRY(bind_current_device());
+    TempBuf cnt;
+    HIP_TRY(cnt.alloc(16, nullptr), ICICLE_ALLOCATION_FAILED);
+    HIP_TRY(hipMemsetAsync(cnt.ptr(), 0, 16, nullptr), ICICLE_COPY_FAILED);
+    k_selftest_quad_ops<C><<<(98 * 4 + 63) / 64, 64>>>(cnt.as<uint32_t>()); // 7 x 7 x 2 pairs (the last block wraps around: t % 7 ...)
+    LAUNCH_CHECK("k_selftest_quad_ops", nullptr);
+    uint32_t h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, cnt.ptr(), 8, hipMemcpyDeviceToHost), ICICLE_COPY_FAILED);
+    *mismatches = (int)(h[0] + h[1]);
+    return ICICLE_SUCCESS;
+  }
+
 } // namespace icicle_hip
 
 using namespace icicle_hip;
@@ -313,6 +370,20 @@ extern "C" icicle_error_t icicle_hip_selftest_inplace_products(int curve, int* m
   try {
     if (curve == 0) return selftest_inplace_run<bn254_g1>(mismatches);
     if (curve == 1) return selftest_inplace_run<bls12_381_g1>(mismatches);
+  } catch (...) {
+  }
+  return ICICLE_INVALID_ARGUMENT;
+}
+
+// Quad-cooperative complete addition / doubling (ec.hpp add_quad, ec_dbl_quad.hpp) against the one-lane formulas on every pair
+// (a G, +- b G), a, b = 0..6, as group elements (curve 0 = bn254, 1 = bls12_381, 2 = bls12_377): *mismatches must come back 0.
+extern "C" icicle_error_t icicle_hip_selftest_quad_group_ops(int curve, int* mismatches)
+{
+  if (!mismatches) return ICICLE_INVALID_POINTER;
+  try {
+    if (curve == 0) return selftest_quad_ops_run<bn254_g1>(mismatches);
+    if (curve == 1) return selftest_quad_ops_run<bls12_381_g1>(mismatches);
+    if (curve == 2) return selftest_quad_ops_run<bls12_377_g1>(mismatches);
   } catch (...) {
   }
   return ICICLE_INVALID_ARGUMENT;

@@ -339,6 +339,10 @@ icicle_error_t icicle_hip_ubench_ntt_pass(int field, double* pass_units_per_seco
 /* Device self-test of the in-place asm field products with aliased and constant operands (curve 0 = bn254, 1 = bls12_381):
  * *mismatches must be 0 (tests/test_gpu_msm.py). */
 icicle_error_t icicle_hip_selftest_inplace_products(int curve, int* mismatches);
+/* Quad-cooperative complete addition / doubling (the ECNTT's butterflies, the MSM's window combine on the GPU) against the one-lane
+ * formulas of the reference (projective.h:73-143) on every pair (a G, +- b G), a, b = 0..6 -- P = Q, P = -Q and the identity included --
+ * as group elements. curve 0 = bn254, 1 = bls12_381, 2 = bls12_377; *mismatches must come back 0. */
+icicle_error_t icicle_hip_selftest_quad_group_ops(int curve, int* mismatches);
 /* msm()/ntt() keep their temporaries cached between calls (about 8 GiB after a 2^26-term MSM). release_workspace gives
  * the idle part back to the device (it is also given back automatically when an allocation would otherwise fail, and by
  * <field>_ntt_release_domain); workspace_bytes reports what is cached for the active device. */

@@ -186,3 +186,17 @@ def test_ecntt_timing_vs_reference_cpu(hip):
     with open(os.path.join("gpurun_out", "ecntt_timing.txt"), "a") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
+
+
+@pytest.mark.parametrize("curve_id,cname", [(0, "bn254"), (1, "bls12_381"), (2, "bls12_377")])
+def test_quad_cooperative_group_operations_against_the_one_lane_formulas(hip, curve_id, cname):
+    """the butterflies' addition (four product rounds over a DPP quad, ec_dbl_quad.hpp EcQuadAdd; the five-round ec.hpp add_quad) and
+    doubling (two product levels, EcDblSmallB::dbl_quad) on every pair (a G, +- b G), a, b = 0..6 -- P = Q, P = -Q, O + P, P + O, O + O and
+    runs of five doublings included -- against the complete one-lane formulas (the reference's, projective.h:73-143; checked against
+    Python integers in tests/test_host_math.py), compared as group elements on the device; every lane of a quad must hold the result"""
+    import ctypes
+    from icicle_amd._lib import lib, check
+
+    bad = ctypes.c_int(-1)
+    check(lib.icicle_hip_selftest_quad_group_ops(curve_id, ctypes.byref(bad)), "selftest")
+    assert bad.value == 0, (cname, bad.value)
