@@ -1071,6 +1071,116 @@ namespace icicle_hip {
     }
   }
 
+  // ---- the same reduction with FOUR lanes per bucket column (round 6): small and mid-size MSMs -------------------------------
+  // Up to ~2^20 terms the bucket reduction is a latency chain, not work: at 2^16 its two kernels were half of a 1.0 ms MSM
+  // (0.28 + 0.22 ms), one wave per SIMD or less, each lane walking ~50 dependent complete additions of fourteen products. Here a
+  // DPP quad owns what a lane owned -- every addition is ec_dbl_quad.hpp's four product rounds, every doubling its two levels --
+  // and a wave reduces 16 columns instead of 64. Same sums (S = sum_c (V_c + T_c) + chunk * sum_c c T_c), uniform window plans of a
+  // single MSM on one device only; the throughput-bound reductions of the large MSMs keep the one-lane kernels above.
+  template <class C>
+  __device__ __forceinline__ typename EC<C>::Proj reduce_quad_add(const typename EC<C>::Proj& a, const typename EC<C>::Proj& b, uint32_t role)
+  {
+    return EcQuadAdd<C>::add(a, b, role);
+  }
+  template <class C>
+  __device__ __forceinline__ typename EC<C>::Proj reduce_quad_dbl(const typename EC<C>::Proj& a, uint32_t role)
+  {
+    if constexpr (has_small_b3<C>::value)
+      return EcDblSmallB<C>::dbl_quad(a, role);
+    else
+      return EC<C>::dbl(a); // (every lane of the quad computes the same value)
+  }
+  // chunk ch of window wp = 16 m buckets from ch * 16 m: V = sum (local index) B, T = sum B (lane 0 of the wave stores)
+  template <class C>
+  __global__ __launch_bounds__(64) void k_reduce_wave_quad(const typename EC<C>::Proj* __restrict__ buckets, typename EC<C>::Proj* __restrict__ chunkV, typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum_direct, uint32_t nb, uint32_t m, uint32_t nsegr)
+  {
+    using E = EC<C>;
+    using Proj = typename E::Proj;
+    const uint32_t role = threadIdx.x & 3u;
+    const int lane = (int)(threadIdx.x >> 2); // 16 quad-lanes per wave
+    const size_t wp = blockIdx.x / nsegr;
+    const uint32_t ch = blockIdx.x % nsegr;
+    const uint32_t k0 = ch * 16u * m;
+    const Proj* b = buckets + wp * nb;
+    Proj line = E::proj_identity(), tri0 = E::proj_identity();
+    for (int i = (int)m - 1; i >= 0; i--) {
+      const uint32_t k = k0 + 16u * (uint32_t)i + (uint32_t)lane;
+      tri0 = reduce_quad_add<C>(tri0, line, role);
+      if (k < nb) line = reduce_quad_add<C>(line, b[k], role); // (the same for the four lanes of a quad)
+    }
+    Proj suf = line; // inclusive suffix sum over the 16 quad-lanes
+    for (int d = 1; d < 16; d <<= 1) {
+      const Proj o = proj_shfl_down(suf, 4 * d);
+      if (lane + d < 16) suf = reduce_quad_add<C>(suf, o, role);
+    }
+    Proj x = proj_shfl_down(suf, 4); // exclusive
+    if (lane == 15) x = E::proj_identity();
+    for (int q = 0; q < 4; q++)
+      tri0 = reduce_quad_dbl<C>(tri0, role); // 16 * tri0
+    Proj v = reduce_quad_add<C>(x, tri0, role);
+    for (int d = 8; d >= 1; d >>= 1) {
+      const Proj o = proj_shfl_down(v, 4 * d);
+      if (lane < d) v = reduce_quad_add<C>(v, o, role);
+    }
+    if (lane == 0) {
+      const size_t oi = wp * nsegr + ch;
+      if (winsum_direct) { // the chunk is the whole window
+        const Proj w = reduce_quad_add<C>(v, suf, role);
+        if (role == 0) winsum_direct[oi] = w;
+      } else if (role == 0) {
+        chunkV[oi] = v;
+        chunkT[oi] = suf;
+      }
+    }
+  }
+  // per window: S = sum_c (V_c + T_c) + chunk * sum_c c T_c over nsegr <= 64 chunks of `chunk` buckets (any size >= 1), one quad per
+  // chunk. The two block sums of k_reduce_window are one here: every quad scales its own exclusive suffix by the chunk size first
+  // (a double-and-add over the bits of `chunk`, side by side in all quads). Serves the chunks of either wave kernel.
+  template <class C>
+  __global__ __launch_bounds__(256) void k_reduce_window_quad(const typename EC<C>::Proj* __restrict__ chunkV, const typename EC<C>::Proj* __restrict__ chunkT, typename EC<C>::Proj* __restrict__ winsum, uint32_t nsegr, uint32_t chunk)
+  {
+    using E = EC<C>;
+    using Proj = typename E::Proj;
+    __shared__ Proj sh[64];
+    const int wp = blockIdx.x, tid = threadIdx.x;
+    const uint32_t role = (uint32_t)tid & 3u;
+    const int q = tid >> 2, lane = q & 15, wave = q >> 4;
+    const int NQ = blockDim.x >> 2, NW = (blockDim.x + 63) / 64; // launched with 4 x (the power of two >= nsegr, at least 16) threads
+    const bool have = (uint32_t)q < nsegr;
+    const Proj t = have ? chunkT[(size_t)wp * nsegr + q] : E::proj_identity();
+    const Proj u = have ? reduce_quad_add<C>(chunkV[(size_t)wp * nsegr + q], t, role) : E::proj_identity();
+    Proj suf = t; // inclusive suffix sum of T over the 16 quad-lanes of the wave
+    for (int d = 1; d < 16; d <<= 1) {
+      const Proj o = proj_shfl_down(suf, 4 * d);
+      if (lane + d < 16) suf = reduce_quad_add<C>(suf, o, role);
+    }
+    if (lane == 0 && role == 0) sh[wave] = suf; // wave totals
+    __syncthreads();
+    Proj x = proj_shfl_down(suf, 4);
+    if (lane == 15) x = E::proj_identity();
+    for (int w = NW - 1; w > wave; w--)
+      x = reduce_quad_add<C>(x, sh[w], role); // exclusive suffix over the block: sum of T_c' for c' > c
+    __syncthreads();
+    {
+      const Proj x1 = x; // chunk * x, most significant bit first (chunk is the same in every lane)
+      for (int bit = 30 - __clz((int)chunk); bit >= 0; bit--) {
+        x = reduce_quad_dbl<C>(x, role);
+        if ((chunk >> bit) & 1u) x = reduce_quad_add<C>(x, x1, role);
+      }
+    }
+    Proj v = reduce_quad_add<C>(u, x, role);
+    if (role == 0) sh[q] = v;
+    __syncthreads();
+    for (int s2 = NQ / 2; s2 >= 1; s2 >>= 1) {
+      if (q < s2) {
+        v = reduce_quad_add<C>(v, sh[q + s2], role);
+        if (role == 0) sh[q] = v;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) winsum[wp] = v;
+  }
+
   // 5c. window combine: result = sum_w 2^(c*w) * winsum[w], written in the reference's
   //     projective_t layout (canonical words). One 128-lane block: lane w scales its own window
   //     sum by c*w doublings (the same critical path as a serial Horner, but the doublings of
@@ -1607,7 +1717,7 @@ namespace icicle_hip {
     HIP_TRY(d_offs.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_cursor.alloc(nbk * 4, st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_buckets.alloc(nbk * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
-    HIP_TRY(d_seg.alloc(2 * TW * nseg * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED); // chunk V | chunk T
+    HIP_TRY(d_seg.alloc(2 * TW * std::max<size_t>(nseg, 64) * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED); // chunk V | chunk T (64: the quad reduction's chunks per window)
     HIP_TRY(d_win.alloc(TW * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
     HIP_TRY(d_ovf.alloc(((size_t)ovf_cap + 16 * 16) * sizeof(OvfSeg), st), ICICLE_ALLOCATION_FAILED); // (+ the per-group slack of the pipelined schedule)
     HIP_TRY(d_ovfpart.alloc(((size_t)ovf_cap + 16 * 16) * sizeof(typename E::Proj), st), ICICLE_ALLOCATION_FAILED);
@@ -1718,7 +1828,7 @@ namespace icicle_hip {
         HIP_TRY(hipStreamWaitEvent(s_sort, ev_ready, 0), ICICLE_SYNCHRONIZATION_FAILED);
       }
       typename E::Proj* chunkV = d_seg.as<typename E::Proj>();
-      typename E::Proj* chunkT = chunkV + TW * nseg;
+      typename E::Proj* chunkT = chunkV + TW * std::max<size_t>(nseg, 64);
       uint32_t ovf_off = 0;
       uint32_t g_ovf_off[16], g_ovf_cap[16];
       for (int g = 0; g < NG; g++) { // overflow segments of a group <= (list entries of its windows) / seg; the caps add up to ovf_cap + 16 NG
@@ -1858,7 +1968,42 @@ namespace icicle_hip {
         const size_t nblocks = (size_t)nlo_w * nseg_lo + (size_t)(nw - nlo_w) * nsegr;
         // whole small windows: several per wave (k_reduce_small); rows per lane: 8, or 4 for the tiniest windows
         static const bool small_on = !(getenv("ICICLE_HIP_MSM_REDUCE_SMALL") && atoi(getenv("ICICLE_HIP_MSM_REDUCE_SMALL")) == 0);
-        if (small_on && direct && nlo_w == 0 && nb >= 16 && nb <= 512 && nw >= 64) {
+        // Four lanes per bucket column while the reduction is a latency chain (single MSM, uniform plan, one device): the window kernel
+        // whenever a window has at most 64 chunks, the wave kernel when its shorter additions beat the one-lane kernel's 3.5 x fewer
+        // lanes -- up to ~2^18 terms; beyond, the reduction is work and the one-lane kernel wins (2^20: 0.56 against 0.43 ms).
+        // ICICLE_HIP_MSM_REDUCE_QUAD=0: off (A/B).
+        static const bool quad_on = !(getenv("ICICLE_HIP_MSM_REDUCE_QUAD") && atoi(getenv("ICICLE_HIP_MSM_REDUCE_QUAD")) == 0);
+        bool quad_done = false, quad_window = false;
+        if constexpr (C::EXT_DEGREE == 1) {
+          const bool small_path = small_on && direct && nlo_w == 0 && nb >= 16 && nb <= 512 && nw >= 64;
+          if (quad_on && !hook && NG == 1 && bb == 1 && pl.n_lo == 0 && seg_lo == 0 && nsegr == nseg && nb >= 16 && !small_path) {
+            quad_window = nseg <= 64 && !direct;
+            if (nb <= 65536) {
+              // chunks per window so that the waves fill the SIMDs once (a wave past 1024 doubles the time of its SIMD), rows to match
+              uint32_t nsq = std::min<uint32_t>(std::min<uint32_t>(64, std::max<uint32_t>(1, 1024 / (uint32_t)nw)), nb / 16);
+              const uint32_t mq = (nb + 16 * nsq - 1) / (16 * nsq);
+              nsq = (nb + 16 * mq - 1) / (16 * mq);
+              // additions on the chain x instructions per addition (in hundreds) x rounds of waves on the 1024 SIMDs
+              const uint64_t cost_q = (uint64_t)(2 * mq + 13) * 13 * (((uint64_t)nw * nsq + 1023) / 1024);
+              const uint64_t cost_s = (uint64_t)(2 * mrow + 19) * 29 * (((uint64_t)nw * nseg + 1023) / 1024);
+              if (cost_q < cost_s) {
+                const bool direct_q = nsq == 1;
+                k_reduce_wave_quad<C><<<(unsigned)((size_t)nw * nsq), 64, 0, sq>>>(buckets + (size_t)w0 * nb, chunkV, chunkT, direct_q ? win : nullptr, nb, mq, nsq);
+                LAUNCH_CHECK("k_reduce_wave_quad", sq);
+                if (!direct_q) {
+                  unsigned qthreads = 64;
+                  while (qthreads < 4 * nsq)
+                    qthreads <<= 1;
+                  k_reduce_window_quad<C><<<(unsigned)nw, qthreads, 0, sq>>>(chunkV, chunkT, win, nsq, 16 * mq);
+                  LAUNCH_CHECK("k_reduce_window_quad", sq);
+                }
+                quad_done = true;
+              }
+            }
+          }
+        }
+        if (quad_done) {
+        } else if (small_on && direct && nlo_w == 0 && nb >= 16 && nb <= 512 && nw >= 64) {
           uint32_t lw_log = 2;
           while ((nb >> lw_log) > 8 && lw_log < 5)
             lw_log++;
@@ -1869,7 +2014,15 @@ namespace icicle_hip {
           k_reduce_wave<C><<<(unsigned)nblocks, 64, 0, sq>>>(buckets + (size_t)w0 * nb, cV, cT, direct ? win : nullptr, nb, nb, mrow, seg_lo, nsegr, nlo_w, nseg_lo, mrow_lo);
           LAUNCH_CHECK("k_reduce_wave", sq);
         }
-        if (!direct) {
+        if (!direct && !quad_done && quad_window) {
+          if constexpr (C::EXT_DEGREE == 1) {
+            unsigned qthreads = 64;
+            while (qthreads < 4 * nseg)
+              qthreads <<= 1;
+            k_reduce_window_quad<C><<<(unsigned)nw, qthreads, 0, sq>>>(cV, cT, win, nseg, 64 * mrow);
+            LAUNCH_CHECK("k_reduce_window_quad", sq);
+          }
+        } else if (!direct && !quad_done) {
           unsigned rthreads = 64; // power of two (LDS tree), >= the chunks of a window
           while (rthreads < std::max(nsegr, nlo_w ? nseg_lo : 0u) && rthreads < RWL)
             rthreads <<= 1;
