@@ -84,8 +84,23 @@ namespace icicle_hip {
       // (a batch runs as ONE launch sequence with batch x the bucket threads and batch x the reduction work: round 1's
       //  weights stay the better fit there -- 16 x 2^16: 3.5 ms against 4.5 ms with the single-MSM fit)
       const bool mid = n >= (1 << 16) && (table || std::max(1, cfg.batch_size) == 1);
+      // A single small MSM of full-width scalars is a chain of latencies, and since the bucket reduction runs four lanes per column
+      // (round 6, msm_impl.hpp k_reduce_wave_quad) a bucket costs little: what counts is the length of the accumulation chains
+      // (n / 2^(c-1) mixed additions per bucket) and the window count. Measured sweeps (profiles/r06_small_msm_c_sweep.txt): up to 2^12
+      // terms c = 8 (32 windows; BN254 2^10 1.23 -> 0.89 ms, BLS12-381 2^11 2.14 -> 1.58), above c = 15 (17 windows of a 254-bit scalar;
+      // BN254 2^15 1.48 -> 1.09 ms) -- or the next c whose top window is not a stub (BLS12-381: 16; 2^15 2.74 -> 2.05 ms).
+      int small_c = 0;
+      // (up to 2^18 terms: from 2^16 the fit below picks 15 for 253 / 254-bit scalars itself, but 13 / 14 for 255-bit ones where 15 leaves a one-bit
+      //  top window -- BLS12-381 2^16 2.81 ms against 2.14 at c = 16, 2^17 2.94 against 2.29)
+      if (!table && std::max(1, cfg.batch_size) == 1 && n < (1 << 18) && p.bits >= 200) {
+        small_c = n <= (1 << 12) ? 8 : 15;
+        for (;; small_c++) {
+          const int w = (p.bits + 1 + small_c - 1) / small_c;
+          if (!(w > 1 && p.bits + 1 - small_c * (w - 1) <= 3)) break;
+        }
+      }
       double best = 1e300;
-      for (int cc = 2; cc <= 21; cc++) {
+      for (int cc = (small_c ? small_c : 2); cc <= (small_c ? small_c : 21); cc++) {
         const int w = (p.bits + 1 + cc - 1) / cc;
         const int wpf = (w + p.pf - 1) / p.pf;
         if (w > 1 && p.bits + 1 - cc * (w - 1) <= 3 && p.bits > 8) continue; // tiny top window

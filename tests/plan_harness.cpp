@@ -116,6 +116,8 @@ extern "C" int msm_plan_check(void)
           if (p.nwin != (p.bits + 1 + p.c - 1) / p.c || p.wpf != (p.nwin + pf - 1) / pf || p.nb != (1u << (p.c - 1))) return tag * 10 + 2;
           if (pf == 1 && p.nwin > 1 && p.bits > 8 && p.bits + 1 - p.c * (p.nwin - 1) <= 3) return tag * 10 + 3; // tiny top window
           if (pf == 1 && batch > 1 && logn <= 17 && p.c > 11) return tag * 10 + 4;
+          // a single small MSM of full-width scalars: the latency rule (8 up to 2^12 terms, then 15 -- or the next c whose top window is no stub)
+          if (pf == 1 && batch == 1 && logn < 18 && bits >= 200 && p.c != (logn <= 12 ? 8 : (bits == 255 ? 16 : 15))) return tag * 10 + 8;
           if (pf > 1) { // a base table: msm_precompute_bases and msm must agree whatever batch_size either call carries
             icicle_msm_config_t c1 = cfg;
             c1.batch_size = 1;

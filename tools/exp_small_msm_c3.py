@@ -1,0 +1,15 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+sys.argv = ["perf_matrix.py", "none"]
+import importlib.util
+spec = importlib.util.spec_from_file_location("pm", "tools/perf_matrix.py")
+pm = importlib.util.module_from_spec(spec)
+try:
+    spec.loader.exec_module(pm)
+except SystemExit:
+    pass
+for curve in ("bls12_381", "bls12_377"):
+    for logn in (16, 17, 18, 19, 20):
+        pm.msm_case(curve, logn)
+        for c in (13, 14, 15, 16, 17, 18):
+            pm.msm_case(curve, logn, c=c)
