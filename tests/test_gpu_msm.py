@@ -728,3 +728,45 @@ assert big2 > (32 << 20) and after < big2 // 4, (big2, after)
     env = dict(os.environ, ICICLE_HIP_WORKSPACE_DECAY_S="1", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert r.returncode == 0 and "DECAY" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("quad", ["1", "0"])
+def test_bucket_reduction_routes_across_the_cost_model_boundary(hip, quad):
+    """Round 6: single MSMs of a uniform plan reduce their buckets with four lanes per bucket column (k_reduce_wave_quad /
+    k_reduce_window_quad, msm_impl.hpp) while the reduction is a latency chain -- the wave kernel up to ~2^18 terms by a cost model, the
+    window kernel whenever a window has at most 64 chunks -- and with the one-lane kernels beyond. Sizes on both sides of every
+    switch (window sizes 8, 15, 16, 17; free chunk sizes: 57 chunks of 288 buckets at 2^16), two curves, against the reference CPU
+    backend; `ICICLE_HIP_MSM_REDUCE_QUAD` is read once per process, hence a child per setting: "0" keeps the one-lane route of
+    rounds 1-5 covered at the small sizes where the default no longer takes it."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import icicle_amd as hip
+from icicle_amd import msm as M, runtime
+from oracle import pyref, ref
+from tests.util import cached_points, points_to_array, rand_scalars, to_words
+runtime.set_device(0)
+for cname, logns in (("bn254", (3, 6, 10, 12, 13, 15, 16, 17, 18, 19, 20)), ("bls12_381", (9, 13, 16, 18))):
+    C = pyref.CURVES[cname]
+    refc = ref.RefCurve(cname)
+    rng = np.random.default_rng(606)
+    for logn in logns:
+        n = (1 << logn) - int(rng.integers(0, 5))
+        period = min(n, 4096)
+        pts = points_to_array(C, cached_points(C, period))
+        bases = np.ascontiguousarray(np.tile(pts, ((n + period - 1) // period, 1))[:n])
+        sc = to_words(rand_scalars(rng, n, C.r), 8)
+        got = M.msm(cname, sc, bases)
+        exp = refc.msm(sc, bases)
+        assert np.array_equal(refc.to_affine(got), refc.to_affine(exp)), (cname, logn)
+print("REDUCE OK")
+""" % root
+    env = dict(os.environ)
+    env["ICICLE_HIP_MSM_REDUCE_QUAD"] = quad
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0 and "REDUCE OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
