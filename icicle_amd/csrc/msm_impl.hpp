@@ -1974,7 +1974,9 @@ namespace icicle_hip {
         // ICICLE_HIP_MSM_REDUCE_QUAD=0: off (A/B).
         static const bool quad_on = !(getenv("ICICLE_HIP_MSM_REDUCE_QUAD") && atoi(getenv("ICICLE_HIP_MSM_REDUCE_QUAD")) == 0);
         bool quad_done = false, quad_window = false;
-        if constexpr (C::EXT_DEGREE == 1) {
+        // (G1, and the G2 whose point fits the registers four lanes deep: BN254's -- BLS12-381's 28-limb Fq2 elements do not)
+        constexpr bool QUAD_OK = C::EXT_DEGREE == 1 || sizeof(typename E::XYZZ) <= 288;
+        if constexpr (QUAD_OK) {
           const bool small_path = small_on && direct && nlo_w == 0 && nb >= 16 && nb <= 512 && nw >= 64;
           if (quad_on && !hook && NG == 1 && bb == 1 && pl.n_lo == 0 && seg_lo == 0 && nsegr == nseg && nb >= 16 && !small_path) {
             quad_window = nseg <= 64 && !direct;
@@ -2015,7 +2017,7 @@ namespace icicle_hip {
           LAUNCH_CHECK("k_reduce_wave", sq);
         }
         if (!direct && !quad_done && quad_window) {
-          if constexpr (C::EXT_DEGREE == 1) {
+          if constexpr (QUAD_OK) {
             unsigned qthreads = 64;
             while (qthreads < 4 * nseg)
               qthreads <<= 1;
