@@ -569,7 +569,10 @@ namespace icicle_hip {
     // at the same time on the stream (rounds 1-4 kept the scale tables next to the stage scratch: 2^20 BLS12-381 points took
     // 2.4 GB + 1.2 GB for a 151 MB transform). Sized once, for the largest of the three.
     static const int forced_r = getenv("ICICLE_HIP_ECNTT_RADIX_LOG") ? atoi(getenv("ICICLE_HIP_ECNTT_RADIX_LOG")) : 0;
-    static const uint64_t budget = getenv("ICICLE_HIP_ECNTT_QUADS") ? (uint64_t)atoll(getenv("ICICLE_HIP_ECNTT_QUADS")) : 16384;
+    // product budget of a matrix-form stage: 16384 quads is the knee for transforms of up to 2^13 points (2^12: 2.04 ms against 2.71 at 32768),
+    // from 2^14 points a second radix-4 stage pays (2^14: 6.49 -> 6.02 ms); profiles/r06_ecntt_quads_budget.txt, re-measured on the round-6 chain
+    static const uint64_t budget_env = getenv("ICICLE_HIP_ECNTT_QUADS") ? (uint64_t)atoll(getenv("ICICLE_HIP_ECNTT_QUADS")) : 0;
+    const uint64_t budget = budget_env ? budget_env : (tot >= 16384 ? 32768 : 16384);
     static const int gtab_mode = getenv("ICICLE_HIP_ECNTT_GTABS") ? atoi(getenv("ICICLE_HIP_ECNTT_GTABS")) : -1; // 0 / 1 force, -1 auto
     int widths[64];
     const int nst = ecntt_stage_plan(logn, tot, budget, forced_r, widths);

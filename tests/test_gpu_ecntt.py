@@ -200,3 +200,30 @@ def test_quad_cooperative_group_operations_against_the_one_lane_formulas(hip, cu
     bad = ctypes.c_int(-1)
     check(lib.icicle_hip_selftest_quad_group_ops(curve_id, ctypes.byref(bad)), "selftest")
     assert bad.value == 0, (cname, bad.value)
+
+
+def test_ecntt_2_14_mixed_stage_plan_vs_reference(hip):
+    """2^14 points: the first size whose stage plan mixes radix-4 matrix-form stages with radix-2 ones under the 32768-quad budget
+    (ecntt.hip ecntt_run) -- forward, and inverse with a bit-reversed ordering and a coset, against the reference CPU backend"""
+    from icicle_amd import ntt as N
+
+    cname, logn = "bn254", 14
+    C, F = pyref.CURVES[cname], pyref.NTT_FIELDS[cname]
+    refc, sf = ref.RefCurve(cname), ref.RefScalarNttField(cname)
+    n, L = 1 << logn, C.limbs_q
+    root = N.get_root_of_unity(cname, n)
+    N.init_domain(cname, root)
+    sf.init_domain(root)
+    try:
+        base = refc.generate_affine_points(n)
+        x = np.ascontiguousarray(np.concatenate([base, np.tile(to_words([1], L), (n, 1))], axis=1).astype(np.uint32)).reshape(-1)
+        for direction, ordering, coset in ((0, 0, 1), (1, 2, 7)):
+            cfg = hip.NTTConfigU256.default()
+            cfg.ordering = ordering
+            cfg.set_coset_gen(coset)
+            got = N.ecntt(cname, x, direction, cfg)
+            exp = refc.ecntt(x, n, direction, ordering=ordering, coset_gen=coset)
+            assert np.array_equal(refc.to_affine(got.reshape(-1, 3 * L)), refc.to_affine(exp.reshape(-1, 3 * L))), (direction, ordering, coset)
+    finally:
+        N.release_domain(cname)
+        sf.release_domain()
